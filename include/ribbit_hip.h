@@ -1,0 +1,141 @@
+/*
+ * ribbit_hip.h -- C ABI of the MI355X (gfx950) implementation of ribbit's per-sequence
+ * shift-XOR tandem-repeat scan.
+ *
+ * The reference (SowpatiLab/ribbit @ 2024_10_08) has no plugin/FFI interface; its de-facto
+ * boundary is the set of free functions processSequence() calls (fasta_utils.cpp:59-250).
+ * Every entry point below names the reference interface it replaces.  All functions are
+ * plain C: pointers and sizes only, no C++ or torch types.  INTEGRATION.md shows the glue a
+ * ribbit maintainer would add to fasta_utils.cpp to call them.
+ *
+ * Conventions
+ *   - every call returns 0 on success or a negative RIBBIT_E_* code; ribbit_hip_last_error()
+ *     returns a human-readable message for the last failure on the calling thread;
+ *   - a handle is bound to one GPU and one HIP stream and is single-thread-affine;
+ *   - there is NO CPU fallback: if no gfx950 device is usable every call fails loudly;
+ *   - host arrays returned through `T **out` are owned by the handle and stay valid until the
+ *     next call that produces the same kind of output, or ribbit_hip_close();
+ *   - positions are 0-based sequence positions p (the reference stores p at bit L-1-p,
+ *     fasta_utils.cpp:93; that reversal is not part of this ABI).
+ */
+#ifndef RIBBIT_HIP_H
+#define RIBBIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RIBBIT_ABI_VERSION 1
+
+enum {
+    RIBBIT_OK = 0,
+    RIBBIT_E_ARG = -1,       /* bad argument */
+    RIBBIT_E_DEVICE = -2,    /* no usable gfx950 device / HIP runtime error */
+    RIBBIT_E_STATE = -3,     /* call made in the wrong order (e.g. scan before load) */
+    RIBBIT_E_NOMEM = -4,     /* host or device allocation failed */
+    RIBBIT_E_OVERFLOW = -5,  /* event buffer could not be grown far enough */
+    RIBBIT_E_INTERNAL = -6
+};
+
+/* seed ranks, global_variables.cpp:28-34 */
+enum { RIBBIT_RANK_P = 5, RIBBIT_RANK_Q = 4, RIBBIT_RANK_S = 3, RIBBIT_RANK_F = 2,
+       RIBBIT_RANK_C = 1, RIBBIT_RANK_A = 0, RIBBIT_RANK_N = -1 };
+
+/* Scan parameters: the reference's process-wide globals that the path reads
+ * (global_variables.h:29-34, ribbit.cpp:191,240-243, fasta_utils.cpp:165). */
+typedef struct RibbitScanParams {
+    int32_t min_motif;        /* MINIMUM_MLEN, -m (default 2) */
+    int32_t max_motif;        /* MAXIMUM_MLEN, -M (default 100) */
+    int32_t window_length;    /* 8  (ribbit.cpp:191) -- only 8 is supported */
+    int32_t subst_threshold;  /* 7  (ribbit.cpp:191) */
+    int32_t anchor_threshold; /* 6  (fasta_utils.cpp:165) */
+    int32_t anchor_length;    /* 3  (ribbit.cpp:191) */
+} RibbitScanParams;
+
+/* The tuple<int,int,int,int> every reference stage exchanges: (start, end, motif length, type). */
+typedef struct RibbitSeed { int32_t start, end, mlen, type; } RibbitSeed;
+
+/* One maximal run found by the perfect scan, before addSeedToSeedPositionsPerfect:
+ * [start, end) is a run of X_m one-bits over non-N bases; term says what closed it. */
+enum { RIBBIT_TERM_ZERO = 0, RIBBIT_TERM_N = 1, RIBBIT_TERM_EOS = 2 };
+typedef struct RibbitRun { int32_t start, end, mlen, term; } RibbitRun;
+
+/* One top-level addSeedToSeedPositions* call a reference scanner would make, in call order:
+ * pos is the scan position of the call (sequence length for the end-of-sequence flush). */
+typedef struct RibbitCall { int32_t pos, mlen, start, end; } RibbitCall;
+
+typedef struct RibbitHandle RibbitHandle;
+
+/* Fills *p with the reference defaults for -m min_motif -M max_motif. */
+void ribbit_scan_params_default(RibbitScanParams *p, int32_t min_motif, int32_t max_motif);
+
+const char *ribbit_hip_last_error(void);
+int ribbit_hip_abi_version(void);
+
+/* Number of usable gfx950 devices (0 if none; never initialises a device context). */
+int ribbit_hip_device_count(void);
+
+/* Open a handle on `device`.  Replaces the globals set up in main() (ribbit.cpp:237-243). */
+int ribbit_hip_open(const RibbitScanParams *params, int device, RibbitHandle **out);
+int ribbit_hip_close(RibbitHandle *h);
+
+/* Use an existing HIP stream (hipStream_t passed as void*) for all work; NULL = handle's own. */
+int ribbit_hip_set_stream(RibbitHandle *h, void *hip_stream);
+
+/*
+ * Load one FASTA record (ASCII bases, no newlines).  Replaces the 2-bit encode of
+ * fasta_utils.cpp:78-115: H2D copy + pack kernel -> device bit planes (left, right, N).
+ * The shift-XOR sweep of fasta_utils.cpp:117-122 is never materialised; each scan kernel
+ * recomputes X_s words in registers.
+ */
+int ribbit_hip_load_record(RibbitHandle *h, const char *ascii, int64_t length);
+/* Same, but the ASCII bases are already in device memory (length bytes at dev_ascii). */
+int ribbit_hip_load_record_device(RibbitHandle *h, const void *dev_ascii, int64_t length);
+
+/*
+ * Device hot loop of processShiftXORsPerfect (parse_perfect_shiftxor.cpp:173-223) without the
+ * addSeed merge: all maximal runs with length >= min(cutoff, 16), sorted by (mlen, start).
+ */
+int ribbit_hip_scan_perfect_runs(RibbitHandle *h, const RibbitRun **out, size_t *n);
+
+/*
+ * The addSeedToSeedPositionsPerfect calls processShiftXORsPerfect would make, in its call
+ * order (position-major, motif-minor, end-of-sequence flush last; cutoffs of :179,:193,:216).
+ */
+int ribbit_hip_perfect_calls(RibbitHandle *h, const RibbitCall **out, size_t *n);
+
+/*
+ * processShiftXORsPerfect (parse_perfect_shiftxor.h:10; called at fasta_utils.cpp:132):
+ * scan + addSeedToSeedPositionsPerfect -> seed_positions_perfect.
+ */
+int ribbit_hip_seeds_perfect(RibbitHandle *h, const RibbitSeed **out, size_t *n);
+
+/*
+ * Bits [start, end) of shift plane `shift` (X_shift, or the anchored plane once
+ * ribbit_hip_anchor_planes has run), one byte per base.  Replaces reads of
+ * lshift_xor_bsets[shift-MINIMUM_SHIFT][L-1-p] (fasta_utils.cpp:220-222, parse_seed.cpp:366).
+ */
+int ribbit_hip_plane_bits(RibbitHandle *h, int32_t shift, int64_t start, int64_t end, uint8_t *out);
+
+/* Popcount of plane `shift` over [start, end): the loop of retainNestedSeed /
+ * retainIdenticalSeeds (parse_perfect_shiftxor.cpp:18-43). */
+int ribbit_hip_range_popcount(RibbitHandle *h, int32_t shift, int64_t start, int64_t end, int32_t *count);
+
+/* Packed device planes copied back to the host (LSB-first: base p is bit p%32 of word p/32);
+ * each array holds ribbit_hip_plane_words() words.  which: 0 left bit, 1 right bit, 2 N mask. */
+int64_t ribbit_hip_plane_words(const RibbitHandle *h);
+int ribbit_hip_packed_plane(RibbitHandle *h, int which, uint32_t *out_words);
+
+/* Timing of the last call, milliseconds, measured with HIP events on the launch stream.
+ * what: 0 pack kernel, 1 perfect-scan kernel, 2 whole last API call (GPU side). */
+int ribbit_hip_last_timing_ms(const RibbitHandle *h, int what, double *ms);
+/* Number of raw device events (run starts + run ends) the last scan produced. */
+int64_t ribbit_hip_last_event_count(const RibbitHandle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

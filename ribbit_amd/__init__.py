@@ -1,0 +1,190 @@
+"""ribbit_amd -- MI355X-native implementation of ribbit's shift-XOR tandem-repeat scan.
+
+This module is only the Python face of the C ABI in include/ribbit_hip.h (ctypes, no torch
+types cross the boundary).  All compute happens in ribbit_amd/libribbit_hip.so (hand-written
+gfx950 kernels + C++ host logic).  There is no CPU fallback: importing works anywhere, but
+opening a scanner without the built library or without a gfx950 GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+__all__ = ["RibbitHipError", "ScanParams", "Scanner", "library_path", "load_library",
+           "RUN_DT", "CALL_DT", "SEED_DT", "RANK", "TERM"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+RANK = {"P": 5, "Q": 4, "S": 3, "F": 2, "C": 1, "A": 0, "N": -1}     # global_variables.cpp:28-34
+TERM = {"ZERO": 0, "N": 1, "EOS": 2}
+
+RUN_DT = np.dtype([("start", "<i4"), ("end", "<i4"), ("mlen", "<i4"), ("term", "<i4")])
+CALL_DT = np.dtype([("pos", "<i4"), ("mlen", "<i4"), ("start", "<i4"), ("end", "<i4")])
+SEED_DT = np.dtype([("start", "<i4"), ("end", "<i4"), ("mlen", "<i4"), ("type", "<i4")])
+
+# every symbol include/ribbit_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "ribbit_scan_params_default", "ribbit_hip_last_error", "ribbit_hip_abi_version",
+    "ribbit_hip_device_count", "ribbit_hip_open", "ribbit_hip_close", "ribbit_hip_set_stream",
+    "ribbit_hip_load_record", "ribbit_hip_load_record_device", "ribbit_hip_scan_perfect_runs",
+    "ribbit_hip_perfect_calls", "ribbit_hip_seeds_perfect", "ribbit_hip_plane_bits",
+    "ribbit_hip_range_popcount", "ribbit_hip_plane_words", "ribbit_hip_packed_plane",
+    "ribbit_hip_last_timing_ms", "ribbit_hip_last_event_count",
+]
+
+
+class RibbitHipError(RuntimeError):
+    pass
+
+
+class ScanParams(C.Structure):
+    """RibbitScanParams (ribbit.cpp:191,240-243; fasta_utils.cpp:165)."""
+    _fields_ = [("min_motif", C.c_int32), ("max_motif", C.c_int32), ("window_length", C.c_int32),
+                ("subst_threshold", C.c_int32), ("anchor_threshold", C.c_int32), ("anchor_length", C.c_int32)]
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libribbit_hip.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Load libribbit_hip.so; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RibbitHipError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(make -C ribbit_amd/csrc). ribbit_amd has no CPU fallback.")
+    L = C.CDLL(path)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.ribbit_scan_params_default.restype = None
+    L.ribbit_scan_params_default.argtypes = [C.POINTER(ScanParams), i32, i32]
+    L.ribbit_hip_last_error.restype = C.c_char_p
+    L.ribbit_hip_last_error.argtypes = []
+    L.ribbit_hip_abi_version.restype = C.c_int
+    L.ribbit_hip_device_count.restype = C.c_int
+    L.ribbit_hip_open.argtypes = [C.POINTER(ScanParams), C.c_int, C.POINTER(vp)]
+    L.ribbit_hip_close.argtypes = [vp]
+    L.ribbit_hip_set_stream.argtypes = [vp, vp]
+    L.ribbit_hip_load_record.argtypes = [vp, C.c_char_p, i64]
+    L.ribbit_hip_load_record_device.argtypes = [vp, vp, i64]
+    for f in ("ribbit_hip_scan_perfect_runs", "ribbit_hip_perfect_calls", "ribbit_hip_seeds_perfect"):
+        getattr(L, f).argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ribbit_hip_plane_bits.argtypes = [vp, i32, i64, i64, vp]
+    L.ribbit_hip_range_popcount.argtypes = [vp, i32, i64, i64, C.POINTER(i32)]
+    L.ribbit_hip_plane_words.restype = i64
+    L.ribbit_hip_plane_words.argtypes = [vp]
+    L.ribbit_hip_packed_plane.argtypes = [vp, C.c_int, vp]
+    L.ribbit_hip_last_timing_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    L.ribbit_hip_last_event_count.restype = i64
+    L.ribbit_hip_last_event_count.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _copy(ptr, n, dt):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dt)
+    buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dt).copy()
+
+
+class Scanner:
+    """One GPU-resident FASTA record and the scans over it.
+
+    Method names follow the reference functions they stand in for
+    (parse_perfect_shiftxor.h:10, fasta_utils.cpp:59-250).
+    """
+
+    def __init__(self, min_motif: int = 2, max_motif: int = 100, device: int = 0):
+        self._L = load_library()
+        self.params = ScanParams()
+        self._L.ribbit_scan_params_default(C.byref(self.params), min_motif, max_motif)
+        h = C.c_void_p()
+        self._h = None
+        self._check(self._L.ribbit_hip_open(C.byref(self.params), device, C.byref(h)))
+        self._h = h
+        self.length = 0
+        self.min_shift = min_motif - 2 if min_motif > 2 else 1     # ribbit.cpp:241
+        self.max_shift = max_motif + 2                              # ribbit.cpp:242
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RibbitHipError(f"ribbit_hip error {rc}: {self._L.ribbit_hip_last_error().decode()}")
+
+    def close(self):
+        if self._h is not None:
+            self._L.ribbit_hip_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream: int | None):
+        self._check(self._L.ribbit_hip_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    # fasta_utils.cpp:78-122 -------------------------------------------------------------
+    def load_record(self, sequence: bytes):
+        self._keep = bytes(sequence)
+        self.length = len(self._keep)
+        self._check(self._L.ribbit_hip_load_record(self._h, self._keep, self.length))
+
+    def load_record_device(self, dev_ptr: int, length: int):
+        self.length = int(length)
+        self._check(self._L.ribbit_hip_load_record_device(self._h, C.c_void_p(dev_ptr), self.length))
+
+    def _list(self, fn, dt):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(fn(self._h, C.byref(p), C.byref(n)))
+        return _copy(p.value, n.value, dt)
+
+    # parse_perfect_shiftxor.cpp:146-226 ---------------------------------------------------
+    def scan_perfect_runs(self):
+        return self._list(self._L.ribbit_hip_scan_perfect_runs, RUN_DT)
+
+    def perfect_calls(self):
+        return self._list(self._L.ribbit_hip_perfect_calls, CALL_DT)
+
+    def processShiftXORsPerfect(self):
+        return self._list(self._L.ribbit_hip_seeds_perfect, SEED_DT)
+
+    # plane access -----------------------------------------------------------------------
+    def plane_bits(self, shift: int, start: int = 0, end: int | None = None):
+        end = self.length if end is None else end
+        out = np.empty(max(end - start, 0), dtype=np.uint8)
+        self._check(self._L.ribbit_hip_plane_bits(self._h, shift, start, end, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def range_popcount(self, shift: int, start: int, end: int) -> int:
+        c = C.c_int32()
+        self._check(self._L.ribbit_hip_range_popcount(self._h, shift, start, end, C.byref(c)))
+        return c.value
+
+    def packed_plane(self, which: int):
+        n = self._L.ribbit_hip_plane_words(self._h)
+        out = np.empty(n, dtype=np.uint32)
+        self._check(self._L.ribbit_hip_packed_plane(self._h, which, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def timing_ms(self, what: int) -> float:
+        ms = C.c_double()
+        self._check(self._L.ribbit_hip_last_timing_ms(self._h, what, C.byref(ms)))
+        return ms.value
+
+    def last_event_count(self) -> int:
+        return int(self._L.ribbit_hip_last_event_count(self._h))

@@ -1,0 +1,457 @@
+// api.cpp -- extern "C" boundary of libribbit_hip.so (see include/ribbit_hip.h).
+// Device memory, streams and HIP-event timing live here; kernels are in kernels.hip and the
+// sequential seed-list logic in seed_lists.cpp.  There is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "device_planes.h"
+#include "kernels.h"
+#include "ribbit_hip.h"
+#include "seed_lists.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(RIBBIT_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;   // elements
+    int ensure(size_t n) {
+        if (n <= cap) return RIBBIT_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return fail(RIBBIT_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e)); }
+        cap = n;
+        return RIBBIT_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+template <typename T>
+struct PinnedBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return RIBBIT_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipHostMalloc((void **)&p, n * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return fail(RIBBIT_E_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e)); }
+        cap = n;
+        return RIBBIT_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct RibbitHandle {
+    RibbitScanParams params{};
+    int device = 0;
+    int min_shift = 1, max_shift = 102;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};        // 0/1 pack, 2/3 scan, 4/5 whole call
+    bool have_timing[3] = {false, false, false};
+
+    bool loaded = false;
+    int64_t length = 0;
+    int64_t ntiles = 0, total_words = 0, tail_words = 0;
+    DevBuf<uint8_t> d_ascii;
+    DevBuf<uint32_t> d_hi, d_lo, d_brk;
+    DevBuf<uint64_t> d_events;
+    DevBuf<uint32_t> d_counters;
+    DevBuf<uint32_t> d_query;
+    PinnedBuf<uint64_t> h_events;
+    PinnedBuf<uint32_t> h_counters;
+    PinnedBuf<uint32_t> h_query;
+
+    int64_t last_event_count = 0;
+    bool runs_valid = false, calls_valid = false, seeds_perfect_valid = false;
+    std::vector<RibbitRun> runs;
+    std::vector<RibbitCall> perfect_calls;
+    rb::SeedLists lists;
+
+    rb::DevicePlanes planes() const {
+        rb::DevicePlanes pl;
+        pl.hi = d_hi.p + rb::LEAD_WORDS;
+        pl.lo = d_lo.p + rb::LEAD_WORDS;
+        pl.brk = d_brk.p + rb::LEAD_WORDS;
+        pl.length = length;
+        pl.ntiles = ntiles;
+        pl.tail_words = tail_words;
+        return pl;
+    }
+};
+
+namespace {
+
+int bind_device(const RibbitHandle *h) {
+    HIP_TRY(hipSetDevice(h->device));
+    return RIBBIT_OK;
+}
+
+int is_gfx950(int device) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+    return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+int pack_loaded_ascii(RibbitHandle *h, const uint8_t *dev_ascii, int64_t length) {
+    h->loaded = false;
+    h->runs_valid = h->calls_valid = h->seeds_perfect_valid = false;
+    h->length = length;
+    const int64_t nwords = length / 32 + 1;   // word holding position L is included
+    h->ntiles = (nwords + rb::TILE_WORDS - 1) / rb::TILE_WORDS;
+    h->tail_words = h->max_shift / 32 + rb::TAIL_SLACK_WORDS;
+    h->total_words = rb::LEAD_WORDS + h->ntiles * rb::TILE_WORDS + h->tail_words;
+    int rc;
+    if ((rc = h->d_hi.ensure((size_t)h->total_words))) return rc;
+    if ((rc = h->d_lo.ensure((size_t)h->total_words))) return rc;
+    if ((rc = h->d_brk.ensure((size_t)h->total_words))) return rc;
+    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    rb::launch_pack(dev_ascii, length, h->d_hi.p, h->d_lo.p, h->d_brk.p, h->total_words, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    h->have_timing[0] = true;
+    h->lists = rb::SeedLists{};
+    h->lists.length = length;
+    h->lists.min_motif = h->params.min_motif;
+    h->lists.max_motif = h->params.max_motif;
+    h->lists.min_shift = h->min_shift;
+    h->loaded = true;
+    return RIBBIT_OK;
+}
+
+// c1 / c2 of parse_perfect_shiftxor.cpp:193 / :179
+inline int cutoff_zero(int m) { return (m <= 6) ? 12 - m : m; }
+inline int cutoff_n(int m, int min_shift) { return (m <= 6) ? 12 - m : m + (m - min_shift); }
+
+int run_perfect_scan(RibbitHandle *h) {
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    if (h->runs_valid) return RIBBIT_OK;
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    h->runs.clear();
+    if ((rc = h->d_counters.ensure(16))) return rc;
+    if ((rc = h->h_counters.ensure(16))) return rc;
+    size_t cap = std::max<size_t>((size_t)1 << 20, (size_t)(h->length / 4));
+    if (h->d_events.cap > cap) cap = h->d_events.cap;
+    const rb::DevicePlanes pl = h->planes();
+    uint32_t produced = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if ((rc = h->d_events.ensure(cap))) return rc;
+        HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, 16 * sizeof(uint32_t), h->stream));
+        rb::PerfectLaunch pp;
+        pp.m_lo = h->params.min_motif;
+        pp.m_hi = h->params.max_motif;
+        pp.ev_cap = (uint32_t)std::min<size_t>(h->d_events.cap, 0xffffffffu);
+        HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+        rb::launch_scan_perfect(pl, pp, h->d_events.p, h->d_counters.p, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+        HIP_TRY(hipMemcpyAsync(h->h_counters.p, h->d_counters.p, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        produced = h->h_counters.p[0];
+        if (produced <= pp.ev_cap) break;
+        if (attempt == 2) return fail(RIBBIT_E_OVERFLOW, "event buffer overflow: %u events", produced);
+        cap = (size_t)produced + 1024;
+    }
+    h->last_event_count = produced;
+    if ((rc = h->h_events.ensure(std::max<size_t>(produced, 1)))) return rc;
+    if (produced) {
+        HIP_TRY(hipMemcpyAsync(h->h_events.p, h->d_events.p, (size_t)produced * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipEventRecord(h->ev[5], h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->have_timing[1] = h->have_timing[2] = true;
+
+    // Events arrive as position-ordered chunks, one per (motif, tile) with any event.  Order the
+    // chunks by (motif, tile), then pair START/END within each motif.
+    struct Chunk { uint32_t mlen, tile; size_t off, n; };
+    std::vector<Chunk> chunks;
+    const uint64_t *ev = h->h_events.p;
+    for (size_t i = 0; i < produced;) {
+        const uint32_t m = rb::ev_mlen(ev[i]);
+        const uint32_t tile = rb::ev_pos(ev[i]) / (uint32_t)rb::TILE_BASES;
+        size_t j = i + 1;
+        while (j < produced && rb::ev_mlen(ev[j]) == m && rb::ev_pos(ev[j]) / (uint32_t)rb::TILE_BASES == tile &&
+               rb::ev_pos(ev[j]) > rb::ev_pos(ev[j - 1]))
+            ++j;
+        chunks.push_back(Chunk{m, tile, i, j - i});
+        i = j;
+    }
+    std::sort(chunks.begin(), chunks.end(), [](const Chunk &a, const Chunk &b) {
+        return a.mlen != b.mlen ? a.mlen < b.mlen : a.tile < b.tile;
+    });
+    int64_t open = -1;
+    uint32_t cur_m = 0;
+    for (const Chunk &c : chunks) {
+        if (c.mlen != cur_m) {
+            if (open != -1) return fail(RIBBIT_E_INTERNAL, "unterminated run for motif %u", cur_m);
+            cur_m = c.mlen;
+        }
+        for (size_t i = c.off; i < c.off + c.n; ++i) {
+            const uint32_t kind = rb::ev_kind(ev[i]);
+            const int64_t pos = rb::ev_pos(ev[i]);
+            if (kind == rb::EV_START) {
+                if (open != -1) return fail(RIBBIT_E_INTERNAL, "two run starts in a row (motif %u, pos %lld)", cur_m, (long long)pos);
+                open = pos;
+            } else {
+                if (open == -1) return fail(RIBBIT_E_INTERNAL, "run end without start (motif %u, pos %lld)", cur_m, (long long)pos);
+                const int term = kind == rb::EV_END_ZERO ? RIBBIT_TERM_ZERO : kind == rb::EV_END_N ? RIBBIT_TERM_N : RIBBIT_TERM_EOS;
+                h->runs.push_back(RibbitRun{(int32_t)open, (int32_t)pos, (int32_t)cur_m, term});
+                open = -1;
+            }
+        }
+    }
+    if (open != -1) return fail(RIBBIT_E_INTERNAL, "unterminated run for motif %u", cur_m);
+    h->runs_valid = true;
+    return RIBBIT_OK;
+}
+
+int build_perfect_calls(RibbitHandle *h) {
+    if (h->calls_valid) return RIBBIT_OK;
+    int rc = run_perfect_scan(h);
+    if (rc) return rc;
+    h->perfect_calls.clear();
+    const int32_t L = (int32_t)h->length;
+    for (const RibbitRun &r : h->runs) {
+        const int len = r.end - r.start;
+        if (r.term == RIBBIT_TERM_ZERO) {                       // parse_perfect_shiftxor.cpp:199-205
+            if (len >= cutoff_zero(r.mlen)) h->perfect_calls.push_back(RibbitCall{r.end, r.mlen, r.start, r.end});
+        } else if (r.term == RIBBIT_TERM_N) {                   // :175-186
+            if (len >= cutoff_n(r.mlen, h->min_shift)) h->perfect_calls.push_back(RibbitCall{r.end, r.mlen, r.start, r.end});
+        } else {                                                // :213-223, flushed with end = L-1
+            if ((L - 1) - r.start >= cutoff_zero(r.mlen)) h->perfect_calls.push_back(RibbitCall{L, r.mlen, r.start, L - 1});
+        }
+    }
+    std::stable_sort(h->perfect_calls.begin(), h->perfect_calls.end(), [](const RibbitCall &a, const RibbitCall &b) {
+        return a.pos != b.pos ? a.pos < b.pos : a.mlen < b.mlen;
+    });
+    h->calls_valid = true;
+    return RIBBIT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ribbit_scan_params_default(RibbitScanParams *p, int32_t min_motif, int32_t max_motif) {
+    if (!p) return;
+    p->min_motif = min_motif;
+    p->max_motif = max_motif;
+    p->window_length = 8;
+    p->subst_threshold = 7;
+    p->anchor_threshold = 6;
+    p->anchor_length = 3;
+}
+
+const char *ribbit_hip_last_error(void) { return g_last_error.c_str(); }
+int ribbit_hip_abi_version(void) { return RIBBIT_ABI_VERSION; }
+
+int ribbit_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; ++d) ok += is_gfx950(d);
+    return ok;
+}
+
+int ribbit_hip_open(const RibbitScanParams *params, int device, RibbitHandle **out) {
+    if (!params || !out) return fail(RIBBIT_E_ARG, "null argument");
+    *out = nullptr;
+    if (params->min_motif < 1 || params->max_motif < params->min_motif || params->max_motif > 990)
+        return fail(RIBBIT_E_ARG, "motif range [%d,%d] not supported (1 <= m <= M <= 990)", params->min_motif, params->max_motif);
+    if (params->window_length != 8) return fail(RIBBIT_E_ARG, "window_length must be 8");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(RIBBIT_E_DEVICE, "no HIP device available (%s); ribbit_amd has no CPU fallback", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(RIBBIT_E_ARG, "device %d out of range (0..%d)", device, n - 1);
+    if (!is_gfx950(device)) return fail(RIBBIT_E_DEVICE, "device %d is not gfx950 (MI355X); kernels are built for gfx950 only", device);
+    RibbitHandle *h = new (std::nothrow) RibbitHandle();
+    if (!h) return fail(RIBBIT_E_NOMEM, "out of host memory");
+    h->params = *params;
+    h->device = device;
+    h->min_shift = (params->min_motif > 2) ? params->min_motif - 2 : 1;   // ribbit.cpp:241
+    h->max_shift = params->max_motif + 2;                                   // ribbit.cpp:242
+    hipError_t err = hipSetDevice(device);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 6 && err == hipSuccess; ++i) err = hipEventCreate(&h->ev[i]);
+    if (err != hipSuccess) {
+        delete h;
+        return fail(RIBBIT_E_DEVICE, "device setup failed: %s", hipGetErrorString(err));
+    }
+    h->stream = h->own_stream;
+    *out = h;
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_close(RibbitHandle *h) {
+    if (!h) return RIBBIT_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->d_ascii.release(); h->d_hi.release(); h->d_lo.release(); h->d_brk.release();
+    h->d_events.release(); h->d_counters.release(); h->d_query.release();
+    h->h_events.release(); h->h_counters.release(); h->h_query.release();
+    for (int i = 0; i < 6; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_set_stream(RibbitHandle *h, void *hip_stream) {
+    if (!h) return fail(RIBBIT_E_ARG, "null handle");
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_load_record(RibbitHandle *h, const char *ascii, int64_t length) {
+    if (!h || (!ascii && length > 0)) return fail(RIBBIT_E_ARG, "null argument");
+    if (length < 0 || length >= ((int64_t)1 << 31) - 64) return fail(RIBBIT_E_ARG, "record length %lld not supported (positions are int32, fasta_utils.cpp:78)", (long long)length);
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    if ((rc = h->d_ascii.ensure((size_t)std::max<int64_t>(length, 16)))) return rc;
+    if (length) HIP_TRY(hipMemcpyAsync(h->d_ascii.p, ascii, (size_t)length, hipMemcpyHostToDevice, h->stream));
+    return pack_loaded_ascii(h, h->d_ascii.p, length);
+}
+
+int ribbit_hip_load_record_device(RibbitHandle *h, const void *dev_ascii, int64_t length) {
+    if (!h || (!dev_ascii && length > 0)) return fail(RIBBIT_E_ARG, "null argument");
+    if (length < 0 || length >= ((int64_t)1 << 31) - 64) return fail(RIBBIT_E_ARG, "record length %lld not supported", (long long)length);
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    return pack_loaded_ascii(h, (const uint8_t *)dev_ascii, length);
+}
+
+int ribbit_hip_scan_perfect_runs(RibbitHandle *h, const RibbitRun **out, size_t *n) {
+    if (!h || !out || !n) return fail(RIBBIT_E_ARG, "null argument");
+    h->runs_valid = false;   // an explicit scan call always relaunches the kernel
+    h->calls_valid = h->seeds_perfect_valid = false;
+    int rc = run_perfect_scan(h);
+    if (rc) return rc;
+    *out = h->runs.data();
+    *n = h->runs.size();
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_perfect_calls(RibbitHandle *h, const RibbitCall **out, size_t *n) {
+    if (!h || !out || !n) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    int rc = build_perfect_calls(h);
+    if (rc) return rc;
+    *out = h->perfect_calls.data();
+    *n = h->perfect_calls.size();
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_seeds_perfect(RibbitHandle *h, const RibbitSeed **out, size_t *n) {
+    if (!h || !out || !n) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    if (!h->seeds_perfect_valid) {
+        int rc = build_perfect_calls(h);
+        if (rc) return rc;
+        h->lists.perfect.clear();
+        for (const RibbitCall &c : h->perfect_calls) rb::perfect_add(h->lists, c.start, c.end, c.mlen);
+        h->seeds_perfect_valid = true;
+    }
+    *out = h->lists.perfect.data();
+    *n = h->lists.perfect.size();
+    return RIBBIT_OK;
+}
+
+static int query_plane(RibbitHandle *h, int32_t shift, int64_t start, int64_t end, bool want_words, uint32_t *count_out) {
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    if (shift < h->min_shift || shift > h->max_shift) return fail(RIBBIT_E_ARG, "shift %d outside [%d,%d]", shift, h->min_shift, h->max_shift);
+    if (start < 0 || end > h->length || start > end) return fail(RIBBIT_E_ARG, "range [%lld,%lld) outside the record", (long long)start, (long long)end);
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    const int64_t w0 = start / 32, w1 = (end + 31) / 32;
+    const int64_t nw = w1 - w0;
+    if (count_out) *count_out = 0;
+    if (nw <= 0) return RIBBIT_OK;
+    if ((rc = h->d_query.ensure((size_t)nw + 16))) return rc;
+    if ((rc = h->h_query.ensure((size_t)nw + 16))) return rc;
+    uint32_t *d_count = h->d_query.p + nw;
+    HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), h->stream));
+    rb::launch_plane_words(h->planes(), shift, w0, nw, want_words ? h->d_query.p : nullptr, start, end, d_count, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->h_query.p, h->d_query.p, ((size_t)nw + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (count_out) *count_out = h->h_query.p[nw];
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_plane_bits(RibbitHandle *h, int32_t shift, int64_t start, int64_t end, uint8_t *out) {
+    if (!h || (!out && end > start)) return fail(RIBBIT_E_ARG, "null argument");
+    int rc = query_plane(h, shift, start, end, true, nullptr);
+    if (rc) return rc;
+    const int64_t w0 = start / 32;
+    for (int64_t p = start; p < end; ++p) out[p - start] = (h->h_query.p[p / 32 - w0] >> (p & 31)) & 1u;
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_range_popcount(RibbitHandle *h, int32_t shift, int64_t start, int64_t end, int32_t *count) {
+    if (!h || !count) return fail(RIBBIT_E_ARG, "null argument");
+    uint32_t c = 0;
+    int rc = query_plane(h, shift, start, end, false, &c);
+    if (rc) return rc;
+    *count = (int32_t)c;
+    return RIBBIT_OK;
+}
+
+int64_t ribbit_hip_plane_words(const RibbitHandle *h) { return h && h->loaded ? h->length / 32 + 1 : 0; }
+
+int ribbit_hip_packed_plane(RibbitHandle *h, int which, uint32_t *out_words) {
+    if (!h || !out_words) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    if (which < 0 || which > 2) return fail(RIBBIT_E_ARG, "which must be 0, 1 or 2");
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    const uint32_t *src = (which == 0 ? h->d_hi.p : which == 1 ? h->d_lo.p : h->d_brk.p) + rb::LEAD_WORDS;
+    const size_t n = (size_t)(h->length / 32 + 1);
+    HIP_TRY(hipMemcpyAsync(out_words, src, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_last_timing_ms(const RibbitHandle *h, int what, double *ms) {
+    if (!h || !ms) return fail(RIBBIT_E_ARG, "null argument");
+    if (what < 0 || what > 2) return fail(RIBBIT_E_ARG, "what must be 0, 1 or 2");
+    if (!h->have_timing[what]) return fail(RIBBIT_E_STATE, "no timing recorded yet");
+    float f = 0.f;
+    HIP_TRY(hipEventSynchronize(h->ev[2 * what + 1]));
+    HIP_TRY(hipEventElapsedTime(&f, h->ev[2 * what], h->ev[2 * what + 1]));
+    *ms = f;
+    return RIBBIT_OK;
+}
+
+int64_t ribbit_hip_last_event_count(const RibbitHandle *h) { return h ? h->last_event_count : 0; }
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// device_planes.h -- HBM layout shared by all ribbit_amd kernels (gfx950 only).
+//
+// A record of L bases is held as three bit planes of 32-bit words, LSB first: base p is
+// bit (p & 31) of word (p >> 5).
+//   hi  = left bit of the 2-bit code   (fasta_utils.cpp:94-114: A 00, C 01, G 10, T 11)
+//   lo  = right bit
+//   brk = "break" mask: 1 for N (any non-ACGT byte), for every position >= L and for the
+//         lead padding (positions < 0).  hi/lo are 0 wherever brk is 1, which reproduces both
+//         the reference's N-encodes-as-A rule and Boost's zero fill of `bitset << s`.
+// Each plane is allocated as LEAD_WORDS + nwords_padded words; kernels receive pointers that
+// are already advanced by LEAD_WORDS, so index -1 is valid.  Tiles: one wavefront owns
+// 64 lanes x WORDS_PER_LANE consecutive words (lane-contiguous, so cross-word funnel shifts
+// stay inside a lane).
+#pragma once
+#include <stdint.h>
+
+namespace rb {
+
+constexpr int WORDS_PER_LANE = 8;
+constexpr int TILE_WORDS = 64 * WORDS_PER_LANE;   // 512 words = 16384 bases per wave tile
+constexpr int TILE_BASES = TILE_WORDS * 32;
+constexpr int LEAD_WORDS = 8;
+constexpr int TAIL_SLACK_WORDS = 8;
+
+struct DevicePlanes {
+    const uint32_t *hi;
+    const uint32_t *lo;
+    const uint32_t *brk;
+    int64_t length;       // L
+    int64_t ntiles;       // tiles covering words 0 .. L/32 (position L included)
+    int64_t tail_words;   // words readable past ntiles*TILE_WORDS
+};
+
+// raw device event: one transition of a per-motif bitmap
+//   bits  0..31 position, 32..47 motif length, 48..51 kind
+enum : uint32_t { EV_START = 0, EV_END_ZERO = 1, EV_END_N = 2, EV_END_EOS = 3 };
+
+__host__ __device__ inline uint64_t ev_pack(uint32_t pos, uint32_t mlen, uint32_t kind) {
+    return (uint64_t)pos | ((uint64_t)mlen << 32) | ((uint64_t)kind << 48);
+}
+inline uint32_t ev_pos(uint64_t e) { return (uint32_t)e; }
+inline uint32_t ev_mlen(uint64_t e) { return (uint32_t)(e >> 32) & 0xffffu; }
+inline uint32_t ev_kind(uint64_t e) { return (uint32_t)(e >> 48) & 0xfu; }
+
+}  // namespace rb

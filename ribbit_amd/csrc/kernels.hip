@@ -1,0 +1,274 @@
+// kernels.hip -- hand-written CDNA4 (gfx950) kernels for ribbit's shift-XOR scan.
+//
+// Integer/bit work only: no MFMA.  The binding resource is 32-bit VALU issue, so the design
+// minimises VALU ops per (32-base word, motif):
+//   * a wavefront owns a tile of 64 lanes x WORDS_PER_LANE consecutive words; every lane keeps
+//     its words of the hi/lo/brk planes in registers for the whole motif loop;
+//   * the shifted operand for shift s = 32q + r is one v_alignbit per word from a second
+//     register set holding the words at offset q, reloaded from LDS only when q changes
+//     (once per 32 shifts), so the sweep X_s = ~(H ^ H>>s) & ~(L ^ L>>s) of
+//     fasta_utils.cpp:117-122 costs 5 VALU ops per word and no memory traffic;
+//   * runs are found with OR-doubling funnel shifts inside a lane (neighbour words are in the
+//     same lane; one halo word each side), and only the rare qualified run STARTs and ENDs are
+//     written out, compacted in position order with a wave prefix sum.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace rb {
+
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh) {
+    // ({hi,lo} >> (sh & 31))[31:0]  -> v_alignbit_b32
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+
+// ---------------------------------------------------------------------------------- pack
+// fasta_utils.cpp:90-115: A/a 00, C/c 01, G/g 10, T/t 11, anything else -> N (code 00).
+// One thread produces one 32-base word of each plane.
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii, int64_t length,
+                                                   uint32_t *__restrict__ hi, uint32_t *__restrict__ lo,
+                                                   uint32_t *__restrict__ brk, int64_t total_words) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_words) return;
+    const int64_t p0 = (t - LEAD_WORDS) * 32;
+    uint32_t h = 0, l = 0, b = 0xffffffffu;
+    if (p0 >= 0 && p0 < length) {
+        uint32_t w[8];
+        const int64_t left = length - p0;
+        const uint8_t *src = ascii + p0;
+        if (left >= 32 && (((uintptr_t)src) & 15) == 0) {
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(src);
+            const uint4 v1 = *reinterpret_cast<const uint4 *>(src + 16);
+            w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
+            w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int idx = 4 * i + k;
+                    const uint32_t c = (idx < left) ? (uint32_t)src[idx] : (uint32_t)'N';
+                    x |= c << (8 * k);
+                }
+                w[i] = x;
+            }
+        }
+        b = 0;
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const uint32_t c = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
+            const uint32_t u = c | 0x20u;
+            const uint32_t valid = (u == 'a') | (u == 'c') | (u == 'g') | (u == 't');
+            const uint32_t code = ((c >> 1) & 3u) ^ ((c >> 2) & 1u);   // a 0, c 1, g 2, t 3
+            h |= (valid & (code >> 1)) << i;
+            l |= (valid & code & 1u) << i;
+            b |= (valid ^ 1u) << i;
+        }
+        if (left < 32) b |= 0xffffffffu << (uint32_t)left;   // positions >= L break every run
+    }
+    hi[t] = h; lo[t] = l; brk[t] = b;
+}
+
+void launch_pack(const uint8_t *dev_ascii, int64_t length, uint32_t *hi, uint32_t *lo, uint32_t *brk,
+                 int64_t total_words, hipStream_t stream) {
+    const int threads = 256;
+    const int64_t blocks = (total_words + threads - 1) / threads;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream, dev_ascii, length, hi, lo, brk,
+                       total_words);
+}
+
+// -------------------------------------------------------------------------- perfect scan
+constexpr int K = WORDS_PER_LANE;
+constexpr int LDS_EXTRA = 40;   // halo + shifted-operand words (supports shifts < 1024)
+
+// Hot loop of processShiftXORsPerfect (parse_perfect_shiftxor.cpp:173-223).
+// For motif m the reference walks maximal runs of X_m ones over non-N bases.  With
+// Z = mismatch | brk those are maximal zero runs of Z.  The run-length cut-offs are
+// c1 = (m<=6 ? 12-m : m) for a run closed by a mismatch (:193) and >= c1 otherwise (:179),
+// so only runs of at least sp = min(c1, 16) zeros can matter; the host applies the exact
+// cut-off.  Per lane and motif:
+//   D[p]  = OR of Z[p .. p+sp-1]          (3-4 OR-doubling funnel steps)
+//   START = Z[p-1] & ~D[p]                 run of >= sp zeros begins at p
+//   END   = Z[p]  & ~D[p-sp]               run of >= sp zeros ends just before p
+// Every qualifying run yields exactly one START and one END (position L for an open run,
+// because brk is 1 from L on), so the host pairs them without any device-side walk.
+__global__ __launch_bounds__(256) void scan_perfect_kernel(DevicePlanes pl, PerfectLaunch pp, int motifs_per_block,
+                                                           uint64_t *__restrict__ events,
+                                                           uint32_t *__restrict__ counters) {
+    __shared__ uint32_t s_hi[TILE_WORDS + LDS_EXTRA];
+    __shared__ uint32_t s_lo[TILE_WORDS + LDS_EXTRA];
+    __shared__ uint32_t s_brk[TILE_WORDS + 8];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t tile_base = (int64_t)blockIdx.x * TILE_WORDS;   // first word owned by this block
+
+    const int bm_lo = pp.m_lo + (int)blockIdx.y * motifs_per_block;
+    const int bm_hi = min(pp.m_hi, bm_lo + motifs_per_block - 1);
+    const int q_hi = bm_hi >> 5;
+
+    // stage words [tile_base-1, tile_base+TILE_WORDS+3+q_hi) : coalesced dword loads, shared by 4 waves
+    const int n_ext = TILE_WORDS + 4 + q_hi;
+    for (int i = threadIdx.x; i < n_ext; i += 256) {
+        s_hi[i] = pl.hi[tile_base - 1 + i];
+        s_lo[i] = pl.lo[tile_base - 1 + i];
+    }
+    for (int i = threadIdx.x; i < TILE_WORDS + 2; i += 256) s_brk[i] = pl.brk[tile_base - 1 + i];
+    __syncthreads();
+
+    // the block's motif range is split over its 4 waves: one wavefront per (tile, motif group)
+    const int nmb = bm_hi - bm_lo + 1;
+    const int per = (nmb + 3) >> 2;
+    const int wm_lo = bm_lo + wave * per;
+    const int wm_hi = min(bm_hi, wm_lo + per - 1);
+    if (wm_lo > wm_hi) return;
+
+    const int lb = lane * K;   // LDS index of word k = -1 of this lane
+    uint32_t H[K + 2], Lo[K + 2], Bk[K + 2];
+#pragma unroll
+    for (int j = 0; j < K + 2; j++) { H[j] = s_hi[lb + j]; Lo[j] = s_lo[lb + j]; Bk[j] = s_brk[lb + j]; }
+
+    uint32_t Hq[K + 3], Lq[K + 3];
+    int cur_q = -1;
+    const uint32_t length = (uint32_t)pl.length;
+    const uint32_t word0 = (uint32_t)(tile_base + lb);   // global index of own word k = 0
+
+    for (int m = wm_lo; m <= wm_hi; ++m) {
+        const int q = m >> 5;
+        const uint32_t r = (uint32_t)m & 31u;
+        if (q != cur_q) {
+            cur_q = q;
+#pragma unroll
+            for (int j = 0; j < K + 3; j++) { Hq[j] = s_hi[lb + j + q]; Lq[j] = s_lo[lb + j + q]; }
+        }
+        const int c1 = (m <= 6) ? 12 - m : m;
+        const int sp = min(c1, 16);
+        const uint32_t t3 = (uint32_t)min(4, sp - 4);
+        const uint32_t t4 = (uint32_t)(sp - 4) - t3;
+
+        // Z = mismatch | break, words k = -1 .. K
+        uint32_t Z[K + 2], D[K + 2];
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) {
+            const uint32_t hs = funnel(Hq[j + 1], Hq[j], r);
+            const uint32_t ls = funnel(Lq[j + 1], Lq[j], r);
+            Z[j] = ((H[j] ^ hs) | (Lo[j] ^ ls)) | Bk[j];
+        }
+        // OR-doubling towards higher positions: spans 2, 4, 4+t3, 4+t3+t4 = sp
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) D[j] = Z[j] | funnel(Z[j + 1], Z[j], 1);
+        D[K + 1] = Z[K + 1] | (Z[K + 1] >> 1);
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) D[j] = D[j] | funnel(D[j + 1], D[j], 2);
+        D[K + 1] = D[K + 1] | (D[K + 1] >> 2);
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) D[j] = D[j] | funnel(D[j + 1], D[j], t3);
+        D[K + 1] = D[K + 1] | (D[K + 1] >> t3);
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) D[j] = D[j] | funnel(D[j + 1], D[j], t4);
+
+        uint32_t SQ[K], EQ[K];
+        uint32_t any = 0;
+        const uint32_t back = 32u - (uint32_t)sp;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int j = k + 1;
+            const uint32_t prev_z = funnel(Z[j], Z[j - 1], 31);      // bit b = Z at position b-1
+            const uint32_t d_back = funnel(D[j], D[j - 1], back);    // bit b = D at position b-sp
+            SQ[k] = prev_z & ~D[j];
+            EQ[k] = Z[j] & ~d_back;
+            any |= SQ[k] | EQ[k];
+        }
+
+        if (__ballot(any != 0) != 0ull) {
+            // rare path: compact this wave's events in position order
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++) cnt += __popc(SQ[k]) + __popc(EQ[k]);
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            const int total = __shfl(incl, 63);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&counters[0], (uint32_t)total);
+            base = __shfl(base, 0);
+            uint32_t idx = base + (uint32_t)(incl - cnt);
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                uint32_t both = SQ[k] | EQ[k];
+                while (both) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(both);
+                    both &= both - 1u;
+                    const uint32_t pos = ((word0 + (uint32_t)k) << 5) + b;
+                    uint32_t kind;
+                    if ((SQ[k] >> b) & 1u) kind = EV_START;
+                    else if (pos >= length) kind = EV_END_EOS;
+                    else if ((Bk[k + 1] >> b) & 1u) kind = EV_END_N;
+                    else kind = EV_END_ZERO;
+                    if (idx < pp.ev_cap) events[idx] = ev_pack(pos, (uint32_t)m, kind);
+                    idx++;
+                }
+            }
+        }
+    }
+}
+
+void launch_scan_perfect(const DevicePlanes &pl, const PerfectLaunch &pp, uint64_t *events, uint32_t *counters,
+                         hipStream_t stream) {
+    const int nm = pp.m_hi - pp.m_lo + 1;
+    if (nm <= 0 || pl.ntiles <= 0) return;
+    // fill the chip: >= ~2048 blocks when the record is short, by splitting the motif range
+    int64_t want_y = (2048 + pl.ntiles - 1) / pl.ntiles;
+    int max_y = (nm + 3) / 4;              // at least one motif per wave
+    int gy = (int)(want_y < 1 ? 1 : (want_y > max_y ? max_y : want_y));
+    int motifs_per_block = (nm + gy - 1) / gy;
+    gy = (nm + motifs_per_block - 1) / motifs_per_block;
+    dim3 grid((unsigned)pl.ntiles, (unsigned)gy);
+    hipLaunchKernelGGL(scan_perfect_kernel, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, events, counters);
+}
+
+// ------------------------------------------------------------------- plane query (a5, a13)
+// X_shift words for host-side range reads: retainNestedSeed / retainIdenticalSeeds
+// (parse_perfect_shiftxor.cpp:18-43) and the seed bit extraction of fasta_utils.cpp:220-222.
+__global__ __launch_bounds__(256) void plane_words_kernel(DevicePlanes pl, int shift, int64_t w0, int64_t nw,
+                                                          uint32_t *__restrict__ out_words, int64_t p0, int64_t p1,
+                                                          uint32_t *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bits = 0;
+    if (i < nw) {
+        const int64_t w = w0 + i;
+        const int q = shift >> 5;
+        const uint32_t r = (uint32_t)shift & 31u;
+        const uint32_t hs = funnel(pl.hi[w + q + 1], pl.hi[w + q], r);
+        const uint32_t ls = funnel(pl.lo[w + q + 1], pl.lo[w + q], r);
+        const uint32_t x = ~((pl.hi[w] ^ hs) | (pl.lo[w] ^ ls));
+        if (out_words) out_words[i] = x;
+        if (count) {
+            // mask to [p0, p1)
+            const int64_t lo_p = w * 32, hi_p = lo_p + 32;
+            uint32_t mask = 0xffffffffu;
+            if (p0 > lo_p) mask &= (p0 >= hi_p) ? 0u : (0xffffffffu << (uint32_t)(p0 - lo_p));
+            if (p1 < hi_p) mask &= (p1 <= lo_p) ? 0u : (0xffffffffu >> (uint32_t)(hi_p - p1));
+            bits = (uint32_t)__popc(x & mask);
+        }
+    }
+    if (count) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) bits += __shfl_down(bits, d);
+        if ((threadIdx.x & 63) == 0 && bits) atomicAdd(count, bits);
+    }
+}
+
+void launch_plane_words(const DevicePlanes &pl, int shift, int64_t w0, int64_t nw, uint32_t *out_words, int64_t p0,
+                        int64_t p1, uint32_t *count, hipStream_t stream) {
+    if (nw <= 0) return;
+    const int64_t blocks = (nw + 255) / 256;
+    hipLaunchKernelGGL(plane_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, pl, shift, w0, nw, out_words,
+                       p0, p1, count);
+}
+
+}  // namespace rb

@@ -1,0 +1,29 @@
+// seed_lists.h -- host half of the scanners: the order-dependent seed-list merges that the
+// reference runs inside processShiftXORs* (sparse, sequential, recursive: they stay on the host,
+// SURVEY.md 8a rows a4/a7/a11).  Product code: must never include anything from oracle/.
+#pragma once
+#include <stdint.h>
+
+#include <functional>
+#include <vector>
+
+#include "ribbit_hip.h"
+
+namespace rb {
+
+// popcount of plane `shift` over [start, end)  (retainNestedSeed's loop); supplied by the caller
+// so that this file has no device dependency (the API layer passes a GPU query).
+using RangeCount = std::function<int(int shift, int start, int end)>;
+
+struct SeedLists {
+    int64_t length = 0;       // bset_size
+    int min_motif = 2, max_motif = 100, min_shift = 1;
+    std::vector<RibbitSeed> perfect, subst, anchored;
+    RangeCount range_count;
+    int64_t guard_hits = 0;   // defined-divergence guards
+};
+
+// addSeedToSeedPositionsPerfect, parse_perfect_shiftxor.cpp:47-142
+void perfect_add(SeedLists &sl, int seed_start, int seed_end, int mlen);
+
+}  // namespace rb

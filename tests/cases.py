@@ -1,0 +1,50 @@
+"""Seeded inputs shared by the CPU (oracle) and GPU parity tests."""
+import numpy as np
+
+from ribbit_amd.simulate import random_sequence, simulate_sequence
+
+
+def _rand(n, seed, alphabet=b"ACGT"):
+    rs = np.random.RandomState(seed)
+    return bytes(np.frombuffer(alphabet, dtype=np.uint8)[rs.randint(0, len(alphabet), size=n)])
+
+
+def edge_cases():
+    """(name, sequence, m_lo, m_hi): the regimes SURVEY.md 3.2 calls out (Q4-Q7) plus tile/word edges."""
+    cases = [
+        ("empty", b"", 2, 6),
+        ("one_base", b"A", 2, 6),
+        ("short_7", b"ACGTACG", 2, 6),
+        ("all_A_100", b"A" * 100, 2, 10),
+        ("all_N_100", b"N" * 100, 2, 10),
+        ("poly_AC", b"AC" * 200, 2, 12),
+        ("tail_As", _rand(300, 11) + b"A" * 64, 2, 20),          # Q5: trailing A's compare equal to the zero fill
+        ("tail_Ns", _rand(300, 12) + b"N" * 40, 2, 20),          # Q5: trailing N's too
+        ("lower", (b"acgtt" * 40) + _rand(100, 13).lower(), 2, 8),
+        ("n_inside_run", b"CAG" * 30 + b"N" + b"CAG" * 30 + _rand(50, 14), 2, 8),      # Q6/Q7
+        ("n_runs", _rand(200, 15) + b"N" * 9 + b"AT" * 40 + b"NN" + b"AT" * 40 + b"N" + _rand(200, 16), 2, 16),
+        ("iupac", _rand(500, 17, b"ACGTRYKMN"), 2, 12),
+        ("word_edges", _rand(31, 18) + b"ACG" * 11 + _rand(32, 19) + b"TTGCA" * 13 + _rand(1, 20), 2, 9),
+        ("exact_32", b"GATTACA" * 4 + b"GATT", 2, 7),
+        ("exact_64", b"CT" * 32, 2, 6),
+        ("m_3_9", _rand(100, 21) + b"AGGCT" * 20 + _rand(100, 22), 3, 9),
+        ("m_5_40", _rand(200, 23) + (_rand(17, 24) * 12) + _rand(200, 25), 5, 40),
+        ("m_30_100", _rand(300, 26) + (_rand(64, 27) * 6) + _rand(300, 28) + (_rand(97, 29) * 4) + _rand(100, 30), 30, 100),
+        ("long_run_cross_tiles", _rand(100, 31) + b"ACGGT" * 8000 + _rand(100, 32), 2, 12),   # > 2 tiles of 16384
+        ("run_to_end", _rand(100, 33) + b"CAT" * 50, 2, 8),
+        ("run_from_start", b"GA" * 60 + _rand(100, 34), 2, 8),
+    ]
+    return cases
+
+
+def simulated_cases():
+    """(name, sequence, m_lo, m_hi) from the seeded generator (BASELINE.json configs, scaled down)."""
+    out = []
+    seq, _ = simulate_sequence(200_000, 1, 2, 6)
+    out.append(("sim_cfg1_200k", seq, 2, 6))
+    seq, _ = simulate_sequence(120_000, 2, 2, 100, n_block_rate=0.3, lower_rate=0.2)
+    out.append(("sim_cfg2_120k", seq, 2, 100))
+    seq, _ = simulate_sequence(60_000, 5, 4, 50, n_block_rate=0.5)
+    out.append(("sim_m4_50_60k", seq, 4, 50))
+    out.append(("random_n_100k", random_sequence(100_000, 3, n_fraction=0.02, n_run_lo=10, n_run_hi=500), 2, 100))
+    return out

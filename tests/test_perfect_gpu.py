@@ -1,0 +1,119 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C ABI against the
+CPU oracle on the same seeded inputs and against the committed fixtures.  Bit-exact (integer work).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import pyref
+import ribbit_amd
+from cases import edge_cases, simulated_cases
+from oracle_lib import LIST_PERFECT, Oracle
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALL = edge_cases() + simulated_cases()
+
+
+def _unpack(words, n):
+    bits = np.unpackbits(words.view(np.uint8), bitorder="little")
+    return bits[:n]
+
+
+def _expected_runs(o, m_lo, m_hi):
+    """all maximal runs of X_m & ~N with length >= min(c1, 16), from the oracle's planes"""
+    nmask = o.nmask()
+    L = len(nmask)
+    out = []
+    for m in range(m_lo, m_hi + 1):
+        sp = min(12 - m if m <= 6 else m, 16)
+        y = o.plane(m) & (1 - nmask)
+        for s, e in pyref.runs_of_ones(y):
+            if e - s >= sp:
+                term = 2 if e == L else (1 if nmask[e] else 0)
+                out.append((s, e, m, term))
+    return out
+
+
+@pytest.mark.parametrize("name,seq,m_lo,m_hi", ALL, ids=[c[0] for c in ALL])
+def test_pack_and_planes_match_oracle(name, seq, m_lo, m_hi):
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc, Oracle(seq, m_lo, m_hi) as o:
+        sc.load_record(seq)
+        n = len(seq)
+        code, nmask = o.codes(), o.nmask()
+        assert np.array_equal(_unpack(sc.packed_plane(0), n), code >> 1)
+        assert np.array_equal(_unpack(sc.packed_plane(1), n), code & 1)
+        assert np.array_equal(_unpack(sc.packed_plane(2), n), nmask)
+        # positions >= L in the last word must break runs
+        assert _unpack(sc.packed_plane(2), (n // 32 + 1) * 32)[n:].all()
+        for s in sorted({sc.min_shift, m_lo, (m_lo + m_hi) // 2, m_hi, sc.max_shift}):
+            assert np.array_equal(sc.plane_bits(s), o.plane(s)), f"shift {s}"
+            if n > 10:
+                a, b = n // 7, n - n // 5
+                assert sc.range_popcount(s, a, b) == o.range_count(s, a, b)
+                assert np.array_equal(sc.plane_bits(s, a, b), o.plane(s)[a:b])
+
+
+@pytest.mark.parametrize("name,seq,m_lo,m_hi", ALL, ids=[c[0] for c in ALL])
+def test_perfect_scan_matches_oracle(name, seq, m_lo, m_hi):
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc, Oracle(seq, m_lo, m_hi) as o:
+        sc.load_record(seq)
+        runs = sc.scan_perfect_runs()
+        got = [tuple(int(x) for x in r) for r in runs]
+        assert got == sorted(_expected_runs(o, m_lo, m_hi), key=lambda t: (t[2], t[0]))
+        o.run_perfect()
+        assert np.array_equal(sc.perfect_calls(), o.calls(LIST_PERFECT).astype(ribbit_amd.CALL_DT))
+        assert np.array_equal(sc.processShiftXORsPerfect(), o.seeds(LIST_PERFECT).astype(ribbit_amd.SEED_DT))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))),
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_perfect_stage_matches_fixture(path):
+    g = np.load(path)
+    with ribbit_amd.Scanner(int(g["m_lo"]), int(g["m_hi"])) as sc:
+        sc.load_record(g["seq"].tobytes())
+        assert np.array_equal(sc.perfect_calls().view("<i4"), g["perfect_calls"].view("<i4"))
+        assert np.array_equal(sc.processShiftXORsPerfect().view("<i4"), g["perfect_after_p"].view("<i4"))
+
+
+def test_reload_and_rescan_is_idempotent():
+    name, seq, m_lo, m_hi = simulated_cases()[1]
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc:
+        sc.load_record(seq)
+        a = sc.scan_perfect_runs()
+        b = sc.scan_perfect_runs()
+        sc.load_record(edge_cases()[5][1])
+        sc.scan_perfect_runs()
+        sc.load_record(seq)
+        c = sc.scan_perfect_runs()
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_full_size_properties_100mbp():
+    """BASELINE.json config 2 size (100 Mbp, m=2..100): size-independent properties, no oracle."""
+    from ribbit_amd.simulate import simulate_sequence
+    total = 100_000_000
+    unit, _ = simulate_sequence(1_000_000, 2, 2, 100)
+    seq = unit * (total // len(unit))
+    with ribbit_amd.Scanner(2, 100) as sc:
+        sc.load_record(seq)
+        runs = sc.scan_perfect_runs()
+        one = None
+        with ribbit_amd.Scanner(2, 100) as sc1:
+            sc1.load_record(unit)
+            one = sc1.scan_perfect_runs()
+    # runs are sorted by (mlen, start), disjoint per motif, and inside the record
+    key = runs["mlen"].astype(np.int64) << 32 | runs["start"]
+    assert np.all(np.diff(key) > 0)
+    assert runs["start"].min() >= 0 and runs["end"].max() <= total
+    same = runs["mlen"][1:] == runs["mlen"][:-1]
+    assert np.all(runs["start"][1:][same] > runs["end"][:-1][same])
+    # periodic input: every run of the 1-Mbp unit that stays clear of the unit's edges recurs in every copy
+    m = 1_000_000
+    inner = one[(one["start"] > 200) & (one["end"] < m - 200)]
+    for copy in (0, 37, 99):
+        sel = runs[(runs["start"] >= copy * m + 200) & (runs["end"] < (copy + 1) * m - 200) & (runs["start"] > copy * m + 200)]
+        sel = sel.copy(); sel["start"] -= copy * m; sel["end"] -= copy * m
+        assert np.array_equal(np.sort(sel, order=["mlen", "start"]), np.sort(inner, order=["mlen", "start"]))
