@@ -83,7 +83,7 @@ struct RibbitHandle {
     int64_t ntiles = 0, total_words = 0, tail_words = 0;
     DevBuf<uint8_t> d_ascii;
     DevBuf<uint32_t> d_hi, d_lo, d_brk;
-    DevBuf<uint64_t> d_events;
+    DevBuf<uint64_t> d_events, d_dense;
     DevBuf<uint32_t> d_counters;
     DevBuf<uint32_t> d_query;
     PinnedBuf<uint64_t> h_events;
@@ -93,6 +93,7 @@ struct RibbitHandle {
     int64_t last_event_count = 0;
     bool runs_valid = false, calls_valid = false, seeds_perfect_valid = false;
     std::vector<RibbitRun> runs;
+    std::vector<uint64_t> chunk_table;   // (offset, count) per (motif, tile)
     std::vector<RibbitCall> perfect_calls;
     rb::SeedLists lists;
 
@@ -157,80 +158,93 @@ int run_perfect_scan(RibbitHandle *h) {
     int rc;
     if ((rc = bind_device(h))) return rc;
     h->runs.clear();
-    if ((rc = h->d_counters.ensure(16))) return rc;
-    if ((rc = h->h_counters.ensure(16))) return rc;
+    if ((rc = h->d_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
+    if ((rc = h->h_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
+    // capacity in events, split evenly over EV_SHARDS regions; grows on overflow
     size_t cap = std::max<size_t>((size_t)1 << 20, (size_t)(h->length / 4));
-    if (h->d_events.cap > cap) cap = h->d_events.cap;
+    cap = std::max(cap, h->d_events.cap);
     const rb::DevicePlanes pl = h->planes();
     uint32_t produced = 0;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0;; ++attempt) {
+        cap = std::min<size_t>((cap + rb::EV_SHARDS - 1) / rb::EV_SHARDS * rb::EV_SHARDS, 0xffffff00u);
         if ((rc = h->d_events.ensure(cap))) return rc;
+        if ((rc = h->d_dense.ensure(cap))) return rc;
         HIP_TRY(hipEventRecord(h->ev[4], h->stream));
-        HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, 16 * sizeof(uint32_t), h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, rb::EV_COUNTER_WORDS * sizeof(uint32_t), h->stream));
         rb::PerfectLaunch pp;
         pp.m_lo = h->params.min_motif;
         pp.m_hi = h->params.max_motif;
-        pp.ev_cap = (uint32_t)std::min<size_t>(h->d_events.cap, 0xffffffffu);
+        pp.ev_cap = (uint32_t)cap;
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
         rb::launch_scan_perfect(pl, pp, h->d_events.p, h->d_counters.p, h->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[3], h->stream));
-        HIP_TRY(hipMemcpyAsync(h->h_counters.p, h->d_counters.p, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        rb::launch_compact_events(h->d_events.p, pp.ev_cap, h->d_counters.p, h->d_dense.p, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->h_counters.p, h->d_counters.p, rb::EV_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        produced = h->h_counters.p[0];
-        if (produced <= pp.ev_cap) break;
-        if (attempt == 2) return fail(RIBBIT_E_OVERFLOW, "event buffer overflow: %u events", produced);
-        cap = (size_t)produced + 1024;
+        produced = h->h_counters.p[rb::EV_SUMMARY];
+        if (!h->h_counters.p[rb::EV_SUMMARY + 1]) break;
+        // some region overflowed: size every region for the fullest one and retry
+        uint32_t worst = 0;
+        for (int t = 0; t < rb::EV_SHARDS; ++t) worst = std::max(worst, h->h_counters.p[t * rb::EV_COUNTER_STRIDE]);
+        if (attempt == 2 || (size_t)worst * rb::EV_SHARDS > 0xffffff00u)
+            return fail(RIBBIT_E_OVERFLOW, "event buffer overflow: fullest region needs %u events", worst);
+        cap = ((size_t)worst + 1024) * rb::EV_SHARDS;
     }
     h->last_event_count = produced;
     if ((rc = h->h_events.ensure(std::max<size_t>(produced, 1)))) return rc;
     if (produced) {
-        HIP_TRY(hipMemcpyAsync(h->h_events.p, h->d_events.p, (size_t)produced * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->h_events.p, h->d_dense.p, (size_t)produced * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     }
     HIP_TRY(hipEventRecord(h->ev[5], h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->have_timing[1] = h->have_timing[2] = true;
 
-    // Events arrive as position-ordered chunks, one per (motif, tile) with any event.  Order the
-    // chunks by (motif, tile), then pair START/END within each motif.
-    struct Chunk { uint32_t mlen, tile; size_t off, n; };
-    std::vector<Chunk> chunks;
+    // Events arrive as position-ordered chunks, exactly one per (motif, tile) that has any event.
+    // Index the chunks in a direct-address table keyed (motif, tile), then walk the table in key
+    // order pairing START/END: O(events), no sort.
     const uint64_t *ev = h->h_events.p;
+    const int m_lo = h->params.min_motif;
+    const size_t nm = (size_t)(h->params.max_motif - m_lo + 1);
+    const size_t ntile = (size_t)(h->length / rb::TILE_BASES + 1);
+    struct Chunk { uint32_t off, n; };
+    static_assert(sizeof(Chunk) == sizeof(uint64_t), "chunk table entry is one 64-bit word");
+    h->chunk_table.assign(nm * ntile, 0);
+    Chunk *table = reinterpret_cast<Chunk *>(h->chunk_table.data());
     for (size_t i = 0; i < produced;) {
         const uint32_t m = rb::ev_mlen(ev[i]);
         const uint32_t tile = rb::ev_pos(ev[i]) / (uint32_t)rb::TILE_BASES;
         size_t j = i + 1;
-        while (j < produced && rb::ev_mlen(ev[j]) == m && rb::ev_pos(ev[j]) / (uint32_t)rb::TILE_BASES == tile &&
-               rb::ev_pos(ev[j]) > rb::ev_pos(ev[j - 1]))
-            ++j;
-        chunks.push_back(Chunk{m, tile, i, j - i});
+        while (j < produced && rb::ev_mlen(ev[j]) == m && rb::ev_pos(ev[j]) / (uint32_t)rb::TILE_BASES == tile) ++j;
+        const size_t key = (size_t)(m - (uint32_t)m_lo) * ntile + tile;
+        if (m < (uint32_t)m_lo || m - (uint32_t)m_lo >= nm || tile >= ntile || table[key].n)
+            return fail(RIBBIT_E_INTERNAL, "malformed event chunk (motif %u, tile %u)", m, tile);
+        table[key] = Chunk{(uint32_t)i, (uint32_t)(j - i)};
         i = j;
     }
-    std::sort(chunks.begin(), chunks.end(), [](const Chunk &a, const Chunk &b) {
-        return a.mlen != b.mlen ? a.mlen < b.mlen : a.tile < b.tile;
-    });
-    int64_t open = -1;
-    uint32_t cur_m = 0;
-    for (const Chunk &c : chunks) {
-        if (c.mlen != cur_m) {
-            if (open != -1) return fail(RIBBIT_E_INTERNAL, "unterminated run for motif %u", cur_m);
-            cur_m = c.mlen;
-        }
-        for (size_t i = c.off; i < c.off + c.n; ++i) {
-            const uint32_t kind = rb::ev_kind(ev[i]);
-            const int64_t pos = rb::ev_pos(ev[i]);
-            if (kind == rb::EV_START) {
-                if (open != -1) return fail(RIBBIT_E_INTERNAL, "two run starts in a row (motif %u, pos %lld)", cur_m, (long long)pos);
-                open = pos;
-            } else {
-                if (open == -1) return fail(RIBBIT_E_INTERNAL, "run end without start (motif %u, pos %lld)", cur_m, (long long)pos);
-                const int term = kind == rb::EV_END_ZERO ? RIBBIT_TERM_ZERO : kind == rb::EV_END_N ? RIBBIT_TERM_N : RIBBIT_TERM_EOS;
-                h->runs.push_back(RibbitRun{(int32_t)open, (int32_t)pos, (int32_t)cur_m, term});
-                open = -1;
+    h->runs.reserve(produced / 2);
+    for (size_t mi = 0; mi < nm; ++mi) {
+        const int32_t mlen = m_lo + (int32_t)mi;
+        int64_t open = -1;
+        for (size_t t = 0; t < ntile; ++t) {
+            const Chunk c = table[mi * ntile + t];
+            for (uint32_t i = c.off; i < c.off + c.n; ++i) {
+                const uint32_t kind = rb::ev_kind(ev[i]);
+                const int64_t pos = rb::ev_pos(ev[i]);
+                if (kind == rb::EV_START) {
+                    if (open != -1) return fail(RIBBIT_E_INTERNAL, "two run starts in a row (motif %d, pos %lld)", mlen, (long long)pos);
+                    open = pos;
+                } else {
+                    if (open == -1 || pos <= open) return fail(RIBBIT_E_INTERNAL, "run end without start (motif %d, pos %lld)", mlen, (long long)pos);
+                    const int term = kind == rb::EV_END_ZERO ? RIBBIT_TERM_ZERO : kind == rb::EV_END_N ? RIBBIT_TERM_N : RIBBIT_TERM_EOS;
+                    h->runs.push_back(RibbitRun{(int32_t)open, (int32_t)pos, mlen, term});
+                    open = -1;
+                }
             }
         }
+        if (open != -1) return fail(RIBBIT_E_INTERNAL, "unterminated run for motif %d", mlen);
     }
-    if (open != -1) return fail(RIBBIT_E_INTERNAL, "unterminated run for motif %u", cur_m);
     h->runs_valid = true;
     return RIBBIT_OK;
 }
@@ -318,7 +332,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ascii.release(); h->d_hi.release(); h->d_lo.release(); h->d_brk.release();
-    h->d_events.release(); h->d_counters.release(); h->d_query.release();
+    h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release();
     h->h_events.release(); h->h_counters.release(); h->h_query.release();
     for (int i = 0; i < 6; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

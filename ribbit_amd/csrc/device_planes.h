@@ -31,6 +31,12 @@ struct DevicePlanes {
     int64_t tail_words;   // words readable past ntiles*TILE_WORDS
 };
 
+// Event buffer sharding: EV_SHARDS regions, one counter each (own 128-byte line).
+constexpr int EV_SHARDS = 64;
+constexpr int EV_COUNTER_STRIDE = 32;                          // uint32 words between counters
+constexpr int EV_SUMMARY = EV_SHARDS * EV_COUNTER_STRIDE;      // [0] total events, [1] overflow flag
+constexpr int EV_COUNTER_WORDS = EV_SUMMARY + EV_COUNTER_STRIDE;
+
 // raw device event: one transition of a per-motif bitmap
 //   bits  0..31 position, 32..47 motif length, 48..51 kind
 enum : uint32_t { EV_START = 0, EV_END_ZERO = 1, EV_END_N = 2, EV_END_EOS = 3 };

@@ -17,9 +17,15 @@ struct PerfectLaunch {
     uint32_t ev_cap;       // capacity of the event buffer, in events
 };
 // parse_perfect_shiftxor.cpp:173-223 hot loop -> run START / END events.
-// counters[0] receives the number of events produced (may exceed ev_cap: overflow).
+// Events land in EV_SHARDS regions of ev_cap/EV_SHARDS events; counters[] (EV_COUNTER_WORDS words,
+// zeroed by the caller) holds one count per region.  A count above the region size = overflow.
 void launch_scan_perfect(const DevicePlanes &pl, const PerfectLaunch &pp, uint64_t *events, uint32_t *counters,
                          hipStream_t stream);
+
+// Gathers the used part of every region into `dense` (same capacity) in shard order and writes
+// counters[EV_SUMMARY] = total events, counters[EV_SUMMARY+1] = 1 if any region overflowed.
+void launch_compact_events(const uint64_t *events, uint32_t ev_cap, uint32_t *counters, uint64_t *dense,
+                           hipStream_t stream);
 
 // X_shift words [w0, w0+nw) -> out_words (device); if count != nullptr also adds the popcount of
 // bits in [p0, p1) to *count.

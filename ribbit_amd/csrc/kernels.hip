@@ -78,6 +78,46 @@ void launch_pack(const uint8_t *dev_ascii, int64_t length, uint32_t *hi, uint32_
                        total_words);
 }
 
+// ---------------------------------------------------------------------- event staging
+// Events are compacted in position order inside a wave (DPP prefix sum, no LDS traffic), staged
+// in a per-wave LDS buffer across the motif loop and flushed with ONE global atomic per flush.
+// The atomic goes to one of EV_SHARDS counters (each on its own 128-byte line, each owning a
+// fixed region of the event buffer): a single counter sustains only ~88 returning atomics/us
+// (MI355X_MICROARCH.md "dequeue"), which bounded the first version of this kernel at 4.8 ms.
+constexpr int EV_STAGE = 256;        // events staged per wave in LDS (2 KiB)
+
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    // Hillis-Steele inside each row of 16 lanes, then two row broadcasts (GFX9 DPP)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+struct EventSink {
+    uint64_t *events;        // global buffer, EV_SHARDS regions of region_cap events
+    uint32_t *counters;      // EV_SHARDS counters, EV_COUNTER_STRIDE words apart
+    uint32_t region_cap;
+    uint32_t shard;
+};
+
+__device__ __forceinline__ void sink_flush(const EventSink &sk, volatile uint64_t *stage, int &staged, int lane) {
+    if (staged == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&sk.counters[sk.shard * EV_COUNTER_STRIDE], (uint32_t)staged);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    uint64_t *dst = sk.events + (size_t)sk.shard * sk.region_cap;
+    for (int i = lane; i < staged; i += 64) {
+        const uint32_t idx = base + (uint32_t)i;
+        if (idx < sk.region_cap) dst[idx] = stage[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    staged = 0;
+}
+
 // -------------------------------------------------------------------------- perfect scan
 constexpr int K = WORDS_PER_LANE;
 constexpr int LDS_EXTRA = 40;   // halo + shifted-operand words (supports shifts < 1024)
@@ -99,6 +139,7 @@ __global__ __launch_bounds__(256) void scan_perfect_kernel(DevicePlanes pl, Perf
     __shared__ uint32_t s_hi[TILE_WORDS + LDS_EXTRA];
     __shared__ uint32_t s_lo[TILE_WORDS + LDS_EXTRA];
     __shared__ uint32_t s_brk[TILE_WORDS + 8];
+    __shared__ uint64_t s_stage[4][EV_STAGE];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -133,6 +174,14 @@ __global__ __launch_bounds__(256) void scan_perfect_kernel(DevicePlanes pl, Perf
     int cur_q = -1;
     const uint32_t length = (uint32_t)pl.length;
     const uint32_t word0 = (uint32_t)(tile_base + lb);   // global index of own word k = 0
+
+    EventSink sink;
+    sink.events = events;
+    sink.counters = counters;
+    sink.region_cap = pp.ev_cap / EV_SHARDS;
+    sink.shard = (blockIdx.x * 4u + (uint32_t)wave + blockIdx.y) % EV_SHARDS;
+    volatile uint64_t *stage = s_stage[wave];
+    int staged = 0;   // wave-uniform
 
     for (int m = wm_lo; m <= wm_hi; ++m) {
         const int q = m >> 5;
@@ -182,21 +231,24 @@ __global__ __launch_bounds__(256) void scan_perfect_kernel(DevicePlanes pl, Perf
         }
 
         if (__ballot(any != 0) != 0ull) {
-            // rare path: compact this wave's events in position order
+            // compact this wave's events in position order into the LDS stage
             int cnt = 0;
 #pragma unroll
             for (int k = 0; k < K; k++) cnt += __popc(SQ[k]) + __popc(EQ[k]);
-            int incl = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int up = __shfl_up(incl, d);
-                if (lane >= d) incl += up;
+            const int incl = wave_inclusive_scan(cnt);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            if (staged + total > EV_STAGE) sink_flush(sink, stage, staged, lane);
+            const bool direct = total > EV_STAGE;   // denser than the stage: write straight to global
+            uint32_t idx = (uint32_t)(incl - cnt);
+            uint64_t *gdst = nullptr;
+            if (direct) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&sink.counters[sink.shard * EV_COUNTER_STRIDE], (uint32_t)total);
+                idx += (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                gdst = sink.events + (size_t)sink.shard * sink.region_cap;
+            } else {
+                idx += (uint32_t)staged;
             }
-            const int total = __shfl(incl, 63);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&counters[0], (uint32_t)total);
-            base = __shfl(base, 0);
-            uint32_t idx = base + (uint32_t)(incl - cnt);
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 uint32_t both = SQ[k] | EQ[k];
@@ -209,12 +261,17 @@ __global__ __launch_bounds__(256) void scan_perfect_kernel(DevicePlanes pl, Perf
                     else if (pos >= length) kind = EV_END_EOS;
                     else if ((Bk[k + 1] >> b) & 1u) kind = EV_END_N;
                     else kind = EV_END_ZERO;
-                    if (idx < pp.ev_cap) events[idx] = ev_pack(pos, (uint32_t)m, kind);
+                    const uint64_t e = ev_pack(pos, (uint32_t)m, kind);
+                    if (direct) { if (idx < sink.region_cap) gdst[idx] = e; }
+                    else stage[idx] = e;
                     idx++;
                 }
             }
+            if (!direct) staged += total;
+            __builtin_amdgcn_wave_barrier();
         }
     }
+    sink_flush(sink, stage, staged, lane);
 }
 
 void launch_scan_perfect(const DevicePlanes &pl, const PerfectLaunch &pp, uint64_t *events, uint32_t *counters,
@@ -229,6 +286,34 @@ void launch_scan_perfect(const DevicePlanes &pl, const PerfectLaunch &pp, uint64
     gy = (nm + motifs_per_block - 1) / motifs_per_block;
     dim3 grid((unsigned)pl.ntiles, (unsigned)gy);
     hipLaunchKernelGGL(scan_perfect_kernel, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, events, counters);
+}
+
+// ------------------------------------------------------------------------ event compaction
+__global__ __launch_bounds__(256) void compact_events_kernel(const uint64_t *__restrict__ events, uint32_t region_cap,
+                                                             uint32_t *__restrict__ counters,
+                                                             uint64_t *__restrict__ dense) {
+    const uint32_t shard = blockIdx.x;
+    uint32_t offset = 0, total = 0, overflow = 0, mine = 0;
+    for (uint32_t t = 0; t < (uint32_t)EV_SHARDS; ++t) {
+        const uint32_t raw = counters[t * EV_COUNTER_STRIDE];
+        const uint32_t c = raw < region_cap ? raw : region_cap;
+        overflow |= raw > region_cap;
+        if (t < shard) offset += c;
+        if (t == shard) mine = c;
+        total += c;
+    }
+    const uint64_t *src = events + (size_t)shard * region_cap;
+    for (uint32_t i = blockIdx.y * 256u + threadIdx.x; i < mine; i += gridDim.y * 256u) dense[offset + i] = src[i];
+    if (shard == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        counters[EV_SUMMARY] = total;
+        counters[EV_SUMMARY + 1] = overflow;
+    }
+}
+
+void launch_compact_events(const uint64_t *events, uint32_t ev_cap, uint32_t *counters, uint64_t *dense,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(compact_events_kernel, dim3(EV_SHARDS, 16), dim3(256), 0, stream, events,
+                       ev_cap / (uint32_t)EV_SHARDS, counters, dense);
 }
 
 // ------------------------------------------------------------------- plane query (a5, a13)
