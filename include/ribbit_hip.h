@@ -114,6 +114,21 @@ int ribbit_hip_perfect_calls(RibbitHandle *h, const RibbitCall **out, size_t *n)
 int ribbit_hip_seeds_perfect(RibbitHandle *h, const RibbitSeed **out, size_t *n);
 
 /*
+ * The addSeedToSeedPositionsSubstitutions calls processShiftXORswithSubstitutions would make
+ * (parse_substitute_shiftxor.cpp:430-574), in its call order: window-scan kernel (8-wide window,
+ * >= 7 matches) + per-motif state machine replay.
+ */
+int ribbit_hip_subst_calls(RibbitHandle *h, const RibbitCall **out, size_t *n);
+
+/*
+ * processShiftXORswithSubstitutions (parse_substitute_shiftxor.h:9; called at fasta_utils.cpp:136).
+ * Runs the perfect stage first if it has not run.  Returns seed_positions_substut and the perfect
+ * list as this stage leaves it (entries may have been re-typed to RIBBIT_RANK_N).
+ */
+int ribbit_hip_seeds_substitutions(RibbitHandle *h, const RibbitSeed **perfect, size_t *n_perfect,
+                                   const RibbitSeed **subst, size_t *n_subst);
+
+/*
  * Bits [start, end) of shift plane `shift` (X_shift, or the anchored plane once
  * ribbit_hip_anchor_planes has run), one byte per base.  Replaces reads of
  * lshift_xor_bsets[shift-MINIMUM_SHIFT][L-1-p] (fasta_utils.cpp:220-222, parse_seed.cpp:366).
@@ -129,8 +144,31 @@ int ribbit_hip_range_popcount(RibbitHandle *h, int32_t shift, int64_t start, int
 int64_t ribbit_hip_plane_words(const RibbitHandle *h);
 int ribbit_hip_packed_plane(RibbitHandle *h, int which, uint32_t *out_words);
 
-/* Timing of the last call, milliseconds, measured with HIP events on the launch stream.
- * what: 0 pack kernel, 1 perfect-scan kernel, 2 whole last API call (GPU side). */
+/*
+ * Host-only replay of scanner call lists through the order-dependent seed-list merges
+ * (addSeedToSeedPositionsPerfect / ...Substitutions).  This is the host half of
+ * ribbit_hip_seeds_*: it needs no GPU, only the packed planes (LSB-first words as returned by
+ * ribbit_hip_packed_plane, padded with at least max_motif/32 + 4 zero words past word L/32) for
+ * the range popcounts of retainNestedSeed / retainIdenticalSeeds.  Used when the call lists come
+ * from elsewhere: other ranks in chunk-sharded multi-GPU runs, or the CPU tests of the merges.
+ * The arrays in *out are malloc'ed; release them with ribbit_seed_lists_free().
+ */
+typedef struct RibbitSeedLists {
+    RibbitSeed *perfect;  size_t n_perfect;
+    RibbitSeed *subst;    size_t n_subst;
+    RibbitSeed *anchored; size_t n_anchored;
+    int64_t guard_hits;   /* defined-divergence guards that fired */
+} RibbitSeedLists;
+int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
+                             const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
+                             const RibbitCall *perfect_calls, size_t n_perfect_calls,
+                             const RibbitCall *subst_calls, size_t n_subst_calls,
+                             RibbitSeedLists *out);
+void ribbit_seed_lists_free(RibbitSeedLists *lists);
+
+/* Timing of the last call, milliseconds.  what: 0 pack kernel, 1 last scan kernel, 2 GPU side of
+ * the last scan (kernel + compaction + read-back), all by HIP events on the launch stream;
+ * 3 host post-processing of the last scan (wall clock). */
 int ribbit_hip_last_timing_ms(const RibbitHandle *h, int what, double *ms);
 /* Number of raw device events (run starts + run ends) the last scan produced. */
 int64_t ribbit_hip_last_event_count(const RibbitHandle *h);

@@ -71,6 +71,7 @@ struct rbo_ctx {
     callvec calls[3];
     seedvec dispatch;
     int64_t guard_hits;
+    int64_t range_queries;      /* how often the merges asked for a range popcount (statistics only) */
 };
 
 int rbo_min_shift(const rbo_ctx *c) { return c->min_shift; }
@@ -96,6 +97,7 @@ int64_t rbo_dispatch(const rbo_ctx *c, const rbo_seed_t **out) {
     *out = c->dispatch.a; return c->dispatch.n;
 }
 int64_t rbo_guard_hits(const rbo_ctx *c) { return c->guard_hits; }
+int64_t rbo_range_queries(const rbo_ctx *c) { return c->range_queries; }
 
 /* ------------------------------------------------------- encode + sweep (a1, a2) */
 
@@ -160,13 +162,15 @@ int rbo_range_count(const rbo_ctx *c, int shift, int start, int end) {
 }
 
 /* retainNestedSeed, parse_perfect_shiftxor.cpp:18-29 (== retainNestedSeedAnchored :59-70) */
-static int retain_nested(const rbo_ctx *c, int start, int end, int nested_mlen, int parent_mlen) {
+static int retain_nested(rbo_ctx *c, int start, int end, int nested_mlen, int parent_mlen) {
+    c->range_queries += 2;
     int nested = rbo_range_count(c, nested_mlen, start, end);
     int parent = rbo_range_count(c, parent_mlen, start, end);
     return !(nested < parent);
 }
 /* retainIdenticalSeeds, parse_perfect_shiftxor.cpp:31-43: tie goes to the smaller plane index */
-static int retain_identical(const rbo_ctx *c, int start, int end, int nested_mlen, int parent_mlen) {
+static int retain_identical(rbo_ctx *c, int start, int end, int nested_mlen, int parent_mlen) {
+    c->range_queries += 2;
     int nested = rbo_range_count(c, nested_mlen, start, end);
     int parent = rbo_range_count(c, parent_mlen, start, end);
     if (nested < parent) return 0;

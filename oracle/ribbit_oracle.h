@@ -73,6 +73,8 @@ int rbo_range_count(const rbo_ctx *c, int shift, int start, int end);
 
 /* number of times the defined-divergence guards fired (Q9 empty-list reads, out-of-range [j] quirk) */
 int64_t rbo_guard_hits(const rbo_ctx *c);
+/* statistics: range popcounts requested by the merges so far */
+int64_t rbo_range_queries(const rbo_ctx *c);
 
 #ifdef __cplusplus
 }

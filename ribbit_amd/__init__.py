@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-__all__ = ["RibbitHipError", "ScanParams", "Scanner", "library_path", "load_library",
+__all__ = ["RibbitHipError", "ScanParams", "Scanner", "library_path", "load_library", "host_replay_calls", "pack_planes",
            "RUN_DT", "CALL_DT", "SEED_DT", "RANK", "TERM"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -32,6 +32,8 @@ ABI_SYMBOLS = [
     "ribbit_hip_perfect_calls", "ribbit_hip_seeds_perfect", "ribbit_hip_plane_bits",
     "ribbit_hip_range_popcount", "ribbit_hip_plane_words", "ribbit_hip_packed_plane",
     "ribbit_hip_last_timing_ms", "ribbit_hip_last_event_count",
+    "ribbit_hip_subst_calls", "ribbit_hip_seeds_substitutions",
+    "ribbit_host_replay_calls", "ribbit_seed_lists_free",
 ]
 
 
@@ -43,6 +45,12 @@ class ScanParams(C.Structure):
     """RibbitScanParams (ribbit.cpp:191,240-243; fasta_utils.cpp:165)."""
     _fields_ = [("min_motif", C.c_int32), ("max_motif", C.c_int32), ("window_length", C.c_int32),
                 ("subst_threshold", C.c_int32), ("anchor_threshold", C.c_int32), ("anchor_length", C.c_int32)]
+
+
+class SeedLists(C.Structure):
+    """RibbitSeedLists (malloc'ed arrays returned by ribbit_host_replay_calls)."""
+    _fields_ = [("perfect", C.c_void_p), ("n_perfect", C.c_size_t), ("subst", C.c_void_p), ("n_subst", C.c_size_t),
+                ("anchored", C.c_void_p), ("n_anchored", C.c_size_t), ("guard_hits", C.c_int64)]
 
 
 def library_path() -> str:
@@ -74,8 +82,13 @@ def load_library():
     L.ribbit_hip_set_stream.argtypes = [vp, vp]
     L.ribbit_hip_load_record.argtypes = [vp, C.c_char_p, i64]
     L.ribbit_hip_load_record_device.argtypes = [vp, vp, i64]
-    for f in ("ribbit_hip_scan_perfect_runs", "ribbit_hip_perfect_calls", "ribbit_hip_seeds_perfect"):
+    for f in ("ribbit_hip_scan_perfect_runs", "ribbit_hip_perfect_calls", "ribbit_hip_seeds_perfect", "ribbit_hip_subst_calls"):
         getattr(L, f).argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ribbit_hip_seeds_substitutions.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ribbit_host_replay_calls.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t,
+                                           C.POINTER(SeedLists)]
+    L.ribbit_seed_lists_free.restype = None
+    L.ribbit_seed_lists_free.argtypes = [C.POINTER(SeedLists)]
     L.ribbit_hip_plane_bits.argtypes = [vp, i32, i64, i64, vp]
     L.ribbit_hip_range_popcount.argtypes = [vp, i32, i64, i64, C.POINTER(i32)]
     L.ribbit_hip_plane_words.restype = i64
@@ -93,6 +106,46 @@ def _copy(ptr, n, dt):
         return np.zeros(0, dtype=dt)
     buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
     return np.frombuffer(buf, dtype=dt).copy()
+
+
+def pack_planes(sequence: bytes, max_motif: int):
+    """numpy packing of a record into (hi, lo, brk) uint32 planes with the padding
+    ribbit_host_replay_calls needs.  Host-side helper for replaying call lists that came from
+    another rank; scans never use it (the GPU packs its own planes)."""
+    n = len(sequence)
+    raw = np.frombuffer(sequence, dtype=np.uint8)
+    up = raw | 0x20
+    valid = (up == ord("a")) | (up == ord("c")) | (up == ord("g")) | (up == ord("t"))
+    code = np.where(valid, ((raw >> 1) & 3) ^ ((raw >> 2) & 1), 0).astype(np.uint8)
+    nwords = n // 32 + 1 + (max_motif + 2) // 32 + 4
+    def pack(bits):
+        buf = np.zeros(nwords * 32, dtype=np.uint8)
+        buf[:n] = bits
+        return np.packbits(buf, bitorder="little").view("<u4").copy()
+    brk_bits = np.ones(nwords * 32, dtype=np.uint8)
+    brk_bits[:n] = ~valid
+    brk = np.packbits(brk_bits, bitorder="little").view("<u4").copy()
+    return pack(code >> 1), pack(code & 1), brk
+
+
+def host_replay_calls(min_motif: int, max_motif: int, sequence: bytes, perfect_calls, subst_calls=None):
+    """ribbit_host_replay_calls: call lists -> (perfect, subst, anchored seed lists, guard_hits). No GPU needed."""
+    L = load_library()
+    params = ScanParams()
+    L.ribbit_scan_params_default(C.byref(params), min_motif, max_motif)
+    hi, lo, brk = pack_planes(sequence, max_motif)
+    pc = np.ascontiguousarray(perfect_calls, dtype=CALL_DT)
+    sc = np.ascontiguousarray(subst_calls if subst_calls is not None else np.zeros(0, CALL_DT), dtype=CALL_DT)
+    out = SeedLists()
+    rc = L.ribbit_host_replay_calls(C.byref(params), len(sequence), hi.ctypes.data, lo.ctypes.data, brk.ctypes.data, len(hi),
+                                    pc.ctypes.data, len(pc), sc.ctypes.data, len(sc), C.byref(out))
+    if rc != 0:
+        raise RibbitHipError(f"ribbit_host_replay_calls error {rc}: {L.ribbit_hip_last_error().decode()}")
+    try:
+        return (_copy(out.perfect, out.n_perfect, SEED_DT), _copy(out.subst, out.n_subst, SEED_DT),
+                _copy(out.anchored, out.n_anchored, SEED_DT), int(out.guard_hits))
+    finally:
+        L.ribbit_seed_lists_free(C.byref(out))
 
 
 class Scanner:
@@ -162,6 +215,16 @@ class Scanner:
 
     def processShiftXORsPerfect(self):
         return self._list(self._L.ribbit_hip_seeds_perfect, SEED_DT)
+
+    # parse_substitute_shiftxor.cpp:391-577 ------------------------------------------------
+    def subst_calls(self):
+        return self._list(self._L.ribbit_hip_subst_calls, CALL_DT)
+
+    def processShiftXORswithSubstitutions(self):
+        """-> (seed_positions_perfect as re-typed by this stage, seed_positions_substut)"""
+        pp, np_, ps, ns = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        self._check(self._L.ribbit_hip_seeds_substitutions(self._h, C.byref(pp), C.byref(np_), C.byref(ps), C.byref(ns)))
+        return _copy(pp.value, np_.value, SEED_DT), _copy(ps.value, ns.value, SEED_DT)
 
     # plane access -----------------------------------------------------------------------
     def plane_bits(self, shift: int, start: int = 0, end: int | None = None):

@@ -1,20 +1,25 @@
 // api.cpp -- extern "C" boundary of libribbit_hip.so (see include/ribbit_hip.h).
-// Device memory, streams and HIP-event timing live here; kernels are in kernels.hip and the
-// sequential seed-list logic in seed_lists.cpp.  There is no CPU fallback anywhere in this file.
+// Device memory, streams and HIP-event timing live here; kernels are in kernels.hip, the
+// per-motif window state machine in window_fsm.cpp and the sequential seed-list merges in
+// seed_lists.cpp.  There is no CPU fallback for any scan anywhere in this library.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "device_planes.h"
+#include "host_planes.h"
 #include "kernels.h"
 #include "ribbit_hip.h"
 #include "seed_lists.h"
+#include "window_fsm.h"
 
 namespace {
 
@@ -67,6 +72,13 @@ struct PinnedBuf {
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+enum Stage { STAGE_NONE = 0, STAGE_PERFECT = 1, STAGE_SUBST = 2 };
+
 }  // namespace
 
 struct RibbitHandle {
@@ -75,8 +87,9 @@ struct RibbitHandle {
     int min_shift = 1, max_shift = 102;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[6] = {};        // 0/1 pack, 2/3 scan, 4/5 whole call
+    hipEvent_t ev[6] = {};        // 0/1 pack, 2/3 scan kernel, 4/5 whole GPU side of the last scan
     bool have_timing[3] = {false, false, false};
+    double host_ms = 0.0;         // host post-processing of the last scan (pairing / FSM)
 
     bool loaded = false;
     int64_t length = 0;
@@ -90,11 +103,23 @@ struct RibbitHandle {
     PinnedBuf<uint32_t> h_counters;
     PinnedBuf<uint32_t> h_query;
 
+    // host copy of the packed planes: answers the sparse, latency-bound range reads of the
+    // sequential merges (retainNestedSeed & co) without a GPU round trip per query
+    rb::HostPlanes host;
+    bool host_planes_valid = false;
+
+    // ordered view of the last event collection
     int64_t last_event_count = 0;
-    bool runs_valid = false, calls_valid = false, seeds_perfect_valid = false;
-    std::vector<RibbitRun> runs;
+    uint32_t produced = 0;
     std::vector<uint64_t> chunk_table;   // (offset, count) per (motif, tile)
+    size_t table_ntile = 0;
+
+    bool runs_valid = false, calls_valid = false;
+    std::vector<RibbitRun> runs;
     std::vector<RibbitCall> perfect_calls;
+    bool subst_calls_valid = false;
+    std::vector<RibbitCall> subst_calls;
+    int stage_done = STAGE_NONE;          // how far the seed lists have been advanced
     rb::SeedLists lists;
 
     rb::DevicePlanes planes() const {
@@ -124,7 +149,9 @@ int is_gfx950(int device) {
 
 int pack_loaded_ascii(RibbitHandle *h, const uint8_t *dev_ascii, int64_t length) {
     h->loaded = false;
-    h->runs_valid = h->calls_valid = h->seeds_perfect_valid = false;
+    h->runs_valid = h->calls_valid = h->subst_calls_valid = false;
+    h->host_planes_valid = false;
+    h->stage_done = STAGE_NONE;
     h->length = length;
     const int64_t nwords = length / 32 + 1;   // word holding position L is included
     h->ntiles = (nwords + rb::TILE_WORDS - 1) / rb::TILE_WORDS;
@@ -148,16 +175,27 @@ int pack_loaded_ascii(RibbitHandle *h, const uint8_t *dev_ascii, int64_t length)
     return RIBBIT_OK;
 }
 
-// c1 / c2 of parse_perfect_shiftxor.cpp:193 / :179
-inline int cutoff_zero(int m) { return (m <= 6) ? 12 - m : m; }
-inline int cutoff_n(int m, int min_shift) { return (m <= 6) ? 12 - m : m + (m - min_shift); }
-
-int run_perfect_scan(RibbitHandle *h) {
-    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
-    if (h->runs_valid) return RIBBIT_OK;
+// D2H of the packed planes (3 bits per base), once per record, for the host-side sparse reads
+int ensure_host_planes(RibbitHandle *h) {
+    if (h->host_planes_valid) return RIBBIT_OK;
     int rc;
     if ((rc = bind_device(h))) return rc;
-    h->runs.clear();
+    const size_t n = (size_t)(h->ntiles * rb::TILE_WORDS + h->tail_words);
+    h->host.resize(h->length, n);
+    HIP_TRY(hipMemcpyAsync(h->host.hi.data(), h->d_hi.p + rb::LEAD_WORDS, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->host.lo.data(), h->d_lo.p + rb::LEAD_WORDS, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->host.brk.data(), h->d_brk.p + rb::LEAD_WORDS, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->host.index_breaks();
+    h->host_planes_valid = true;
+    return RIBBIT_OK;
+}
+
+// Launch one scan kernel, compact its sharded event regions, copy the events back and index the
+// (motif, tile) chunks.  which: 0 perfect run scan, 1 window scan (1 mismatch), 2 window scan (2).
+int collect_events(RibbitHandle *h, int which) {
+    int rc;
+    if ((rc = bind_device(h))) return rc;
     if ((rc = h->d_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
     if ((rc = h->h_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
     // capacity in events, split evenly over EV_SHARDS regions; grows on overflow
@@ -176,7 +214,8 @@ int run_perfect_scan(RibbitHandle *h) {
         pp.m_hi = h->params.max_motif;
         pp.ev_cap = (uint32_t)cap;
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-        rb::launch_scan_perfect(pl, pp, h->d_events.p, h->d_counters.p, h->stream);
+        if (which == 0) rb::launch_scan_perfect(pl, pp, h->d_events.p, h->d_counters.p, h->stream);
+        else rb::launch_scan_window(pl, pp, which, h->d_events.p, h->d_counters.p, h->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[3], h->stream));
         rb::launch_compact_events(h->d_events.p, pp.ev_cap, h->d_counters.p, h->d_dense.p, h->stream);
@@ -193,6 +232,7 @@ int run_perfect_scan(RibbitHandle *h) {
         cap = ((size_t)worst + 1024) * rb::EV_SHARDS;
     }
     h->last_event_count = produced;
+    h->produced = produced;
     if ((rc = h->h_events.ensure(std::max<size_t>(produced, 1)))) return rc;
     if (produced) {
         HIP_TRY(hipMemcpyAsync(h->h_events.p, h->d_dense.p, (size_t)produced * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
@@ -202,51 +242,85 @@ int run_perfect_scan(RibbitHandle *h) {
     h->have_timing[1] = h->have_timing[2] = true;
 
     // Events arrive as position-ordered chunks, exactly one per (motif, tile) that has any event.
-    // Index the chunks in a direct-address table keyed (motif, tile), then walk the table in key
-    // order pairing START/END: O(events), no sort.
+    // Index them in a direct-address table keyed (motif, tile): O(events), no sort.
     const uint64_t *ev = h->h_events.p;
-    const int m_lo = h->params.min_motif;
-    const size_t nm = (size_t)(h->params.max_motif - m_lo + 1);
+    const uint32_t m_lo = (uint32_t)h->params.min_motif;
+    const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
     const size_t ntile = (size_t)(h->length / rb::TILE_BASES + 1);
     struct Chunk { uint32_t off, n; };
     static_assert(sizeof(Chunk) == sizeof(uint64_t), "chunk table entry is one 64-bit word");
     h->chunk_table.assign(nm * ntile, 0);
+    h->table_ntile = ntile;
     Chunk *table = reinterpret_cast<Chunk *>(h->chunk_table.data());
     for (size_t i = 0; i < produced;) {
         const uint32_t m = rb::ev_mlen(ev[i]);
         const uint32_t tile = rb::ev_pos(ev[i]) / (uint32_t)rb::TILE_BASES;
         size_t j = i + 1;
         while (j < produced && rb::ev_mlen(ev[j]) == m && rb::ev_pos(ev[j]) / (uint32_t)rb::TILE_BASES == tile) ++j;
-        const size_t key = (size_t)(m - (uint32_t)m_lo) * ntile + tile;
-        if (m < (uint32_t)m_lo || m - (uint32_t)m_lo >= nm || tile >= ntile || table[key].n)
-            return fail(RIBBIT_E_INTERNAL, "malformed event chunk (motif %u, tile %u)", m, tile);
+        if (m < m_lo || m - m_lo >= nm || tile >= ntile) return fail(RIBBIT_E_INTERNAL, "malformed event (motif %u, tile %u)", m, tile);
+        const size_t key = (size_t)(m - m_lo) * ntile + tile;
+        if (table[key].n) return fail(RIBBIT_E_INTERNAL, "duplicate event chunk (motif %u, tile %u)", m, tile);
         table[key] = Chunk{(uint32_t)i, (uint32_t)(j - i)};
         i = j;
     }
-    h->runs.reserve(produced / 2);
-    for (size_t mi = 0; mi < nm; ++mi) {
-        const int32_t mlen = m_lo + (int32_t)mi;
-        int64_t open = -1;
-        for (size_t t = 0; t < ntile; ++t) {
-            const Chunk c = table[mi * ntile + t];
-            for (uint32_t i = c.off; i < c.off + c.n; ++i) {
-                const uint32_t kind = rb::ev_kind(ev[i]);
-                const int64_t pos = rb::ev_pos(ev[i]);
-                if (kind == rb::EV_START) {
-                    if (open != -1) return fail(RIBBIT_E_INTERNAL, "two run starts in a row (motif %d, pos %lld)", mlen, (long long)pos);
-                    open = pos;
-                } else {
-                    if (open == -1 || pos <= open) return fail(RIBBIT_E_INTERNAL, "run end without start (motif %d, pos %lld)", mlen, (long long)pos);
-                    const int term = kind == rb::EV_END_ZERO ? RIBBIT_TERM_ZERO : kind == rb::EV_END_N ? RIBBIT_TERM_N : RIBBIT_TERM_EOS;
-                    h->runs.push_back(RibbitRun{(int32_t)open, (int32_t)pos, mlen, term});
-                    open = -1;
-                }
-            }
-        }
-        if (open != -1) return fail(RIBBIT_E_INTERNAL, "unterminated run for motif %d", mlen);
+    return RIBBIT_OK;
+}
+
+// Visit the events of motif index mi in position order: fn(pos, kind) -> false aborts.
+template <typename Fn>
+bool for_each_event(const RibbitHandle *h, size_t mi, Fn fn) {
+    struct Chunk { uint32_t off, n; };
+    const Chunk *table = reinterpret_cast<const Chunk *>(h->chunk_table.data()) + mi * h->table_ntile;
+    const uint64_t *ev = h->h_events.p;
+    for (size_t t = 0; t < h->table_ntile; ++t) {
+        const Chunk c = table[t];
+        for (uint32_t i = c.off; i < c.off + c.n; ++i)
+            if (!fn((int64_t)rb::ev_pos(ev[i]), rb::ev_kind(ev[i]))) return false;
     }
+    return true;
+}
+
+// c1 / c2 of parse_perfect_shiftxor.cpp:193 / :179
+inline int cutoff_zero(int m) { return (m <= 6) ? 12 - m : m; }
+inline int cutoff_n(int m, int min_shift) { return (m <= 6) ? 12 - m : m + (m - min_shift); }
+
+int run_perfect_scan(RibbitHandle *h) {
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    if (h->runs_valid) return RIBBIT_OK;
+    h->runs.clear();
+    int rc = collect_events(h, 0);
+    if (rc) return rc;
+    const double t0 = now_ms();
+    const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
+    h->runs.reserve(h->produced / 2);
+    for (size_t mi = 0; mi < nm; ++mi) {
+        const int32_t mlen = h->params.min_motif + (int32_t)mi;
+        int64_t open = -1;
+        bool bad = false;
+        for_each_event(h, mi, [&](int64_t pos, uint32_t kind) {
+            if (kind == rb::EV_START) {
+                if (open != -1) { bad = true; return false; }
+                open = pos;
+            } else {
+                if (open == -1 || pos <= open) { bad = true; return false; }
+                const int term = kind == rb::EV_END_ZERO ? RIBBIT_TERM_ZERO : kind == rb::EV_END_N ? RIBBIT_TERM_N : RIBBIT_TERM_EOS;
+                h->runs.push_back(RibbitRun{(int32_t)open, (int32_t)pos, mlen, term});
+                open = -1;
+            }
+            return true;
+        });
+        if (bad || open != -1) return fail(RIBBIT_E_INTERNAL, "run START/END events of motif %d do not alternate", mlen);
+    }
+    h->host_ms = now_ms() - t0;
     h->runs_valid = true;
     return RIBBIT_OK;
+}
+
+void sort_calls(std::vector<RibbitCall> &calls) {
+    // reference call order: scan position major, motif minor; the end-of-sequence flush (pos == L) last
+    std::stable_sort(calls.begin(), calls.end(), [](const RibbitCall &a, const RibbitCall &b) {
+        return a.pos != b.pos ? a.pos < b.pos : a.mlen < b.mlen;
+    });
 }
 
 int build_perfect_calls(RibbitHandle *h) {
@@ -265,10 +339,55 @@ int build_perfect_calls(RibbitHandle *h) {
             if ((L - 1) - r.start >= cutoff_zero(r.mlen)) h->perfect_calls.push_back(RibbitCall{L, r.mlen, r.start, L - 1});
         }
     }
-    std::stable_sort(h->perfect_calls.begin(), h->perfect_calls.end(), [](const RibbitCall &a, const RibbitCall &b) {
-        return a.pos != b.pos ? a.pos < b.pos : a.mlen < b.mlen;
-    });
+    sort_calls(h->perfect_calls);
     h->calls_valid = true;
+    return RIBBIT_OK;
+}
+
+int advance_to_perfect(RibbitHandle *h) {
+    if (h->stage_done >= STAGE_PERFECT) return RIBBIT_OK;
+    int rc = build_perfect_calls(h);
+    if (rc) return rc;
+    h->lists.perfect.clear();
+    for (const RibbitCall &c : h->perfect_calls) rb::perfect_add(h->lists, c.start, c.end, c.mlen);
+    h->stage_done = STAGE_PERFECT;
+    return RIBBIT_OK;
+}
+
+// window scan (1 mismatch) + per-motif state machine -> the addSeed call list of
+// processShiftXORswithSubstitutions (parse_substitute_shiftxor.cpp:430-574)
+int build_subst_calls(RibbitHandle *h) {
+    if (h->subst_calls_valid) return RIBBIT_OK;
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    int rc = ensure_host_planes(h);
+    if (rc) return rc;
+    if ((rc = collect_events(h, 1))) return rc;
+    const double t0 = now_ms();
+    h->subst_calls.clear();
+    const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
+    for (size_t mi = 0; mi < nm; ++mi) {
+        const int32_t mlen = h->params.min_motif + (int32_t)mi;
+        rb::WindowFsm fsm(h->host, mlen, h->subst_calls);
+        bool ok = for_each_event(h, mi, [&](int64_t pos, uint32_t kind) { return fsm.event(pos, kind); });
+        if (!ok || !fsm.finish()) return fail(RIBBIT_E_INTERNAL, "window START/END events of motif %d do not alternate", mlen);
+    }
+    sort_calls(h->subst_calls);
+    h->host_ms = now_ms() - t0;
+    h->subst_calls_valid = true;
+    return RIBBIT_OK;
+}
+
+int advance_to_subst(RibbitHandle *h) {
+    if (h->stage_done >= STAGE_SUBST) return RIBBIT_OK;
+    int rc = advance_to_perfect(h);
+    if (rc) return rc;
+    if ((rc = build_subst_calls(h))) return rc;
+    const rb::HostPlanes *hp = &h->host;
+    h->lists.range_count = [hp](int shift, int start, int end) { return hp->range_count(shift, start, end); };
+    h->lists.subst.clear();
+    int from_index = 0;
+    for (const RibbitCall &c : h->subst_calls) from_index = rb::subst_add(h->lists, c.start, c.end, c.mlen, from_index, RIBBIT_RANK_S);
+    h->stage_done = STAGE_SUBST;
     return RIBBIT_OK;
 }
 
@@ -303,6 +422,8 @@ int ribbit_hip_open(const RibbitScanParams *params, int device, RibbitHandle **o
     if (params->min_motif < 1 || params->max_motif < params->min_motif || params->max_motif > 990)
         return fail(RIBBIT_E_ARG, "motif range [%d,%d] not supported (1 <= m <= M <= 990)", params->min_motif, params->max_motif);
     if (params->window_length != 8) return fail(RIBBIT_E_ARG, "window_length must be 8");
+    if (params->subst_threshold != 7 || params->anchor_threshold != 6 || params->anchor_length != 3)
+        return fail(RIBBIT_E_ARG, "only the reference's fixed thresholds are supported (7, 6, anchor 3: ribbit.cpp:191, fasta_utils.cpp:165)");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -367,7 +488,7 @@ int ribbit_hip_load_record_device(RibbitHandle *h, const void *dev_ascii, int64_
 int ribbit_hip_scan_perfect_runs(RibbitHandle *h, const RibbitRun **out, size_t *n) {
     if (!h || !out || !n) return fail(RIBBIT_E_ARG, "null argument");
     h->runs_valid = false;   // an explicit scan call always relaunches the kernel
-    h->calls_valid = h->seeds_perfect_valid = false;
+    h->calls_valid = false;
     int rc = run_perfect_scan(h);
     if (rc) return rc;
     *out = h->runs.data();
@@ -388,16 +509,81 @@ int ribbit_hip_perfect_calls(RibbitHandle *h, const RibbitCall **out, size_t *n)
 int ribbit_hip_seeds_perfect(RibbitHandle *h, const RibbitSeed **out, size_t *n) {
     if (!h || !out || !n) return fail(RIBBIT_E_ARG, "null argument");
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
-    if (!h->seeds_perfect_valid) {
-        int rc = build_perfect_calls(h);
-        if (rc) return rc;
-        h->lists.perfect.clear();
-        for (const RibbitCall &c : h->perfect_calls) rb::perfect_add(h->lists, c.start, c.end, c.mlen);
-        h->seeds_perfect_valid = true;
-    }
+    if (h->stage_done > STAGE_PERFECT) return fail(RIBBIT_E_STATE, "a later stage already re-typed the perfect list; reload the record");
+    int rc = advance_to_perfect(h);
+    if (rc) return rc;
     *out = h->lists.perfect.data();
     *n = h->lists.perfect.size();
     return RIBBIT_OK;
+}
+
+int ribbit_hip_subst_calls(RibbitHandle *h, const RibbitCall **out, size_t *n) {
+    if (!h || !out || !n) return fail(RIBBIT_E_ARG, "null argument");
+    int rc = build_subst_calls(h);
+    if (rc) return rc;
+    *out = h->subst_calls.data();
+    *n = h->subst_calls.size();
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_seeds_substitutions(RibbitHandle *h, const RibbitSeed **perfect, size_t *n_perfect,
+                                   const RibbitSeed **subst, size_t *n_subst) {
+    if (!h || !perfect || !n_perfect || !subst || !n_subst) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    if (h->stage_done > STAGE_SUBST) return fail(RIBBIT_E_STATE, "a later stage already re-typed the lists; reload the record");
+    int rc = advance_to_subst(h);
+    if (rc) return rc;
+    *perfect = h->lists.perfect.data();
+    *n_perfect = h->lists.perfect.size();
+    *subst = h->lists.subst.data();
+    *n_subst = h->lists.subst.size();
+    return RIBBIT_OK;
+}
+
+int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
+                             const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
+                             const RibbitCall *perfect_calls, size_t n_perfect_calls,
+                             const RibbitCall *subst_calls, size_t n_subst_calls,
+                             RibbitSeedLists *out) {
+    if (!params || !out || (length > 0 && (!hi || !lo || !brk))) return fail(RIBBIT_E_ARG, "null argument");
+    if ((n_perfect_calls && !perfect_calls) || (n_subst_calls && !subst_calls)) return fail(RIBBIT_E_ARG, "null call list");
+    const size_t need = (size_t)(length / 32 + 1) + (size_t)(params->max_motif + 2) / 32 + 2;
+    if (nwords < need) return fail(RIBBIT_E_ARG, "planes too short: %zu words, need %zu (zero padding past the record)", nwords, need);
+    std::memset(out, 0, sizeof *out);
+    rb::HostPlanes hp;
+    hp.resize(length, nwords);
+    std::memcpy(hp.hi.data(), hi, nwords * sizeof(uint32_t));
+    std::memcpy(hp.lo.data(), lo, nwords * sizeof(uint32_t));
+    std::memcpy(hp.brk.data(), brk, nwords * sizeof(uint32_t));
+    rb::SeedLists sl;
+    sl.length = length;
+    sl.min_motif = params->min_motif;
+    sl.max_motif = params->max_motif;
+    sl.min_shift = (params->min_motif > 2) ? params->min_motif - 2 : 1;
+    sl.range_count = [&hp](int shift, int start, int end) { return hp.range_count(shift, start, end); };
+    for (size_t i = 0; i < n_perfect_calls; ++i) rb::perfect_add(sl, perfect_calls[i].start, perfect_calls[i].end, perfect_calls[i].mlen);
+    int from_index = 0;
+    for (size_t i = 0; i < n_subst_calls; ++i)
+        from_index = rb::subst_add(sl, subst_calls[i].start, subst_calls[i].end, subst_calls[i].mlen, from_index, RIBBIT_RANK_S);
+    auto give = [](const std::vector<RibbitSeed> &v, RibbitSeed **p, size_t *n) {
+        *n = v.size();
+        *p = (RibbitSeed *)std::malloc(std::max<size_t>(v.size(), 1) * sizeof(RibbitSeed));
+        if (*p && !v.empty()) std::memcpy(*p, v.data(), v.size() * sizeof(RibbitSeed));
+        return *p != nullptr;
+    };
+    if (!give(sl.perfect, &out->perfect, &out->n_perfect) || !give(sl.subst, &out->subst, &out->n_subst) ||
+        !give(sl.anchored, &out->anchored, &out->n_anchored)) {
+        ribbit_seed_lists_free(out);
+        return fail(RIBBIT_E_NOMEM, "out of host memory");
+    }
+    out->guard_hits = sl.guard_hits;
+    return RIBBIT_OK;
+}
+
+void ribbit_seed_lists_free(RibbitSeedLists *lists) {
+    if (!lists) return;
+    std::free(lists->perfect); std::free(lists->subst); std::free(lists->anchored);
+    std::memset(lists, 0, sizeof *lists);
 }
 
 static int query_plane(RibbitHandle *h, int32_t shift, int64_t start, int64_t end, bool want_words, uint32_t *count_out) {
@@ -457,7 +643,8 @@ int ribbit_hip_packed_plane(RibbitHandle *h, int which, uint32_t *out_words) {
 
 int ribbit_hip_last_timing_ms(const RibbitHandle *h, int what, double *ms) {
     if (!h || !ms) return fail(RIBBIT_E_ARG, "null argument");
-    if (what < 0 || what > 2) return fail(RIBBIT_E_ARG, "what must be 0, 1 or 2");
+    if (what == 3) { *ms = h->host_ms; return RIBBIT_OK; }
+    if (what < 0 || what > 3) return fail(RIBBIT_E_ARG, "what must be 0..3");
     if (!h->have_timing[what]) return fail(RIBBIT_E_STATE, "no timing recorded yet");
     float f = 0.f;
     HIP_TRY(hipEventSynchronize(h->ev[2 * what + 1]));

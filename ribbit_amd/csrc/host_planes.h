@@ -1,0 +1,48 @@
+// host_planes.h -- host copy of the packed device planes (3 bits per base).
+//
+// The sequential seed-list merges (addSeedToSeedPositions*) ask for a handful of plane bits at a
+// time -- retainNestedSeed / retainIdenticalSeeds (parse_perfect_shiftxor.cpp:18-43) several
+// thousand times per Mbp -- and each answer steers the very next decision, so a GPU round trip per
+// query would cost tens of microseconds each.  The planes the GPU packed are therefore copied back
+// once per record and those sparse reads are answered here, word-parallel.  Nothing in this file
+// scans the sequence per (base, motif): that work exists only as HIP kernels.
+#pragma once
+#include <stdint.h>
+
+#include <utility>
+#include <vector>
+
+namespace rb {
+
+struct HostPlanes {
+    int64_t length = 0;
+    std::vector<uint32_t> hi, lo, brk;   // word 0 = bases 0..31, padded past L as on the device
+
+    // maximal intervals [first, last] of window starts q that are NOT evaluated by the window scans
+    // because an N lies in [q, q+7] (`valid_position < window_length`, parse_substitute_shiftxor.cpp:469)
+    std::vector<std::pair<int64_t, int64_t>> blocked;
+
+    void resize(int64_t len, size_t nwords) {
+        length = len;
+        hi.assign(nwords, 0); lo.assign(nwords, 0); brk.assign(nwords, 0);
+        blocked.clear();
+    }
+    void index_breaks();
+
+    // X_shift word w: bit b = (code[p] == code[p+shift]), p = 32w+b  (fasta_utils.cpp:120-122)
+    uint32_t x_word(int shift, int64_t w) const {
+        const int64_t q = shift >> 5;
+        const unsigned r = (unsigned)shift & 31u;
+        const uint64_t h2 = ((uint64_t)hi[w + q + 1] << 32) | hi[w + q];
+        const uint64_t l2 = ((uint64_t)lo[w + q + 1] << 32) | lo[w + q];
+        return ~((hi[w] ^ (uint32_t)(h2 >> r)) | (lo[w] ^ (uint32_t)(l2 >> r)));
+    }
+    // popcount of X_shift over [start, end)
+    int range_count(int shift, int start, int end) const;
+
+    // smallest window start q >= from that the window scans evaluate (0 <= q <= L-8, no N in
+    // [q, q+7]); -1 if there is none
+    int64_t first_evaluated(int64_t from) const;
+};
+
+}  // namespace rb

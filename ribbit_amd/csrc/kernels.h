@@ -22,6 +22,12 @@ struct PerfectLaunch {
 void launch_scan_perfect(const DevicePlanes &pl, const PerfectLaunch &pp, uint64_t *events, uint32_t *counters,
                          hipStream_t stream);
 
+// Window scan (parse_substitute_shiftxor.cpp:430-532 with allowed_mismatches = 1, i.e. threshold 7;
+// parse_anchored_shiftxor.cpp:580-679 with 2, threshold 6) -> pass-streak START / END events at
+// window-start positions.  Same event buffer conventions as launch_scan_perfect.
+void launch_scan_window(const DevicePlanes &pl, const PerfectLaunch &pp, int allowed_mismatches, uint64_t *events,
+                        uint32_t *counters, hipStream_t stream);
+
 // Gathers the used part of every region into `dense` (same capacity) in shard order and writes
 // counters[EV_SUMMARY] = total events, counters[EV_SUMMARY+1] = 1 if any region overflowed.
 void launch_compact_events(const uint64_t *events, uint32_t ev_cap, uint32_t *counters, uint64_t *dense,

@@ -118,6 +118,48 @@ __device__ __forceinline__ void sink_flush(const EventSink &sk, volatile uint64_
     staged = 0;
 }
 
+// Compact one motif's START (S) / END (E) bitmaps of this wave, in position order, into the
+// wave's LDS stage (or straight to global memory when there are more than EV_STAGE of them).
+// end_kind(k, bit, pos) classifies an END event.  Called wave-uniformly.
+template <typename EndKind>
+__device__ __forceinline__ void stage_events(const uint32_t (&S)[WORDS_PER_LANE], const uint32_t (&E)[WORDS_PER_LANE],
+                                             uint32_t word0, uint32_t mlen, const EventSink &sink,
+                                             volatile uint64_t *stage, int &staged, int lane, EndKind end_kind) {
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < WORDS_PER_LANE; k++) cnt += __popc(S[k]) + __popc(E[k]);
+    const int incl = wave_inclusive_scan(cnt);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (staged + total > EV_STAGE) sink_flush(sink, stage, staged, lane);
+    const bool direct = total > EV_STAGE;
+    uint32_t idx = (uint32_t)(incl - cnt);
+    uint64_t *gdst = nullptr;
+    if (direct) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&sink.counters[sink.shard * EV_COUNTER_STRIDE], (uint32_t)total);
+        idx += (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        gdst = sink.events + (size_t)sink.shard * sink.region_cap;
+    } else {
+        idx += (uint32_t)staged;
+    }
+#pragma unroll
+    for (int k = 0; k < WORDS_PER_LANE; k++) {
+        uint32_t both = S[k] | E[k];
+        while (both) {
+            const uint32_t b = (uint32_t)__builtin_ctz(both);
+            both &= both - 1u;
+            const uint32_t pos = ((word0 + (uint32_t)k) << 5) + b;
+            const uint32_t kind = ((S[k] >> b) & 1u) ? (uint32_t)EV_START : end_kind(k, b, pos);
+            const uint64_t e = ev_pack(pos, mlen, kind);
+            if (direct) { if (idx < sink.region_cap) gdst[idx] = e; }
+            else stage[idx] = e;
+            idx++;
+        }
+    }
+    if (!direct) staged += total;
+    __builtin_amdgcn_wave_barrier();
+}
+
 // -------------------------------------------------------------------------- perfect scan
 constexpr int K = WORDS_PER_LANE;
 constexpr int LDS_EXTRA = 40;   // halo + shifted-operand words (supports shifts < 1024)
@@ -231,44 +273,10 @@ __global__ __launch_bounds__(256) void scan_perfect_kernel(DevicePlanes pl, Perf
         }
 
         if (__ballot(any != 0) != 0ull) {
-            // compact this wave's events in position order into the LDS stage
-            int cnt = 0;
-#pragma unroll
-            for (int k = 0; k < K; k++) cnt += __popc(SQ[k]) + __popc(EQ[k]);
-            const int incl = wave_inclusive_scan(cnt);
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            if (staged + total > EV_STAGE) sink_flush(sink, stage, staged, lane);
-            const bool direct = total > EV_STAGE;   // denser than the stage: write straight to global
-            uint32_t idx = (uint32_t)(incl - cnt);
-            uint64_t *gdst = nullptr;
-            if (direct) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&sink.counters[sink.shard * EV_COUNTER_STRIDE], (uint32_t)total);
-                idx += (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                gdst = sink.events + (size_t)sink.shard * sink.region_cap;
-            } else {
-                idx += (uint32_t)staged;
-            }
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                uint32_t both = SQ[k] | EQ[k];
-                while (both) {
-                    const uint32_t b = (uint32_t)__builtin_ctz(both);
-                    both &= both - 1u;
-                    const uint32_t pos = ((word0 + (uint32_t)k) << 5) + b;
-                    uint32_t kind;
-                    if ((SQ[k] >> b) & 1u) kind = EV_START;
-                    else if (pos >= length) kind = EV_END_EOS;
-                    else if ((Bk[k + 1] >> b) & 1u) kind = EV_END_N;
-                    else kind = EV_END_ZERO;
-                    const uint64_t e = ev_pack(pos, (uint32_t)m, kind);
-                    if (direct) { if (idx < sink.region_cap) gdst[idx] = e; }
-                    else stage[idx] = e;
-                    idx++;
-                }
-            }
-            if (!direct) staged += total;
-            __builtin_amdgcn_wave_barrier();
+            stage_events(SQ, EQ, word0, (uint32_t)m, sink, stage, staged, lane, [&](int k, uint32_t b, uint32_t pos) {
+                if (pos >= length) return (uint32_t)EV_END_EOS;
+                return ((Bk[k + 1] >> b) & 1u) ? (uint32_t)EV_END_N : (uint32_t)EV_END_ZERO;
+            });
         }
     }
     sink_flush(sink, stage, staged, lane);
@@ -286,6 +294,158 @@ void launch_scan_perfect(const DevicePlanes &pl, const PerfectLaunch &pp, uint64
     gy = (nm + motifs_per_block - 1) / motifs_per_block;
     dim3 grid((unsigned)pl.ntiles, (unsigned)gy);
     hipLaunchKernelGGL(scan_perfect_kernel, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, events, counters);
+}
+
+// --------------------------------------------------------------------------- window scan
+// Hot loop of processShiftXORswithSubstitutions (parse_substitute_shiftxor.cpp:430-532) and, with
+// ALLOWED = 2, of processShiftXORsAnchored (parse_anchored_shiftxor.cpp:580-679).
+// The reference slides an 8-bit window over X_m, skipping N: at scan position p (window start
+// q = p-7) it "passes" when popcount(X_m[q..q+7]) >= 8-ALLOWED and no N lies in [q, q+7]
+// (`valid_position >= window_length`).  Here, per 32-base word and motif:
+//   ge2 / ge3 = "at least 2 / 3 mismatches in [q, q+7]"   bit-sliced counter, 3 doubling levels
+//   pass      = evaluated & ~(ALLOWED == 1 ? ge2 : ge3)
+// and only the transitions of `pass` leave the chip: START at the first passing q of a streak,
+// END at the first non-passing q after it, classified FAIL (evaluated, failed -> the reference's
+// "pending end" is q+7), N (position q+7 is an N: the streak is discarded, :433-458) or EOS
+// (q+7 == L: streak still open at the end-of-sequence flush, :534-574).  The per-motif finite
+// state machine that turns streaks into addSeed calls is replayed on the host from these events.
+template <int ALLOWED>
+__global__ __launch_bounds__(256) void scan_window_kernel(DevicePlanes pl, PerfectLaunch pp, int motifs_per_block,
+                                                          uint64_t *__restrict__ events,
+                                                          uint32_t *__restrict__ counters) {
+    __shared__ uint32_t s_hi[TILE_WORDS + LDS_EXTRA];
+    __shared__ uint32_t s_lo[TILE_WORDS + LDS_EXTRA];
+    __shared__ uint32_t s_brk[TILE_WORDS + 8];
+    __shared__ uint64_t s_stage[4][EV_STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t tile_base = (int64_t)blockIdx.x * TILE_WORDS;
+
+    const int bm_lo = pp.m_lo + (int)blockIdx.y * motifs_per_block;
+    const int bm_hi = min(pp.m_hi, bm_lo + motifs_per_block - 1);
+    const int q_hi = bm_hi >> 5;
+    const int n_ext = TILE_WORDS + 4 + q_hi;
+    for (int i = threadIdx.x; i < n_ext; i += 256) {
+        s_hi[i] = pl.hi[tile_base - 1 + i];
+        s_lo[i] = pl.lo[tile_base - 1 + i];
+    }
+    for (int i = threadIdx.x; i < TILE_WORDS + 2; i += 256) s_brk[i] = pl.brk[tile_base - 1 + i];
+    __syncthreads();
+
+    const int nmb = bm_hi - bm_lo + 1;
+    const int per = (nmb + 3) >> 2;
+    const int wm_lo = bm_lo + wave * per;
+    const int wm_hi = min(bm_hi, wm_lo + per - 1);
+    if (wm_lo > wm_hi) return;
+
+    const int lb = lane * K;
+    uint32_t H[K + 2], Lo[K + 2];
+    uint32_t EVAL[K + 1];   // words k = -1 .. K-1: window starting here holds no break
+    {
+        uint32_t B[K + 2];
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) { H[j] = s_hi[lb + j]; Lo[j] = s_lo[lb + j]; B[j] = s_brk[lb + j]; }
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) B[j] |= funnel(B[j + 1], B[j], 1);
+        B[K + 1] |= B[K + 1] >> 1;
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) B[j] |= funnel(B[j + 1], B[j], 2);
+        B[K + 1] |= B[K + 1] >> 2;
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) EVAL[j] = ~(B[j] | funnel(B[j + 1], B[j], 4));
+    }
+
+    uint32_t Hq[K + 3], Lq[K + 3];
+    int cur_q = -1;
+    const uint32_t length = (uint32_t)pl.length;
+    const uint32_t word0 = (uint32_t)(tile_base + lb);
+
+    EventSink sink;
+    sink.events = events;
+    sink.counters = counters;
+    sink.region_cap = pp.ev_cap / EV_SHARDS;
+    sink.shard = (blockIdx.x * 4u + (uint32_t)wave + blockIdx.y) % EV_SHARDS;
+    volatile uint64_t *stage = s_stage[wave];
+    int staged = 0;
+
+    for (int m = wm_lo; m <= wm_hi; ++m) {
+        const int q = m >> 5;
+        const uint32_t r = (uint32_t)m & 31u;
+        if (q != cur_q) {
+            cur_q = q;
+#pragma unroll
+            for (int j = 0; j < K + 3; j++) { Hq[j] = s_hi[lb + j + q]; Lq[j] = s_lo[lb + j + q]; }
+        }
+        // A1 = any mismatch in a span, B1 = at least two, C1 = at least three (spans 1 -> 2 -> 4 -> 8)
+        uint32_t A1[K + 2], B1[K + 2], C1[K + 2];
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) {
+            const uint32_t hs = funnel(Hq[j + 1], Hq[j], r);
+            const uint32_t ls = funnel(Lq[j + 1], Lq[j], r);
+            A1[j] = (H[j] ^ hs) | (Lo[j] ^ ls);     // mismatch word (N compares as A, as in the reference)
+        }
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) {          // span 2
+            const uint32_t sa = (j <= K) ? funnel(A1[j + 1 <= K + 1 ? j + 1 : j], A1[j], 1) : (A1[j] >> 1);
+            B1[j] = A1[j] & sa;
+            A1[j] = A1[j] | sa;
+        }
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) {          // span 4
+            const uint32_t sa = (j <= K) ? funnel(A1[j + 1 <= K + 1 ? j + 1 : j], A1[j], 2) : (A1[j] >> 2);
+            const uint32_t sb = (j <= K) ? funnel(B1[j + 1 <= K + 1 ? j + 1 : j], B1[j], 2) : (B1[j] >> 2);
+            if (ALLOWED == 2) C1[j] = (B1[j] & sa) | (A1[j] & sb);
+            B1[j] = B1[j] | sb | (A1[j] & sa);
+            A1[j] = A1[j] | sa;
+        }
+        uint32_t PASS[K + 1];
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) {          // span 8, words k = -1 .. K-1 only
+            const uint32_t sa = funnel(A1[j + 1], A1[j], 4);
+            const uint32_t sb = funnel(B1[j + 1], B1[j], 4);
+            uint32_t bad;
+            if (ALLOWED == 2) {
+                const uint32_t sc = funnel(C1[j + 1], C1[j], 4);
+                bad = C1[j] | sc | (B1[j] & sa) | (A1[j] & sb);
+            } else {
+                bad = B1[j] | sb | (A1[j] & sa);
+            }
+            PASS[j] = EVAL[j] & ~bad;
+        }
+        uint32_t ST[K], EN[K];
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint32_t prev = funnel(PASS[k + 1], PASS[k], 31);   // bit b = pass at q-1
+            ST[k] = PASS[k + 1] & ~prev;
+            EN[k] = ~PASS[k + 1] & prev;
+            any |= ST[k] | EN[k];
+        }
+        if (__ballot(any != 0) != 0ull) {
+            stage_events(ST, EN, word0, (uint32_t)m, sink, stage, staged, lane, [&](int k, uint32_t b, uint32_t pos) {
+                if ((EVAL[k + 1] >> b) & 1u) return (uint32_t)EV_END_ZERO;          // evaluated and failed
+                return (pos + 7u >= length) ? (uint32_t)EV_END_EOS : (uint32_t)EV_END_N;
+            });
+        }
+    }
+    sink_flush(sink, stage, staged, lane);
+}
+
+void launch_scan_window(const DevicePlanes &pl, const PerfectLaunch &pp, int allowed_mismatches, uint64_t *events,
+                        uint32_t *counters, hipStream_t stream) {
+    const int nm = pp.m_hi - pp.m_lo + 1;
+    if (nm <= 0 || pl.ntiles <= 0) return;
+    int64_t want_y = (2048 + pl.ntiles - 1) / pl.ntiles;
+    int max_y = (nm + 3) / 4;
+    int gy = (int)(want_y < 1 ? 1 : (want_y > max_y ? max_y : want_y));
+    int motifs_per_block = (nm + gy - 1) / gy;
+    gy = (nm + motifs_per_block - 1) / motifs_per_block;
+    dim3 grid((unsigned)pl.ntiles, (unsigned)gy);
+    if (allowed_mismatches == 1)
+        hipLaunchKernelGGL(scan_window_kernel<1>, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, events, counters);
+    else
+        hipLaunchKernelGGL(scan_window_kernel<2>, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, events, counters);
 }
 
 // ------------------------------------------------------------------------ event compaction

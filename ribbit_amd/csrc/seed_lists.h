@@ -26,4 +26,12 @@ struct SeedLists {
 // addSeedToSeedPositionsPerfect, parse_perfect_shiftxor.cpp:47-142
 void perfect_add(SeedLists &sl, int seed_start, int seed_end, int mlen);
 
+// seedlen_cutoffs of processShiftXORswithSubstitutions (parse_substitute_shiftxor.cpp:423)
+inline int subst_seedlen_cutoff(int mlen) { return mlen > 30 ? mlen / 3 : 10; }
+// seedlen_cutoffs of processShiftXORsAnchored (parse_anchored_shiftxor.cpp:572-573)
+inline int anchored_seedlen_cutoff(int mlen) { return mlen >= 10 ? (int)(0.9 * mlen) : (mlen > 6 ? mlen : 10); }
+
+// addSeedToSeedPositionsSubstitutions, parse_substitute_shiftxor.cpp:18-388; returns the new cursor
+int subst_add(SeedLists &sl, int seed_start, int seed_end, int mlen, int from_index, int seed_type);
+
 }  // namespace rb

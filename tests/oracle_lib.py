@@ -45,6 +45,8 @@ def lib():
         L.rbo_length.argtypes = [C.c_void_p]
         L.rbo_guard_hits.restype = C.c_int64
         L.rbo_guard_hits.argtypes = [C.c_void_p]
+        L.rbo_range_queries.restype = C.c_int64
+        L.rbo_range_queries.argtypes = [C.c_void_p]
         for f in ("rbo_plane", "rbo_anchor_plane"):
             getattr(L, f).restype = C.POINTER(C.c_uint8)
             getattr(L, f).argtypes = [C.c_void_p, C.c_int]
@@ -152,3 +154,6 @@ class Oracle:
 
     def guard_hits(self):
         return self._L.rbo_guard_hits(self._h)
+
+    def range_queries(self):
+        return self._L.rbo_range_queries(self._h)

@@ -1,0 +1,61 @@
+"""CPU tests of the product's host-side seed-list merges (ribbit_amd/csrc/seed_lists.cpp) through
+the C ABI entry ribbit_host_replay_calls: the oracle's call logs are replayed through the product's
+own, independently written merges and the resulting lists must equal the oracle's bit for bit.
+No GPU needed; the GPU tests check that the kernels reproduce the call logs themselves."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import ribbit_amd
+from cases import edge_cases, simulated_cases
+from oracle_lib import LIST_PERFECT, LIST_SUBST, Oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALL = edge_cases() + simulated_cases()
+
+
+def test_pack_planes_matches_oracle_encoding():
+    for name, seq, m_lo, m_hi in edge_cases():
+        hi, lo, brk = ribbit_amd.pack_planes(seq, m_hi)
+        n = len(seq)
+        with Oracle(seq, m_lo, m_hi) as o:
+            code, nmask = o.codes(), o.nmask()
+        bits = lambda w: np.unpackbits(w.view(np.uint8), bitorder="little")
+        assert np.array_equal(bits(hi)[:n], code >> 1) and np.array_equal(bits(lo)[:n], code & 1), name
+        assert np.array_equal(bits(brk)[:n], nmask) and bits(brk)[n:].all() and not bits(hi)[n:].any(), name
+
+
+@pytest.mark.parametrize("name,seq,m_lo,m_hi", ALL, ids=[c[0] for c in ALL])
+def test_replay_of_oracle_calls_reproduces_oracle_lists(name, seq, m_lo, m_hi):
+    with Oracle(seq, m_lo, m_hi) as o:
+        o.run_perfect()
+        perfect_after_p = o.seeds(LIST_PERFECT)
+        pcalls = o.calls(LIST_PERFECT)
+        p_only, _, _, _ = ribbit_amd.host_replay_calls(m_lo, m_hi, seq, pcalls)
+        assert np.array_equal(p_only.view("<i4"), perfect_after_p.view("<i4"))
+        o.run_subst()
+        perfect, subst, _, guards = ribbit_amd.host_replay_calls(m_lo, m_hi, seq, pcalls, o.calls(LIST_SUBST))
+        assert np.array_equal(perfect.view("<i4"), o.seeds(LIST_PERFECT).view("<i4"))
+        assert np.array_equal(subst.view("<i4"), o.seeds(LIST_SUBST).view("<i4"))
+        assert guards == 0
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=lambda p: os.path.basename(p)[:-4])
+def test_replay_matches_fixture(path):
+    g = np.load(path)
+    seq = g["seq"].tobytes()
+    perfect, subst, _, _ = ribbit_amd.host_replay_calls(int(g["m_lo"]), int(g["m_hi"]), seq, g["perfect_calls"], g["subst_calls"])
+    assert np.array_equal(perfect.view("<i4"), g["perfect_after_s"].view("<i4"))
+    assert np.array_equal(subst.view("<i4"), g["subst_after_s"].view("<i4"))
+
+
+def test_replay_rejects_short_planes(hip_lib):
+    import ctypes as C
+    p = ribbit_amd.ScanParams()
+    hip_lib.ribbit_scan_params_default(C.byref(p), 2, 100)
+    w = np.zeros(4, dtype=np.uint32)
+    out = ribbit_amd.SeedLists()
+    rc = hip_lib.ribbit_host_replay_calls(C.byref(p), 100, w.ctypes.data, w.ctypes.data, w.ctypes.data, 4, None, 0, None, 0, C.byref(out))
+    assert rc == -1 and b"planes too short" in hip_lib.ribbit_hip_last_error()
