@@ -129,6 +129,34 @@ int ribbit_hip_seeds_substitutions(RibbitHandle *h, const RibbitSeed **perfect, 
                                    const RibbitSeed **subst, size_t *n_subst);
 
 /*
+ * The addSeedToSeedPositionsAnchored calls processShiftXORsAnchored would make
+ * (parse_anchored_shiftxor.cpp:580-723), in its call order.  Runs the fused anchored kernel:
+ * generateAnchoredShiftXORs (parse_anchored_shiftxor.h:10, called at fasta_utils.cpp:144), the plane
+ * composition of fasta_utils.cpp:146-160 and the 6-of-8 window scan.  After this call "plane m"
+ * means the composed plane for every motif length m (as in the reference, fasta_utils.cpp:159).
+ * This build handles max_motif <= 110 in the anchored stage.
+ */
+int ribbit_hip_anchored_calls(RibbitHandle *h, const RibbitCall **out, size_t *n);
+
+/*
+ * processShiftXORsAnchored (parse_anchored_shiftxor.h:14; called at fasta_utils.cpp:166).  Runs the
+ * earlier stages first if needed.  Returns all three seed lists as the stage leaves them.
+ */
+int ribbit_hip_seeds_anchored(RibbitHandle *h, const RibbitSeed **perfect, size_t *n_perfect,
+                              const RibbitSeed **subst, size_t *n_subst,
+                              const RibbitSeed **anchored, size_t *n_anchored);
+
+/*
+ * The 3-way merge by start of fasta_utils.cpp:187-224: the seeds handed to refinement
+ * (processSeedMotifWise / processSeed), in order, RANK_N entries and seeds shorter than 0.9*m dropped.
+ */
+int ribbit_hip_dispatch_seeds(RibbitHandle *h, const RibbitSeed **out, size_t *n);
+
+/* How often the defined-divergence guards fired in the merges of this record (the
+ * reference has undefined behaviour there; 0 on ordinary inputs). */
+int64_t ribbit_hip_guard_hits(const RibbitHandle *h);
+
+/*
  * Bits [start, end) of shift plane `shift` (X_shift, or the anchored plane once
  * ribbit_hip_anchor_planes has run), one byte per base.  Replaces reads of
  * lshift_xor_bsets[shift-MINIMUM_SHIFT][L-1-p] (fasta_utils.cpp:220-222, parse_seed.cpp:366).
@@ -157,12 +185,17 @@ typedef struct RibbitSeedLists {
     RibbitSeed *perfect;  size_t n_perfect;
     RibbitSeed *subst;    size_t n_subst;
     RibbitSeed *anchored; size_t n_anchored;
+    RibbitSeed *dispatch; size_t n_dispatch;   /* fasta_utils.cpp:187-224 order */
     int64_t guard_hits;   /* defined-divergence guards that fired */
 } RibbitSeedLists;
+/* xa: composed planes XA_m for m = min_motif..max_motif, xa_stride words each (may be NULL when
+ * there are no anchored calls). */
 int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
                              const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
+                             const uint32_t *xa, size_t xa_stride,
                              const RibbitCall *perfect_calls, size_t n_perfect_calls,
                              const RibbitCall *subst_calls, size_t n_subst_calls,
+                             const RibbitCall *anchored_calls, size_t n_anchored_calls,
                              RibbitSeedLists *out);
 void ribbit_seed_lists_free(RibbitSeedLists *lists);
 

@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-__all__ = ["RibbitHipError", "ScanParams", "Scanner", "library_path", "load_library", "host_replay_calls", "pack_planes",
+__all__ = ["RibbitHipError", "ScanParams", "Scanner", "library_path", "load_library", "host_replay_calls", "pack_planes", "pack_bit_planes",
            "RUN_DT", "CALL_DT", "SEED_DT", "RANK", "TERM"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_last_timing_ms", "ribbit_hip_last_event_count",
     "ribbit_hip_subst_calls", "ribbit_hip_seeds_substitutions",
     "ribbit_host_replay_calls", "ribbit_seed_lists_free",
+    "ribbit_hip_anchored_calls", "ribbit_hip_seeds_anchored", "ribbit_hip_dispatch_seeds", "ribbit_hip_guard_hits",
 ]
 
 
@@ -50,7 +51,8 @@ class ScanParams(C.Structure):
 class SeedLists(C.Structure):
     """RibbitSeedLists (malloc'ed arrays returned by ribbit_host_replay_calls)."""
     _fields_ = [("perfect", C.c_void_p), ("n_perfect", C.c_size_t), ("subst", C.c_void_p), ("n_subst", C.c_size_t),
-                ("anchored", C.c_void_p), ("n_anchored", C.c_size_t), ("guard_hits", C.c_int64)]
+                ("anchored", C.c_void_p), ("n_anchored", C.c_size_t), ("dispatch", C.c_void_p), ("n_dispatch", C.c_size_t),
+                ("guard_hits", C.c_int64)]
 
 
 def library_path() -> str:
@@ -82,11 +84,15 @@ def load_library():
     L.ribbit_hip_set_stream.argtypes = [vp, vp]
     L.ribbit_hip_load_record.argtypes = [vp, C.c_char_p, i64]
     L.ribbit_hip_load_record_device.argtypes = [vp, vp, i64]
-    for f in ("ribbit_hip_scan_perfect_runs", "ribbit_hip_perfect_calls", "ribbit_hip_seeds_perfect", "ribbit_hip_subst_calls"):
+    for f in ("ribbit_hip_scan_perfect_runs", "ribbit_hip_perfect_calls", "ribbit_hip_seeds_perfect", "ribbit_hip_subst_calls",
+              "ribbit_hip_anchored_calls", "ribbit_hip_dispatch_seeds"):
         getattr(L, f).argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.ribbit_hip_seeds_substitutions.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
-    L.ribbit_host_replay_calls.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t,
-                                           C.POINTER(SeedLists)]
+    L.ribbit_hip_seeds_anchored.argtypes = [vp] + [C.POINTER(vp), C.POINTER(C.c_size_t)] * 3
+    L.ribbit_hip_guard_hits.restype = i64
+    L.ribbit_hip_guard_hits.argtypes = [vp]
+    L.ribbit_host_replay_calls.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t,
+                                           vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(SeedLists)]
     L.ribbit_seed_lists_free.restype = None
     L.ribbit_seed_lists_free.argtypes = [C.POINTER(SeedLists)]
     L.ribbit_hip_plane_bits.argtypes = [vp, i32, i64, i64, vp]
@@ -128,22 +134,39 @@ def pack_planes(sequence: bytes, max_motif: int):
     return pack(code >> 1), pack(code & 1), brk
 
 
-def host_replay_calls(min_motif: int, max_motif: int, sequence: bytes, perfect_calls, subst_calls=None):
-    """ribbit_host_replay_calls: call lists -> (perfect, subst, anchored seed lists, guard_hits). No GPU needed."""
+def pack_bit_planes(planes_bits, length: int):
+    """list of byte-per-base 0/1 arrays -> (uint32 words motif-major, stride): the xa argument of
+    ribbit_host_replay_calls."""
+    stride = (length // 32 + 1 + 7) // 8 * 8 + 16
+    out = np.zeros((len(planes_bits), stride), dtype="<u4")
+    for i, bits in enumerate(planes_bits):
+        buf = np.zeros(stride * 32, dtype=np.uint8)
+        buf[:length] = bits
+        out[i] = np.packbits(buf, bitorder="little").view("<u4")
+    return np.ascontiguousarray(out), stride
+
+
+def host_replay_calls(min_motif: int, max_motif: int, sequence: bytes, perfect_calls, subst_calls=None,
+                      anchored_calls=None, xa=None, xa_stride: int = 0):
+    """ribbit_host_replay_calls: call lists -> dict(perfect, subst, anchored, dispatch, guard_hits). No GPU needed."""
     L = load_library()
     params = ScanParams()
     L.ribbit_scan_params_default(C.byref(params), min_motif, max_motif)
     hi, lo, brk = pack_planes(sequence, max_motif)
+    empty = np.zeros(0, CALL_DT)
     pc = np.ascontiguousarray(perfect_calls, dtype=CALL_DT)
-    sc = np.ascontiguousarray(subst_calls if subst_calls is not None else np.zeros(0, CALL_DT), dtype=CALL_DT)
+    sc = np.ascontiguousarray(subst_calls if subst_calls is not None else empty, dtype=CALL_DT)
+    ac = np.ascontiguousarray(anchored_calls if anchored_calls is not None else empty, dtype=CALL_DT)
     out = SeedLists()
     rc = L.ribbit_host_replay_calls(C.byref(params), len(sequence), hi.ctypes.data, lo.ctypes.data, brk.ctypes.data, len(hi),
-                                    pc.ctypes.data, len(pc), sc.ctypes.data, len(sc), C.byref(out))
+                                    xa.ctypes.data if xa is not None else None, xa_stride,
+                                    pc.ctypes.data, len(pc), sc.ctypes.data, len(sc), ac.ctypes.data, len(ac), C.byref(out))
     if rc != 0:
         raise RibbitHipError(f"ribbit_host_replay_calls error {rc}: {L.ribbit_hip_last_error().decode()}")
     try:
-        return (_copy(out.perfect, out.n_perfect, SEED_DT), _copy(out.subst, out.n_subst, SEED_DT),
-                _copy(out.anchored, out.n_anchored, SEED_DT), int(out.guard_hits))
+        return {"perfect": _copy(out.perfect, out.n_perfect, SEED_DT), "subst": _copy(out.subst, out.n_subst, SEED_DT),
+                "anchored": _copy(out.anchored, out.n_anchored, SEED_DT), "dispatch": _copy(out.dispatch, out.n_dispatch, SEED_DT),
+                "guard_hits": int(out.guard_hits)}
     finally:
         L.ribbit_seed_lists_free(C.byref(out))
 
@@ -225,6 +248,26 @@ class Scanner:
         pp, np_, ps, ns = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
         self._check(self._L.ribbit_hip_seeds_substitutions(self._h, C.byref(pp), C.byref(np_), C.byref(ps), C.byref(ns)))
         return _copy(pp.value, np_.value, SEED_DT), _copy(ps.value, ns.value, SEED_DT)
+
+    # parse_anchored_shiftxor.cpp:20-56, 538-726; fasta_utils.cpp:143-224 --------------------
+    def anchored_calls(self):
+        return self._list(self._L.ribbit_hip_anchored_calls, CALL_DT)
+
+    def processShiftXORsAnchored(self):
+        """-> (perfect, substitution, anchored seed lists as the anchored stage leaves them)"""
+        ptrs = [C.c_void_p() for _ in range(3)]
+        ns = [C.c_size_t() for _ in range(3)]
+        args = []
+        for p, n in zip(ptrs, ns):
+            args += [C.byref(p), C.byref(n)]
+        self._check(self._L.ribbit_hip_seeds_anchored(self._h, *args))
+        return tuple(_copy(p.value, n.value, SEED_DT) for p, n in zip(ptrs, ns))
+
+    def dispatch_seeds(self):
+        return self._list(self._L.ribbit_hip_dispatch_seeds, SEED_DT)
+
+    def guard_hits(self) -> int:
+        return int(self._L.ribbit_hip_guard_hits(self._h))
 
     # plane access -----------------------------------------------------------------------
     def plane_bits(self, shift: int, start: int = 0, end: int | None = None):

@@ -77,7 +77,7 @@ double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-enum Stage { STAGE_NONE = 0, STAGE_PERFECT = 1, STAGE_SUBST = 2 };
+enum Stage { STAGE_NONE = 0, STAGE_PERFECT = 1, STAGE_SUBST = 2, STAGE_ANCHORED = 3 };
 
 }  // namespace
 
@@ -99,6 +99,8 @@ struct RibbitHandle {
     DevBuf<uint64_t> d_events, d_dense;
     DevBuf<uint32_t> d_counters;
     DevBuf<uint32_t> d_query;
+    DevBuf<uint32_t> d_xa;             // composed planes XA_m, motif-major
+    int64_t xa_stride = 0;
     PinnedBuf<uint64_t> h_events;
     PinnedBuf<uint32_t> h_counters;
     PinnedBuf<uint32_t> h_query;
@@ -119,6 +121,9 @@ struct RibbitHandle {
     std::vector<RibbitCall> perfect_calls;
     bool subst_calls_valid = false;
     std::vector<RibbitCall> subst_calls;
+    bool anchored_calls_valid = false;
+    std::vector<RibbitCall> anchored_calls;
+    std::vector<RibbitSeed> dispatch;
     int stage_done = STAGE_NONE;          // how far the seed lists have been advanced
     rb::SeedLists lists;
 
@@ -149,7 +154,7 @@ int is_gfx950(int device) {
 
 int pack_loaded_ascii(RibbitHandle *h, const uint8_t *dev_ascii, int64_t length) {
     h->loaded = false;
-    h->runs_valid = h->calls_valid = h->subst_calls_valid = false;
+    h->runs_valid = h->calls_valid = h->subst_calls_valid = h->anchored_calls_valid = false;
     h->host_planes_valid = false;
     h->stage_done = STAGE_NONE;
     h->length = length;
@@ -192,7 +197,7 @@ int ensure_host_planes(RibbitHandle *h) {
 }
 
 // Launch one scan kernel, compact its sharded event regions, copy the events back and index the
-// (motif, tile) chunks.  which: 0 perfect run scan, 1 window scan (1 mismatch), 2 window scan (2).
+// (motif, tile) chunks.  which: 0 perfect run scan, 1 window scan (1 mismatch), 2 fused anchored scan.
 int collect_events(RibbitHandle *h, int which) {
     int rc;
     if ((rc = bind_device(h))) return rc;
@@ -215,7 +220,8 @@ int collect_events(RibbitHandle *h, int which) {
         pp.ev_cap = (uint32_t)cap;
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
         if (which == 0) rb::launch_scan_perfect(pl, pp, h->d_events.p, h->d_counters.p, h->stream);
-        else rb::launch_scan_window(pl, pp, which, h->d_events.p, h->d_counters.p, h->stream);
+        else if (which == 1) rb::launch_scan_window(pl, pp, 1, h->d_events.p, h->d_counters.p, h->stream);
+        else rb::launch_scan_anchored(pl, pp, h->d_xa.p, h->xa_stride, h->d_events.p, h->d_counters.p, h->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[3], h->stream));
         rb::launch_compact_events(h->d_events.p, pp.ev_cap, h->d_counters.p, h->d_dense.p, h->stream);
@@ -246,7 +252,8 @@ int collect_events(RibbitHandle *h, int which) {
     const uint64_t *ev = h->h_events.p;
     const uint32_t m_lo = (uint32_t)h->params.min_motif;
     const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
-    const size_t ntile = (size_t)(h->length / rb::TILE_BASES + 1);
+    const uint32_t tile_bases = which == 2 ? (uint32_t)rb::ATILE_BASES : (uint32_t)rb::TILE_BASES;
+    const size_t ntile = (size_t)(h->length / tile_bases + 1);
     struct Chunk { uint32_t off, n; };
     static_assert(sizeof(Chunk) == sizeof(uint64_t), "chunk table entry is one 64-bit word");
     h->chunk_table.assign(nm * ntile, 0);
@@ -254,9 +261,9 @@ int collect_events(RibbitHandle *h, int which) {
     Chunk *table = reinterpret_cast<Chunk *>(h->chunk_table.data());
     for (size_t i = 0; i < produced;) {
         const uint32_t m = rb::ev_mlen(ev[i]);
-        const uint32_t tile = rb::ev_pos(ev[i]) / (uint32_t)rb::TILE_BASES;
+        const uint32_t tile = rb::ev_pos(ev[i]) / tile_bases;
         size_t j = i + 1;
-        while (j < produced && rb::ev_mlen(ev[j]) == m && rb::ev_pos(ev[j]) / (uint32_t)rb::TILE_BASES == tile) ++j;
+        while (j < produced && rb::ev_mlen(ev[j]) == m && rb::ev_pos(ev[j]) / tile_bases == tile) ++j;
         if (m < m_lo || m - m_lo >= nm || tile >= ntile) return fail(RIBBIT_E_INTERNAL, "malformed event (motif %u, tile %u)", m, tile);
         const size_t key = (size_t)(m - m_lo) * ntile + tile;
         if (table[key].n) return fail(RIBBIT_E_INTERNAL, "duplicate event chunk (motif %u, tile %u)", m, tile);
@@ -391,6 +398,73 @@ int advance_to_subst(RibbitHandle *h) {
     return RIBBIT_OK;
 }
 
+// fused anchored kernel (anchor planes + composition + 6-of-8 window scan) + state machine ->
+// the addSeed call list of processShiftXORsAnchored (parse_anchored_shiftxor.cpp:580-723); also
+// materialises the composed planes XA_m and copies them to the host for the merges' range reads.
+int build_anchored_calls(RibbitHandle *h) {
+    if (h->anchored_calls_valid) return RIBBIT_OK;
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    if (h->params.max_motif > rb::ANCHORED_MAX_MOTIF)
+        return fail(RIBBIT_E_ARG, "the anchored stage of this build supports max_motif <= %d (got %d)", rb::ANCHORED_MAX_MOTIF, h->params.max_motif);
+    int rc = ensure_host_planes(h);
+    if (rc) return rc;
+    const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
+    h->xa_stride = ((h->length / 32 + 1) + 7) / 8 * 8 + 16;
+    if ((rc = h->d_xa.ensure(nm * (size_t)h->xa_stride))) return rc;
+    if ((rc = collect_events(h, 2))) return rc;
+    // composed planes -> host (the sequential merges read a few bits at a time, far too often for a GPU round trip each)
+    h->host.xa.resize(nm * (size_t)h->xa_stride);
+    h->host.xa_stride = h->xa_stride;
+    h->host.xa_m_lo = h->params.min_motif;
+    h->host.xa_m_hi = h->params.max_motif;
+    HIP_TRY(hipMemcpyAsync(h->host.xa.data(), h->d_xa.p, nm * (size_t)h->xa_stride * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const double t0 = now_ms();
+    h->anchored_calls.clear();
+    for (size_t mi = 0; mi < nm; ++mi) {
+        const int32_t mlen = h->params.min_motif + (int32_t)mi;
+        rb::WindowFsm fsm(h->host, mlen, h->anchored_calls);
+        bool ok = for_each_event(h, mi, [&](int64_t pos, uint32_t kind) { return fsm.event(pos, kind); });
+        if (!ok || !fsm.finish()) return fail(RIBBIT_E_INTERNAL, "anchored START/END events of motif %d do not alternate", mlen);
+    }
+    sort_calls(h->anchored_calls);
+    h->host_ms = now_ms() - t0;
+    h->anchored_calls_valid = true;
+    return RIBBIT_OK;
+}
+
+// Replay of the anchored call list.  In the reference every in-loop call updates the cursor pair,
+// but the end-of-sequence flush keeps the returned cursors only for the first of the two calls it
+// makes when a motif has both a pending group and an unmerged open streak
+// (parse_anchored_shiftxor.cpp:713 vs :688,:697,:706,:717).
+void replay_anchored_calls(rb::SeedLists &lists, const std::vector<RibbitCall> &calls, int64_t length) {
+    rb::Cursor2 cur;
+    for (size_t i = 0; i < calls.size(); ++i) {
+        const RibbitCall &c = calls[i];
+        const rb::Cursor2 next = rb::anchored_add(lists, c.start, c.end, c.mlen, cur, RIBBIT_RANK_A);
+        const bool flush = c.pos == (int32_t)length;
+        const bool first_of_two = flush && i + 1 < calls.size() && calls[i + 1].pos == c.pos && calls[i + 1].mlen == c.mlen;
+        if (!flush || first_of_two) cur = next;
+    }
+}
+
+int advance_to_anchored(RibbitHandle *h) {
+    if (h->stage_done >= STAGE_ANCHORED) return RIBBIT_OK;
+    int rc = advance_to_subst(h);
+    if (rc) return rc;
+    if ((rc = build_anchored_calls(h))) return rc;
+    const rb::HostPlanes *hp = &h->host;
+    // from here on "plane m" means the composed plane XA_m (fasta_utils.cpp:159)
+    h->lists.range_count = [hp](int shift, int start, int end) {
+        return hp->has_xa(shift) ? hp->range_count_xa(shift, start, end) : hp->range_count(shift, start, end);
+    };
+    h->lists.anchored.clear();
+    replay_anchored_calls(h->lists, h->anchored_calls, h->length);
+    rb::dispatch_order(h->lists, h->dispatch);
+    h->stage_done = STAGE_ANCHORED;
+    return RIBBIT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -453,7 +527,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ascii.release(); h->d_hi.release(); h->d_lo.release(); h->d_brk.release();
-    h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release();
+    h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release();
     h->h_events.release(); h->h_counters.release(); h->h_query.release();
     for (int i = 0; i < 6; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -540,15 +614,53 @@ int ribbit_hip_seeds_substitutions(RibbitHandle *h, const RibbitSeed **perfect, 
     return RIBBIT_OK;
 }
 
+int ribbit_hip_anchored_calls(RibbitHandle *h, const RibbitCall **out, size_t *n) {
+    if (!h || !out || !n) return fail(RIBBIT_E_ARG, "null argument");
+    int rc = build_anchored_calls(h);
+    if (rc) return rc;
+    *out = h->anchored_calls.data();
+    *n = h->anchored_calls.size();
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_seeds_anchored(RibbitHandle *h, const RibbitSeed **perfect, size_t *n_perfect,
+                              const RibbitSeed **subst, size_t *n_subst,
+                              const RibbitSeed **anchored, size_t *n_anchored) {
+    if (!h || !perfect || !n_perfect || !subst || !n_subst || !anchored || !n_anchored) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    int rc = advance_to_anchored(h);
+    if (rc) return rc;
+    *perfect = h->lists.perfect.data();   *n_perfect = h->lists.perfect.size();
+    *subst = h->lists.subst.data();       *n_subst = h->lists.subst.size();
+    *anchored = h->lists.anchored.data(); *n_anchored = h->lists.anchored.size();
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_dispatch_seeds(RibbitHandle *h, const RibbitSeed **out, size_t *n) {
+    if (!h || !out || !n) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    int rc = advance_to_anchored(h);
+    if (rc) return rc;
+    *out = h->dispatch.data();
+    *n = h->dispatch.size();
+    return RIBBIT_OK;
+}
+
+int64_t ribbit_hip_guard_hits(const RibbitHandle *h) { return h ? h->lists.guard_hits : 0; }
+
 int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
                              const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
+                             const uint32_t *xa, size_t xa_stride,
                              const RibbitCall *perfect_calls, size_t n_perfect_calls,
                              const RibbitCall *subst_calls, size_t n_subst_calls,
+                             const RibbitCall *anchored_calls, size_t n_anchored_calls,
                              RibbitSeedLists *out) {
     if (!params || !out || (length > 0 && (!hi || !lo || !brk))) return fail(RIBBIT_E_ARG, "null argument");
-    if ((n_perfect_calls && !perfect_calls) || (n_subst_calls && !subst_calls)) return fail(RIBBIT_E_ARG, "null call list");
+    if ((n_perfect_calls && !perfect_calls) || (n_subst_calls && !subst_calls) || (n_anchored_calls && !anchored_calls))
+        return fail(RIBBIT_E_ARG, "null call list");
     const size_t need = (size_t)(length / 32 + 1) + (size_t)(params->max_motif + 2) / 32 + 2;
     if (nwords < need) return fail(RIBBIT_E_ARG, "planes too short: %zu words, need %zu (zero padding past the record)", nwords, need);
+    if (n_anchored_calls && (!xa || xa_stride < (size_t)(length / 32 + 1))) return fail(RIBBIT_E_ARG, "anchored calls need the composed planes (xa)");
     std::memset(out, 0, sizeof *out);
     rb::HostPlanes hp;
     hp.resize(length, nwords);
@@ -565,6 +677,22 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
     int from_index = 0;
     for (size_t i = 0; i < n_subst_calls; ++i)
         from_index = rb::subst_add(sl, subst_calls[i].start, subst_calls[i].end, subst_calls[i].mlen, from_index, RIBBIT_RANK_S);
+    if (xa) {
+        const size_t nm = (size_t)(params->max_motif - params->min_motif + 1);
+        hp.xa.assign(xa, xa + nm * xa_stride);
+        hp.xa_stride = (int64_t)xa_stride;
+        hp.xa_m_lo = params->min_motif;
+        hp.xa_m_hi = params->max_motif;
+        sl.range_count = [&hp](int shift, int start, int end) {
+            return hp.has_xa(shift) ? hp.range_count_xa(shift, start, end) : hp.range_count(shift, start, end);
+        };
+    }
+    std::vector<RibbitSeed> dispatch;
+    if (n_anchored_calls || xa) {
+        std::vector<RibbitCall> ac(anchored_calls, anchored_calls + n_anchored_calls);
+        replay_anchored_calls(sl, ac, length);
+        rb::dispatch_order(sl, dispatch);
+    }
     auto give = [](const std::vector<RibbitSeed> &v, RibbitSeed **p, size_t *n) {
         *n = v.size();
         *p = (RibbitSeed *)std::malloc(std::max<size_t>(v.size(), 1) * sizeof(RibbitSeed));
@@ -572,7 +700,7 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
         return *p != nullptr;
     };
     if (!give(sl.perfect, &out->perfect, &out->n_perfect) || !give(sl.subst, &out->subst, &out->n_subst) ||
-        !give(sl.anchored, &out->anchored, &out->n_anchored)) {
+        !give(sl.anchored, &out->anchored, &out->n_anchored) || !give(dispatch, &out->dispatch, &out->n_dispatch)) {
         ribbit_seed_lists_free(out);
         return fail(RIBBIT_E_NOMEM, "out of host memory");
     }
@@ -582,7 +710,7 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
 
 void ribbit_seed_lists_free(RibbitSeedLists *lists) {
     if (!lists) return;
-    std::free(lists->perfect); std::free(lists->subst); std::free(lists->anchored);
+    std::free(lists->perfect); std::free(lists->subst); std::free(lists->anchored); std::free(lists->dispatch);
     std::memset(lists, 0, sizeof *lists);
 }
 
@@ -610,6 +738,13 @@ static int query_plane(RibbitHandle *h, int32_t shift, int64_t start, int64_t en
 
 int ribbit_hip_plane_bits(RibbitHandle *h, int32_t shift, int64_t start, int64_t end, uint8_t *out) {
     if (!h || (!out && end > start)) return fail(RIBBIT_E_ARG, "null argument");
+    if (h->loaded && h->anchored_calls_valid && h->host.has_xa(shift)) {
+        // composed plane (fasta_utils.cpp:159): written by the anchored kernel, already on the host
+        if (start < 0 || end > h->length || start > end) return fail(RIBBIT_E_ARG, "range [%lld,%lld) outside the record", (long long)start, (long long)end);
+        const uint32_t *w = h->host.xa.data() + (int64_t)(shift - h->host.xa_m_lo) * h->host.xa_stride;
+        for (int64_t p = start; p < end; ++p) out[p - start] = (w[p >> 5] >> (p & 31)) & 1u;
+        return RIBBIT_OK;
+    }
     int rc = query_plane(h, shift, start, end, true, nullptr);
     if (rc) return rc;
     const int64_t w0 = start / 32;

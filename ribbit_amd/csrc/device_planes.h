@@ -19,8 +19,8 @@ namespace rb {
 constexpr int WORDS_PER_LANE = 8;
 constexpr int TILE_WORDS = 64 * WORDS_PER_LANE;   // 512 words = 16384 bases per wave tile
 constexpr int TILE_BASES = TILE_WORDS * 32;
-constexpr int LEAD_WORDS = 8;
-constexpr int TAIL_SLACK_WORDS = 8;
+constexpr int LEAD_WORDS = 16;          // >= WORDS_PER_LANE + 1 (the anchored kernel has a halo lane on each side)
+constexpr int TAIL_SLACK_WORDS = 544;    // >= TILE_WORDS + halo lane + shifted-operand words
 
 struct DevicePlanes {
     const uint32_t *hi;
@@ -30,6 +30,15 @@ struct DevicePlanes {
     int64_t ntiles;       // tiles covering words 0 .. L/32 (position L included)
     int64_t tail_words;   // words readable past ntiles*TILE_WORDS
 };
+
+// The anchored kernel gives up lanes 0 and 63 of every wave as halo lanes (run lengths that decide
+// whether a run is an anchor extend up to 2*shift bases beyond a lane), so its tiles are narrower.
+constexpr int ATILE_LANES = 62;
+constexpr int ATILE_WORDS = ATILE_LANES * WORDS_PER_LANE;   // 496 words = 15872 bases
+constexpr int ATILE_BASES = ATILE_WORDS * 32;
+// largest motif the anchored kernel handles exactly: 2*(max_motif+2) must fit in the 7 words a halo
+// lane can vouch for beyond its boundary word
+constexpr int ANCHORED_MAX_MOTIF = (7 * 32) / 2 - 2;        // 110
 
 // Event buffer sharding: EV_SHARDS regions, one counter each (own 128-byte line).
 constexpr int EV_SHARDS = 64;

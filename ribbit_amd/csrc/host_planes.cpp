@@ -43,6 +43,20 @@ int HostPlanes::range_count(int shift, int start, int end) const {
     return total;
 }
 
+int HostPlanes::range_count_xa(int mlen, int start, int end) const {
+    if (end <= start) return 0;
+    const uint32_t *w = xa.data() + (int64_t)(mlen - xa_m_lo) * xa_stride;
+    int total = 0;
+    const int64_t w0 = start >> 5, w1 = (end - 1) >> 5;
+    for (int64_t i = w0; i <= w1; ++i) {
+        uint32_t x = w[i];
+        if (i == w0) x &= 0xffffffffu << (start & 31);
+        if (i == w1) { const int hi_bits = ((end - 1) & 31) + 1; if (hi_bits < 32) x &= (1u << hi_bits) - 1u; }
+        total += __builtin_popcount(x);
+    }
+    return total;
+}
+
 int64_t HostPlanes::first_evaluated(int64_t from) const {
     int64_t q = std::max<int64_t>(from, 0);
     // last blocked interval starting at or before q

@@ -22,11 +22,21 @@ struct HostPlanes {
     // because an N lies in [q, q+7] (`valid_position < window_length`, parse_substitute_shiftxor.cpp:469)
     std::vector<std::pair<int64_t, int64_t>> blocked;
 
+    // composed planes XA_m of the anchored stage (fasta_utils.cpp:143-161), motif-major, xa_stride
+    // words per motif; written by the anchored kernel and copied back once
+    std::vector<uint32_t> xa;
+    int64_t xa_stride = 0;
+    int xa_m_lo = 0, xa_m_hi = -1;
+
     void resize(int64_t len, size_t nwords) {
         length = len;
         hi.assign(nwords, 0); lo.assign(nwords, 0); brk.assign(nwords, 0);
         blocked.clear();
+        xa.clear(); xa_stride = 0; xa_m_lo = 0; xa_m_hi = -1;
     }
+    bool has_xa(int mlen) const { return mlen >= xa_m_lo && mlen <= xa_m_hi; }
+    // popcount of XA_mlen over [start, end)
+    int range_count_xa(int mlen, int start, int end) const;
     void index_breaks();
 
     // X_shift word w: bit b = (code[p] == code[p+shift]), p = 32w+b  (fasta_utils.cpp:120-122)

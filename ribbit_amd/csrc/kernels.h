@@ -28,6 +28,13 @@ void launch_scan_perfect(const DevicePlanes &pl, const PerfectLaunch &pp, uint64
 void launch_scan_window(const DevicePlanes &pl, const PerfectLaunch &pp, int allowed_mismatches, uint64_t *events,
                         uint32_t *counters, hipStream_t stream);
 
+// generateAnchoredShiftXORs (parse_anchored_shiftxor.cpp:20-56) + the composition of
+// fasta_utils.cpp:143-161 + the window scan of processShiftXORsAnchored (:580-679), fused.
+// xa (may be null) receives the composed planes XA_m, motif-major, xa_stride words per motif.
+// Tiles are ATILE_WORDS wide.  Requires pp.m_hi <= ANCHORED_MAX_MOTIF.
+void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint32_t *xa, int64_t xa_stride,
+                          uint64_t *events, uint32_t *counters, hipStream_t stream);
+
 // Gathers the used part of every region into `dense` (same capacity) in shard order and writes
 // counters[EV_SUMMARY] = total events, counters[EV_SUMMARY+1] = 1 if any region overflowed.
 void launch_compact_events(const uint64_t *events, uint32_t ev_cap, uint32_t *counters, uint64_t *dense,

@@ -448,6 +448,266 @@ void launch_scan_window(const DevicePlanes &pl, const PerfectLaunch &pp, int all
         hipLaunchKernelGGL(scan_window_kernel<2>, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, events, counters);
 }
 
+// ------------------------------------------------------------------------- anchored scan
+// Fused generateAnchoredShiftXORs (parse_anchored_shiftxor.cpp:20-56), plane composition
+// (fasta_utils.cpp:143-161) and window scan of processShiftXORsAnchored (:580-679, threshold 6).
+//
+// anchor_s keeps the bits of every maximal run of X_s ones that (a) is closed by a zero at a
+// position p <= L-1-s (the reference only walks p = 0..L-1-s, so a run still open there is dropped)
+// and (b) has 3 <= length < 2s.  N is ignored.  To make (a) a length test, X_s is forced to 1 from
+// p = L-s on: such a run becomes unbounded and fails "< 2s".  Run lengths are classified per lane:
+//   * a lane owns 8 consecutive words (256 bases); per word it knows its leading / trailing ones;
+//   * a sequential carry over the 8 words gives, for every word, the length of the run entering
+//     from the left (CL) and from the right (CR) -- seeded with the neighbour lanes' trailing /
+//     leading ones, or SATURATED when the neighbour lane is all ones (a full lane is >= 256 >= 2s);
+//   * runs interior to a word are handled bit-parallel (>= 3 by AND of shifts; >= 2s, only
+//     possible when 2s <= 30, by AND-/OR-doubling).
+// Lanes 0 and 63 are halo lanes (their own neighbours are unknown): they compute but emit nothing.
+// The composed plane XA_m = X_m | anchor_{m-2} | anchor_{m-1} | anchor_{m+1} | anchor_{m+2}
+// needs five consecutive shifts, so every wave walks s = m_lo-2 .. m_hi+2 of its motif group with a
+// register ring of the last five anchor words and the last three mismatch words.
+constexpr int RUN_SAT = 1 << 20;
+
+__global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, PerfectLaunch pp, int motifs_per_block,
+                                                            uint32_t *__restrict__ xa, int64_t xa_stride,
+                                                            uint64_t *__restrict__ events,
+                                                            uint32_t *__restrict__ counters) {
+    __shared__ uint32_t s_hi[64 * K + LDS_EXTRA];
+    __shared__ uint32_t s_lo[64 * K + LDS_EXTRA];
+    __shared__ uint32_t s_brk[64 * K + 8];
+    __shared__ uint64_t s_stage[4][EV_STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t tile_base = (int64_t)blockIdx.x * ATILE_WORDS;   // first OWN word (lane 1, k = 0)
+    const int64_t first = tile_base - K - 1;                       // word held at LDS index 0
+
+    const int bm_lo = pp.m_lo + (int)blockIdx.y * motifs_per_block;
+    const int bm_hi = min(pp.m_hi, bm_lo + motifs_per_block - 1);
+    const int q_hi = (bm_hi + 2) >> 5;
+    const int n_ext = 64 * K + 4 + q_hi;
+    for (int i = threadIdx.x; i < n_ext; i += 256) {
+        s_hi[i] = pl.hi[first + i];
+        s_lo[i] = pl.lo[first + i];
+    }
+    for (int i = threadIdx.x; i < 64 * K + 2; i += 256) s_brk[i] = pl.brk[first + i];
+    __syncthreads();
+
+    const int nmb = bm_hi - bm_lo + 1;
+    const int per = (nmb + 3) >> 2;
+    const int wm_lo = bm_lo + wave * per;
+    const int wm_hi = min(bm_hi, wm_lo + per - 1);
+    if (wm_lo > wm_hi) return;
+
+    const int lb = lane * K;
+    const bool own_lane = lane >= 1 && lane <= ATILE_LANES;
+    uint32_t H[K + 2], Lo[K + 2];
+    uint32_t EVAL[K + 1];
+    {
+        uint32_t B[K + 2];
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) { H[j] = s_hi[lb + j]; Lo[j] = s_lo[lb + j]; B[j] = s_brk[lb + j]; }
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) B[j] |= funnel(B[j + 1], B[j], 1);
+        B[K + 1] |= B[K + 1] >> 1;
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) B[j] |= funnel(B[j + 1], B[j], 2);
+        B[K + 1] |= B[K + 1] >> 2;
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) EVAL[j] = ~(B[j] | funnel(B[j + 1], B[j], 4));
+    }
+
+    const int64_t w_own0 = tile_base + (int64_t)(lane - 1) * K;     // global index of this lane's word k = 0
+    const uint32_t word0 = (uint32_t)w_own0;
+    const int64_t length = pl.length;
+    // masks are only needed where the lane touches p < 0 or p >= L - (largest shift)
+    const int64_t lane_lo = (w_own0 - 1) * 32, lane_hi = (w_own0 + K + 1) * 32;
+    const bool edge_lane = lane_lo < 0 || lane_hi > length - (int64_t)(wm_hi + 2);
+    const bool edge_wave = __ballot(edge_lane) != 0ull;
+
+    uint32_t Hq[K + 3], Lq[K + 3];
+    int cur_q = -1;
+
+    uint32_t AN[5][K + 2];   // anchor words of shifts s-4 .. s   (index j: word k = j-1)
+    uint32_t MM[3][K + 2];   // mismatch words of shifts s-2 .. s
+#pragma unroll
+    for (int a = 0; a < 5; a++)
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) AN[a][j] = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) MM[a][j] = 0;
+
+    EventSink sink;
+    sink.events = events;
+    sink.counters = counters;
+    sink.region_cap = pp.ev_cap / EV_SHARDS;
+    sink.shard = (blockIdx.x * 4u + (uint32_t)wave + blockIdx.y) % EV_SHARDS;
+    volatile uint64_t *stage = s_stage[wave];
+    int staged = 0;
+
+    const int s_first = max(1, wm_lo - 2);
+    for (int s = s_first; s <= wm_hi + 2; ++s) {
+        const int q = s >> 5;
+        const uint32_t r = (uint32_t)s & 31u;
+        if (q != cur_q) {
+            cur_q = q;
+#pragma unroll
+            for (int j = 0; j < K + 3; j++) { Hq[j] = s_hi[lb + j + q]; Lq[j] = s_lo[lb + j + q]; }
+        }
+        // rotate the rings: slot 4 / slot 2 receive shift s
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) {
+            AN[0][j] = AN[1][j]; AN[1][j] = AN[2][j]; AN[2][j] = AN[3][j]; AN[3][j] = AN[4][j];
+            MM[0][j] = MM[1][j]; MM[1][j] = MM[2][j];
+        }
+        uint32_t X[K];   // X'_s on the own words k = 0..K-1
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) {
+            const uint32_t hs = funnel(Hq[j + 1], Hq[j], r);
+            const uint32_t ls = funnel(Lq[j + 1], Lq[j], r);
+            MM[2][j] = (H[j] ^ hs) | (Lo[j] ^ ls);
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) X[k] = ~MM[2][k + 1];
+        if (edge_wave) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int64_t bp = (w_own0 + k) * 32;
+                const int64_t f = (length - s) - bp;          // first forced bit of this word
+                const uint32_t force = f <= 0 ? 0xffffffffu : (f >= 32 ? 0u : (0xffffffffu << (uint32_t)f));
+                X[k] = (bp < 0) ? 0u : (X[k] | force);
+            }
+        }
+        // ---- anchors of shift s on the own words
+        const int two_s = 2 * s;
+        int lead1[K], trail1[K];
+        int span_lead = 0, span_trail = 0;
+        bool alive = true;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint32_t nx = ~X[k];
+            lead1[k] = nx ? __builtin_ctz(nx) : 32;
+            trail1[k] = nx ? __builtin_clz(nx) : 32;
+            span_lead += alive ? lead1[k] : 0;
+            alive = alive && (nx == 0u);
+        }
+        const bool span_full = alive;
+        alive = true;
+#pragma unroll
+        for (int k = K - 1; k >= 0; k--) {
+            span_trail += alive ? trail1[k] : 0;
+            alive = alive && (X[k] == 0xffffffffu);
+        }
+        int left_in = __shfl_up(span_full ? RUN_SAT : span_trail, 1);
+        int right_in = __shfl_down(span_full ? RUN_SAT : span_lead, 1);
+        if (lane == 0) left_in = 0;
+        if (lane == 63) right_in = 0;
+        int CL[K], CR[K];
+        {
+            int c = left_in;
+#pragma unroll
+            for (int k = 0; k < K; k++) { CL[k] = c; c = (X[k] == 0xffffffffu) ? min(c + 32, RUN_SAT) : trail1[k]; }
+            c = right_in;
+#pragma unroll
+            for (int k = K - 1; k >= 0; k--) { CR[k] = c; c = (X[k] == 0xffffffffu) ? min(c + 32, RUN_SAT) : lead1[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint32_t x = X[k];
+            const bool isfull = x == 0xffffffffu;
+            const uint32_t mask_low = isfull ? 0xffffffffu : ((1u << lead1[k]) - 1u);
+            const uint32_t mask_high = (isfull || trail1[k] == 0) ? 0u : (0xffffffffu << (32 - trail1[k]));
+            const int low_len = CL[k] + lead1[k] + (isfull ? CR[k] : 0);
+            const int high_len = trail1[k] + CR[k];
+            const uint32_t inter = x & ~mask_low & ~mask_high;
+            const uint32_t r3 = inter & (inter >> 1) & (inter >> 2);
+            uint32_t keep = r3 | (r3 << 1) | (r3 << 2);
+            if (two_s <= 30) {   // wave-uniform: interior runs can reach 2s only for small shifts
+                uint32_t rr = inter;
+                for (int span = 1; span < two_s;) { const int sh = min(span, two_s - span); rr &= rr >> sh; span += sh; }
+                for (int span = 1; span < two_s;) { const int sh = min(span, two_s - span); rr |= rr << sh; span += sh; }
+                keep &= ~rr;
+            }
+            if (lead1[k] > 0 && low_len >= 3 && low_len < two_s) keep |= mask_low;
+            if (high_len >= 3 && high_len < two_s) keep |= mask_high;
+            AN[4][k + 1] = keep;
+        }
+        AN[4][0] = __shfl_up(AN[4][K], 1);          // left neighbour's last own word
+        AN[4][K + 1] = __shfl_down(AN[4][1], 1);    // right neighbour's first own word
+
+        const int m = s - 2;
+        if (m < wm_lo) continue;
+        // ---- composed mismatch of motif m:  ~XA_m = mismatch_m & ~(anchor_{m-2,m-1,m+1,m+2})
+        uint32_t A1[K + 2], B1[K + 2], C1[K + 2];
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) A1[j] = MM[0][j] & ~(AN[0][j] | AN[1][j] | AN[3][j] | AN[4][j]);
+        if (xa != nullptr && own_lane) {
+            uint32_t *dst = xa + (int64_t)(m - pp.m_lo) * xa_stride + w_own0;
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (w_own0 + k < xa_stride) dst[k] = ~A1[k + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) {          // span 2
+            const uint32_t sa = (j <= K) ? funnel(A1[j + 1 <= K + 1 ? j + 1 : j], A1[j], 1) : (A1[j] >> 1);
+            B1[j] = A1[j] & sa;
+            A1[j] = A1[j] | sa;
+        }
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) {          // span 4
+            const uint32_t sa = (j <= K) ? funnel(A1[j + 1 <= K + 1 ? j + 1 : j], A1[j], 2) : (A1[j] >> 2);
+            const uint32_t sb = (j <= K) ? funnel(B1[j + 1 <= K + 1 ? j + 1 : j], B1[j], 2) : (B1[j] >> 2);
+            C1[j] = (B1[j] & sa) | (A1[j] & sb);
+            B1[j] = B1[j] | sb | (A1[j] & sa);
+            A1[j] = A1[j] | sa;
+        }
+        uint32_t PASS[K + 1];
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) {          // span 8: at least three mismatches fail the window
+            const uint32_t sa = funnel(A1[j + 1], A1[j], 4);
+            const uint32_t sb = funnel(B1[j + 1], B1[j], 4);
+            const uint32_t sc = funnel(C1[j + 1], C1[j], 4);
+            const uint32_t bad = C1[j] | sc | (B1[j] & sa) | (A1[j] & sb);
+            PASS[j] = EVAL[j] & ~bad;
+        }
+        uint32_t ST[K], EN[K];
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint32_t prev = funnel(PASS[k + 1], PASS[k], 31);
+            ST[k] = own_lane ? (PASS[k + 1] & ~prev) : 0u;
+            EN[k] = own_lane ? (~PASS[k + 1] & prev) : 0u;
+            any |= ST[k] | EN[k];
+        }
+        if (__ballot(any != 0) != 0ull) {
+            stage_events(ST, EN, word0, (uint32_t)m, sink, stage, staged, lane, [&](int k, uint32_t b, uint32_t pos) {
+                if ((EVAL[k + 1] >> b) & 1u) return (uint32_t)EV_END_ZERO;
+                return ((int64_t)pos + 7 >= length) ? (uint32_t)EV_END_EOS : (uint32_t)EV_END_N;
+            });
+        }
+    }
+    sink_flush(sink, stage, staged, lane);
+}
+
+void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint32_t *xa, int64_t xa_stride,
+                          uint64_t *events, uint32_t *counters, hipStream_t stream) {
+    const int nm = pp.m_hi - pp.m_lo + 1;
+    const int64_t nwords = pl.length / 32 + 1;
+    const int64_t ntiles = (nwords + ATILE_WORDS - 1) / ATILE_WORDS;
+    if (nm <= 0 || ntiles <= 0) return;
+    // each wave recomputes 4 extra shifts around its motif group, so keep the groups large
+    int64_t want_y = (1024 + ntiles - 1) / ntiles;
+    int max_y = (nm + 31) / 32;
+    int gy = (int)(want_y < 1 ? 1 : (want_y > max_y ? max_y : want_y));
+    int motifs_per_block = (nm + gy - 1) / gy;
+    gy = (nm + motifs_per_block - 1) / motifs_per_block;
+    dim3 grid((unsigned)ntiles, (unsigned)gy);
+    hipLaunchKernelGGL(scan_anchored_kernel, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, xa, xa_stride, events,
+                       counters);
+}
+
 // ------------------------------------------------------------------------ event compaction
 __global__ __launch_bounds__(256) void compact_events_kernel(const uint64_t *__restrict__ events, uint32_t region_cap,
                                                              uint32_t *__restrict__ counters,

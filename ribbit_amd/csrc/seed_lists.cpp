@@ -248,4 +248,292 @@ int subst_add(SeedLists &sl, int seed_start, int seed_end, int mlen, int from_in
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Anchored stage.
+namespace {
+
+enum Src : uint8_t { FROM_P, FROM_S, FROM_A };
+struct Cand3 { Src src; int idx; };
+
+inline const RibbitSeed &seed_of(const SeedLists &sl, Src src, int idx) {
+    return src == FROM_P ? sl.perfect[idx] : src == FROM_S ? sl.subst[idx] : sl.anchored[idx];
+}
+
+// One backward walk over a single list as the reference writes it three times in mergeAllLists:
+// take entries while their end reaches seed_start; stop (and mark the list done) at the first end
+// below seed_start or at the front of the list.
+template <typename Push>
+void walk_back(const std::vector<RibbitSeed> &list, long &i, int seed_start, Push push) {
+    for (;;) {
+        const int end = list[i].end;
+        if (end >= seed_start) { push(i); --i; }
+        if (i < 0 || end < seed_start) return;
+    }
+}
+
+// mergeAllLists (merge_types.cpp:11-189).  Phase 1 interleaves perfect and substitution seeds by
+// descending end (starting at the two cursors); phase 2 interleaves that candidate list -- walked
+// from its LAST element, i.e. by ascending end -- with the anchored list walked from its end.
+// Divergence D1: an empty substitution list is treated as exhausted (the reference reads it: UB).
+void merge_all_lists(SeedLists &sl, Cursor2 from, int seed_start, std::vector<Cand3> &out) {
+    const std::vector<RibbitSeed> &P = sl.perfect, &S = sl.subst, &A = sl.anchored;
+    std::vector<Cand3> ps;
+    bool p_done = P.empty(), s_done = false;
+    if (S.empty()) { s_done = true; ++sl.guard_hits; }
+    long pi = from.perfect, si = from.subst;
+    auto push_p = [&](long i) { if (P[i].type != RIBBIT_RANK_N) ps.push_back({FROM_P, (int)i}); };
+    auto push_s = [&](long i) { if (S[i].type != RIBBIT_RANK_N) ps.push_back({FROM_S, (int)i}); };
+    while (!(p_done && s_done)) {
+        if (s_done) { walk_back(P, pi, seed_start, push_p); p_done = true; }            // :30-45
+        else if (p_done) { walk_back(S, si, seed_start, push_s); s_done = true; }        // :47-62
+        else {                                                                           // :64-93
+            const int p_end = P[pi].end, s_end = S[si].end;
+            if (s_end > p_end) { push_s(si); --si; } else { push_p(pi); --pi; }
+            if (pi < 0 || p_end < seed_start) p_done = true;
+            if (si < 0 || s_end < seed_start) s_done = true;
+        }
+    }
+
+    out.clear();
+    if (A.empty()) { out = ps; return; }                                                 // :103-106
+    long ai = (long)A.size() - 1;
+    auto push_a = [&](long i) { if (A[i].type != RIBBIT_RANK_N) out.push_back({FROM_A, (int)i}); };
+    if (ps.empty()) { walk_back(A, ai, seed_start, push_a); return; }                    // :107-122
+    long ci = (long)ps.size() - 1;
+    bool c_done = false, a_done = false;
+    while (!(c_done && a_done)) {                                                        // :124-187
+        if (a_done) {
+            for (;;) {                                                                   // :127-140
+                const Cand3 c = ps[ci];
+                const int end = seed_of(sl, c.src, c.idx).end;
+                if (end >= seed_start) { out.push_back(c); --ci; }
+                if (ci < 0 || end < seed_start) break;
+            }
+            c_done = true;
+        } else if (c_done) {
+            walk_back(A, ai, seed_start, push_a);                                        // :143-157
+            a_done = true;
+        } else {                                                                         // :160-185
+            const Cand3 c = ps[ci];
+            const int c_end = seed_of(sl, c.src, c.idx).end, a_end = A[ai].end;
+            if (a_end > c_end) { out.push_back({FROM_A, (int)ai}); --ai; }               // no RANK_N test here (:168-171)
+            else { out.push_back(c); --ci; }
+            if (ci < 0 || c_end < seed_start) c_done = true;
+            if (ai < 0 || a_end < seed_start) a_done = true;
+        }
+    }
+}
+
+}  // namespace
+
+Cursor2 anchored_add(SeedLists &sl, int seed_start, int seed_end, int mlen, const Cursor2 from, int seed_type) {
+    std::vector<RibbitSeed> &P = sl.perfect, &S = sl.subst, &A = sl.anchored;
+    constexpr int RA = RIBBIT_RANK_A, RC = RIBBIT_RANK_C, RP = RIBBIT_RANK_P, RS = RIBBIT_RANK_S, RQ = RIBBIT_RANK_Q;
+    std::vector<Cand3> cands;
+    struct Child { int idx, mlen, type; };
+    std::vector<Child> factor_children, nonfactor_children;
+
+    // state the reference keeps in function-scope variables across loop iterations; the coverage code
+    // after the loop reads whatever was left in them (Q8)
+    int o_start = 0, o_end = 0, o_rend = 0, o_mlen = 0, o_type = 0;
+
+    for (;;) {
+        // :133-151 both cursors restart from the caller's values on every (tail-)recursion
+        Cursor2 cur = from;
+        while ((size_t)cur.perfect < P.size() && P[cur.perfect].start <= seed_end && (size_t)cur.perfect != P.size() - 1) ++cur.perfect;
+        while ((size_t)cur.subst < S.size() && S[cur.subst].start <= seed_end && (size_t)cur.subst != S.size() - 1) ++cur.subst;
+
+        if (seed_end - seed_start < anchored_seedlen_cutoff(mlen)) return cur;              // :153
+
+        merge_all_lists(sl, cur, seed_start, cands);                                         // :156
+        factor_children.clear();
+        nonfactor_children.clear();
+
+        const int seed_rend = seed_end + mlen, seed_len = seed_end - seed_start, seed_rlen = seed_len + mlen;
+        bool restart = false;
+        auto again = [&](int s, int e, int m, int t) { seed_start = s; seed_end = e; mlen = m; seed_type = t; restart = true; };
+        auto retire_by_type = [&](int type, int idx) {                                       // :270-271 and twins
+            if (type == RP) P[idx].type = RIBBIT_RANK_N;
+            else if (type == RS || type == RQ) S[idx].type = RIBBIT_RANK_N;
+        };
+
+        for (const Cand3 &c : cands) {
+            const RibbitSeed &old = seed_of(sl, c.src, c.idx);
+            o_start = old.start; o_mlen = old.mlen; o_end = old.end; o_rend = o_end + o_mlen; o_type = old.type;
+
+            if (o_end < seed_start) break;                                                   // :203
+            if (o_type == RIBBIT_RANK_N) continue;                                           // :205
+            if (seed_end < o_start) continue;                                                // :208
+            const int o_len = o_end - o_start, o_rlen = o_rend - o_start;
+            const bool same_rank = (seed_type == RA && o_type == RA) || (seed_type == RC && o_type == RC);
+
+            if (seed_start == o_start && seed_end == o_end) {                                // :215 identical
+                if (seed_type == RA && o_type > RA) return cur;
+                if (seed_type == RC && o_type == RA) A[c.idx].type = RIBBIT_RANK_N;
+            } else if (o_start <= seed_start && seed_end <= o_end) {                         // :231 new inside old
+                if (o_type > seed_type) return cur;
+                if (seed_type == RC && o_type == RA) continue;
+                if (same_rank) {
+                    if (mlen % o_mlen == 0 && mlen != 4) return cur;                         // :241
+                    if (o_mlen % mlen == 0 && o_mlen != 4) {                                 // :246
+                        if (seed_rlen >= o_mlen - 1 || seed_rlen >= o_len) {
+                            A[c.idx].type = RIBBIT_RANK_N;
+                            again(o_start, o_end, mlen, seed_type); break;
+                        }
+                        continue;
+                    }
+                    if (!keep_nested(sl, seed_start, seed_end, mlen, o_mlen)) return cur;    // :257
+                    continue;
+                }
+            } else if (seed_start <= o_start && o_end <= seed_end) {                         // :265 old inside new
+                if (o_type > seed_type) {
+                    if (mlen % o_mlen == 0) {                                                // :268
+                        if (o_rlen >= mlen - 2 || o_rlen >= seed_len - 2) {
+                            retire_by_type(o_type, c.idx);
+                            again(seed_start, seed_end, o_mlen, RC); break;
+                        }
+                        factor_children.push_back({c.idx, o_mlen, o_type});
+                    } else if (o_mlen % mlen == 0 || o_mlen > mlen) {                        // :285 / :301 (same action)
+                        if (o_mlen >= 4 * mlen || o_len >= 4 * mlen) {
+                            retire_by_type(o_type, c.idx);
+                            again(seed_start, seed_end, mlen, RC); break;
+                        }
+                    } else {                                                                 // :312
+                        nonfactor_children.push_back({c.idx, o_mlen, o_type});
+                    }
+                } else if (seed_type == RC && o_type == RA) {                                // :319
+                    A[c.idx].type = RIBBIT_RANK_N;
+                } else if (same_rank) {                                                      // :323
+                    if (o_mlen == mlen || !keep_nested(sl, o_start, o_end, o_mlen, mlen)) {
+                        A[c.idx].type = RIBBIT_RANK_N;
+                    } else if (mlen % o_mlen == 0) {                                         // :332
+                        if (o_rlen >= mlen - 2 || o_rlen >= seed_len - 2) {
+                            A[c.idx].type = RIBBIT_RANK_N;
+                            again(seed_start, seed_end, o_mlen, seed_type); break;
+                        }
+                    }
+                }
+            } else {                                                                         // :351 partial overlap
+                int overlap, ms, me;
+                if (o_start < seed_start) {
+                    const int reach = (o_mlen <= mlen) ? o_rend : o_end;
+                    overlap = (seed_end <= reach ? seed_end : reach) - seed_start;
+                    ms = o_start; me = seed_end;
+                } else {
+                    const int reach = (mlen <= o_mlen) ? seed_rend : seed_end;
+                    overlap = (o_end <= reach ? o_end : reach) - o_start;
+                    ms = seed_start; me = o_end;
+                }
+                if (seed_type == RA && o_type > RC) {                                        // :376
+                    if (mlen == o_mlen && overlap >= 4 * mlen) {
+                        retire_by_type(o_type, c.idx);
+                        again(ms, me, mlen, RC); break;
+                    }
+                    if (!(mlen % o_mlen == 0 || o_mlen % mlen == 0) && (overlap >= mlen - 1 || overlap >= seed_len - 1)) return cur;
+                } else if ((seed_type == RA || seed_type == RC) && (o_type == RA || o_type == RC)) {   // :398
+                    if (mlen == o_mlen) {
+                        // the `seed_type == ... ;` statements at :402,:410,:420,:428 compare and discard: no effect
+                        bool merge;
+                        if (o_len >= seed_len)
+                            merge = (seed_len >= 3 * mlen) ? (overlap >= 3 * mlen - 1 || overlap >= seed_len - 1)
+                                                           : (overlap >= mlen - 1 || overlap >= seed_len - 1);
+                        else
+                            merge = (o_len >= 3 * o_mlen && (overlap >= 3 * o_mlen - 1 || overlap >= o_len - 1)) ||
+                                    (!(o_len >= 3 * o_mlen && (overlap >= 3 * o_mlen - 1 || overlap >= o_len - 1)) &&
+                                     seed_len < 3 * o_mlen && (overlap >= o_mlen - 1 || overlap >= o_len - 1));
+                        if (merge) {
+                            A[c.idx].type = RIBBIT_RANK_N;
+                            again(ms, me, o_mlen, seed_type); break;
+                        }
+                    }
+                }
+            }
+        }
+        if (restart) continue;
+
+        // :441-468 coverage of the new seed by non-factor perfect/substitution children.  Q8: the lists
+        // are indexed with the LOOP COUNTER j, and children typed Q leave the previous values in place.
+        // Divergence D2: an out-of-range j keeps the stale values (the reference reads out of bounds).
+        if (!nonfactor_children.empty()) {
+            int coverage = 0;
+            uint32_t prev_start = 0xffffffffu;
+            for (size_t j = 0; j < nonfactor_children.size(); ++j) {
+                const int t = nonfactor_children[j].type;
+                const std::vector<RibbitSeed> *src = t == RP ? &P : t == RS ? &S : nullptr;
+                if (src) {
+                    if (j < src->size()) { o_start = (*src)[j].start; o_mlen = (*src)[j].mlen; o_end = (*src)[j].end; o_rend = o_end + o_mlen; }
+                    else ++sl.guard_hits;
+                }
+                if ((uint32_t)o_rend >= prev_start) coverage = (int)((uint32_t)coverage + (prev_start - (uint32_t)o_start));
+                else if (o_rend < seed_end) coverage += o_rend - o_start;
+                else coverage += seed_end - o_start;
+                prev_start = (uint32_t)o_start;
+            }
+            if (coverage > 0.5 * seed_len) return cur;                                       // :467
+        }
+
+        // :471-526 coverage by factor children, per child motif size (the reference's two unordered_maps;
+        // operator[] on a missing key inserts 0)
+        if (!factor_children.empty()) {
+            std::vector<int> prev_of(sl.max_motif + 8, 0), cov_of(sl.max_motif + 8, 0);
+            std::vector<char> has_cov(sl.max_motif + 8, 0);
+            for (const Child &ch : factor_children) { prev_of[ch.mlen] = -1; cov_of[ch.mlen] = 0; has_cov[ch.mlen] = 1; }
+            for (size_t j = 0; j < factor_children.size(); ++j) {
+                const int t = factor_children[j].type;
+                const std::vector<RibbitSeed> *src = t == RP ? &P : t == RS ? &S : nullptr;
+                if (src) {
+                    if (j < src->size()) { o_start = (*src)[j].start; o_mlen = (*src)[j].mlen; o_end = (*src)[j].end; o_rend = o_end + o_mlen; }
+                    else ++sl.guard_hits;
+                }
+                const uint32_t prev_start = (uint32_t)prev_of[o_mlen];
+                has_cov[o_mlen] = 1;
+                if ((uint32_t)o_rend >= prev_start) cov_of[o_mlen] = (int)((uint32_t)cov_of[o_mlen] + (prev_start - (uint32_t)o_start));
+                else if (o_rend < seed_end) cov_of[o_mlen] += o_rend - o_start;
+                else cov_of[o_mlen] += seed_end - o_start;
+                prev_of[o_mlen] = o_start;
+            }
+            for (int f = 0; f < (int)cov_of.size(); ++f) {                                   // ascending factor sizes (:504-507)
+                if (!has_cov[f] || !(cov_of[f] >= 0.8 * seed_len)) continue;
+                mlen = f; seed_type = RC;                                                    // :509
+                for (size_t j = 0; j < factor_children.size(); ++j) {                        // :511-522, stale start/end written back
+                    const int t = factor_children[j].type;
+                    std::vector<RibbitSeed> *dst = t == RP ? &P : t == RS ? &S : nullptr;
+                    if (!dst) continue;
+                    if (j >= dst->size()) { ++sl.guard_hits; continue; }
+                    o_mlen = (*dst)[j].mlen;
+                    if (o_mlen == f) (*dst)[j] = RibbitSeed{o_start, o_end, o_mlen, RIBBIT_RANK_N};
+                }
+                break;
+            }
+        }
+
+        const int limit = (int)sl.length - mlen;                                             // :529-531
+        if (seed_end > limit) seed_end = limit;
+        A.push_back(RibbitSeed{seed_start, seed_end, mlen, seed_type});
+        return cur;
+    }
+}
+
+void dispatch_order(const SeedLists &sl, std::vector<RibbitSeed> &out) {
+    // fasta_utils.cpp:187-224.  `smallest` is a uint64_t compared with int starts; the picked list
+    // persists across iterations when no head is smaller (cannot happen for starts >= 0).
+    const std::vector<RibbitSeed> &P = sl.perfect, &S = sl.subst, &A = sl.anchored;
+    size_t ip = 0, is = 0, ia = 0;
+    int pick = -1;
+    out.clear();
+    while (ip < P.size() || is < S.size() || ia < A.size()) {
+        uint64_t smallest = ~(uint64_t)0;
+        if (ip < P.size() && smallest > (uint64_t)(int64_t)P[ip].start) { smallest = (uint64_t)(int64_t)P[ip].start; pick = 0; }
+        if (is < S.size() && smallest > (uint64_t)(int64_t)S[is].start) { smallest = (uint64_t)(int64_t)S[is].start; pick = 1; }
+        if (ia < A.size() && smallest > (uint64_t)(int64_t)A[ia].start) { smallest = (uint64_t)(int64_t)A[ia].start; pick = 2; }
+        RibbitSeed seed;
+        if (pick == 0 && ip < P.size()) seed = P[ip++];
+        else if (pick == 1 && is < S.size()) seed = S[is++];
+        else if (pick == 2 && ia < A.size()) seed = A[ia++];
+        else break;
+        if (seed.type == RIBBIT_RANK_N) continue;                                            // :213
+        if (seed.end - seed.start >= 0.9 * seed.mlen) out.push_back(seed);                   // :224
+    }
+}
+
 }  // namespace rb

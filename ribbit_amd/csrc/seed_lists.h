@@ -34,4 +34,15 @@ inline int anchored_seedlen_cutoff(int mlen) { return mlen >= 10 ? (int)(0.9 * m
 // addSeedToSeedPositionsSubstitutions, parse_substitute_shiftxor.cpp:18-388; returns the new cursor
 int subst_add(SeedLists &sl, int seed_start, int seed_end, int mlen, int from_index, int seed_type);
 
+
+// cursors into the perfect and substitution lists carried between addSeedToSeedPositionsAnchored calls
+struct Cursor2 { int perfect = 0, subst = 0; };
+
+// addSeedToSeedPositionsAnchored (parse_anchored_shiftxor.cpp:113-534) incl. mergeAllLists
+// (merge_types.cpp:11-189); range_count must answer on the COMPOSED planes XA_m.
+Cursor2 anchored_add(SeedLists &sl, int seed_start, int seed_end, int mlen, Cursor2 from, int seed_type);
+
+// 3-way merge by start + filters of fasta_utils.cpp:187-224: the seeds that reach refinement, in order
+void dispatch_order(const SeedLists &sl, std::vector<RibbitSeed> &out);
+
 }  // namespace rb

@@ -10,7 +10,7 @@ import pytest
 
 import ribbit_amd
 from cases import edge_cases, simulated_cases
-from oracle_lib import LIST_PERFECT, LIST_SUBST, Oracle
+from oracle_lib import LIST_ANCHORED, LIST_PERFECT, LIST_SUBST, Oracle
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL = edge_cases() + simulated_cases()
@@ -33,22 +33,34 @@ def test_replay_of_oracle_calls_reproduces_oracle_lists(name, seq, m_lo, m_hi):
         o.run_perfect()
         perfect_after_p = o.seeds(LIST_PERFECT)
         pcalls = o.calls(LIST_PERFECT)
-        p_only, _, _, _ = ribbit_amd.host_replay_calls(m_lo, m_hi, seq, pcalls)
-        assert np.array_equal(p_only.view("<i4"), perfect_after_p.view("<i4"))
+        r = ribbit_amd.host_replay_calls(m_lo, m_hi, seq, pcalls)
+        assert np.array_equal(r["perfect"].view("<i4"), perfect_after_p.view("<i4"))
         o.run_subst()
-        perfect, subst, _, guards = ribbit_amd.host_replay_calls(m_lo, m_hi, seq, pcalls, o.calls(LIST_SUBST))
-        assert np.array_equal(perfect.view("<i4"), o.seeds(LIST_PERFECT).view("<i4"))
-        assert np.array_equal(subst.view("<i4"), o.seeds(LIST_SUBST).view("<i4"))
-        assert guards == 0
+        scalls = o.calls(LIST_SUBST)
+        r = ribbit_amd.host_replay_calls(m_lo, m_hi, seq, pcalls, scalls)
+        assert np.array_equal(r["perfect"].view("<i4"), o.seeds(LIST_PERFECT).view("<i4"))
+        assert np.array_equal(r["subst"].view("<i4"), o.seeds(LIST_SUBST).view("<i4"))
+        assert r["guard_hits"] == 0
+        # anchored stage: the oracle's composed planes and call log through the product's merges
+        o.run_anchor_planes()
+        xa, stride = ribbit_amd.pack_bit_planes([o.plane(m) for m in range(m_lo, m_hi + 1)], len(seq))
+        o.run_anchored()
+        o.run_dispatch()
+        r = ribbit_amd.host_replay_calls(m_lo, m_hi, seq, pcalls, scalls, o.calls(LIST_ANCHORED), xa, stride)
+        assert np.array_equal(r["perfect"].view("<i4"), o.seeds(LIST_PERFECT).view("<i4"))
+        assert np.array_equal(r["subst"].view("<i4"), o.seeds(LIST_SUBST).view("<i4"))
+        assert np.array_equal(r["anchored"].view("<i4"), o.seeds(LIST_ANCHORED).view("<i4"))
+        assert np.array_equal(r["dispatch"].view("<i4"), o.dispatch().view("<i4"))
+        assert r["guard_hits"] == o.guard_hits()
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=lambda p: os.path.basename(p)[:-4])
 def test_replay_matches_fixture(path):
     g = np.load(path)
     seq = g["seq"].tobytes()
-    perfect, subst, _, _ = ribbit_amd.host_replay_calls(int(g["m_lo"]), int(g["m_hi"]), seq, g["perfect_calls"], g["subst_calls"])
-    assert np.array_equal(perfect.view("<i4"), g["perfect_after_s"].view("<i4"))
-    assert np.array_equal(subst.view("<i4"), g["subst_after_s"].view("<i4"))
+    r = ribbit_amd.host_replay_calls(int(g["m_lo"]), int(g["m_hi"]), seq, g["perfect_calls"], g["subst_calls"])
+    assert np.array_equal(r["perfect"].view("<i4"), g["perfect_after_s"].view("<i4"))
+    assert np.array_equal(r["subst"].view("<i4"), g["subst_after_s"].view("<i4"))
 
 
 def test_replay_rejects_short_planes(hip_lib):
@@ -57,5 +69,6 @@ def test_replay_rejects_short_planes(hip_lib):
     hip_lib.ribbit_scan_params_default(C.byref(p), 2, 100)
     w = np.zeros(4, dtype=np.uint32)
     out = ribbit_amd.SeedLists()
-    rc = hip_lib.ribbit_host_replay_calls(C.byref(p), 100, w.ctypes.data, w.ctypes.data, w.ctypes.data, 4, None, 0, None, 0, C.byref(out))
+    rc = hip_lib.ribbit_host_replay_calls(C.byref(p), 100, w.ctypes.data, w.ctypes.data, w.ctypes.data, 4, None, 0,
+                                          None, 0, None, 0, None, 0, C.byref(out))
     assert rc == -1 and b"planes too short" in hip_lib.ribbit_hip_last_error()
