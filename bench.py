@@ -6,9 +6,10 @@ pack kernel (fasta_utils.cpp:78-115) + perfect shift-XOR scan kernel over m=2..1
 (fasta_utils.cpp:117-122 + parse_perfect_shiftxor.cpp:173-223) + event read-back + host pairing
 into runs.  Workload = BASELINE.json configs[1]: 100 Mbp synthetic FASTA, -m 2 -M 100, perfect scan.
 
-N > 1: one process per GPU (torch.distributed, backend nccl == RCCL).  The path shards by chunk:
-every rank scans its own 100-Mbp chunk (weak scaling) and the sparse run records are exchanged with
-an all-gather over RCCL before the (host) merge, as BASELINE.json's north_star prescribes.
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL).  The path shards by record
+(option 1): every rank scans its own 100-Mbp record (weak scaling, no data-path
+collective) and the sparse run records are exchanged with an all-gather-v over RCCL before the
+(host) merge, as BASELINE.json's north_star prescribes.
 
 Prints ONE JSON line on rank 0.
 """
@@ -48,12 +49,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bases", type=int, default=WORKLOAD_BASES, help="bases per GPU (default: BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="after the timed region, launch the known-byte-count stream-read kernel (for PMC passes)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
 
     import ribbit_amd
+    from ribbit_amd.distributed import allgather_records
     from ribbit_amd.simulate import simulate_sequence
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -67,7 +71,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl")
 
-    # synthetic record: every rank owns one chunk of a (world x bases) record, generator seed 2 + rank
+    # synthetic records: every rank owns one record, generator seed 2 + rank
     seq, _ = simulate_sequence(args.bases, 2 + rank, M_LO, M_HI)
     dev = torch.device("cuda", local_rank)
     d_ascii = torch.frombuffer(bytearray(seq), dtype=torch.uint8).to(dev)
@@ -80,15 +84,7 @@ def main():
         runs = sc.scan_perfect_runs()
         if world > 1:
             # all-gather-v of the sparse run records over RCCL/xGMI (count exchange + padded gather)
-            n = torch.tensor([len(runs)], device=dev, dtype=torch.int64)
-            counts = [torch.zeros_like(n) for _ in range(world)]
-            dist.all_gather(counts, n)
-            cap = int(max(c.item() for c in counts))
-            buf = torch.zeros((cap, 4), device=dev, dtype=torch.int32)
-            if len(runs):
-                buf[:len(runs)] = torch.from_numpy(runs.view("<i4").reshape(-1, 4)).to(dev)
-            gathered = [torch.empty_like(buf) for _ in range(world)]
-            dist.all_gather(gathered, buf)
+            allgather_records(runs, dev)
         return runs
 
     for _ in range(args.warmup):
@@ -114,7 +110,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if args.calibrate:
+        sc.debug_stream_read(256 << 20)
+
     if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and args.bases == WORKLOAD_BASES:
+            # HBM bytes per scan_perfect_kernel launch from the committed rocprofv3 PMC passes
+            # (FETCH_SIZE / WRITE_SIZE collected separately, corrected as profiles/README.md explains)
+            traffic = json.load(open(tpath)).get("scan_perfect_kernel_hbm_bytes_per_launch")
         total_bases = args.bases * world * args.steps
         kavg = float(np.mean(kernel_ms))
         achieved = args.bases * ALGO_BYTES_PER_BASE / (kavg * 1e-3) / 1e9
@@ -126,9 +131,10 @@ def main():
             "config": {"workload": f"{args.bases} bp synthetic record per GPU, -m {M_LO} -M {M_HI}, "
                                    "pack + perfect shift-XOR scan (BASELINE.json configs[1])",
                        "bases_per_gpu": args.bases, "min_motif": M_LO, "max_motif": M_HI,
-                       "parallelism": f"chunk-sharded x{world}" if world > 1 else "single GPU"},
+                       "parallelism": f"record-sharded x{world} + all-gather-v of runs" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "scan_perfect_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": args.bases * ALGO_BYTES_PER_BASE,
                          "kernel_ms": kavg, "pack_kernel_ms": float(np.mean(pack_ms)),
                          "kernel_gbases_per_s": args.bases / (kavg * 1e-3) / 1e9,
                          "note": "integer-VALU bound by design (SURVEY.md 8d); HBM fraction reported as required"},

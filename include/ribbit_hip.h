@@ -203,6 +203,11 @@ void ribbit_seed_lists_free(RibbitSeedLists *lists);
  * the last scan (kernel + compaction + read-back), all by HIP events on the launch stream;
  * 3 host post-processing of the last scan (wall clock). */
 int ribbit_hip_last_timing_ms(const RibbitHandle *h, int what, double *ms);
+/* Profiling aid (no effect on results): streams `nbytes` of the loaded record's ASCII buffer /
+ * planes through calib_stream_read_kernel so that a PMC pass contains a launch with a known byte
+ * count in the scan kernels' access shape.  nbytes is clamped to what is resident. */
+int ribbit_hip_debug_stream_read(RibbitHandle *h, int64_t nbytes, int64_t *bytes_read);
+
 /* Number of raw device events (run starts + run ends) the last scan produced. */
 int64_t ribbit_hip_last_event_count(const RibbitHandle *h);
 

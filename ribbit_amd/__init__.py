@@ -35,6 +35,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_subst_calls", "ribbit_hip_seeds_substitutions",
     "ribbit_host_replay_calls", "ribbit_seed_lists_free",
     "ribbit_hip_anchored_calls", "ribbit_hip_seeds_anchored", "ribbit_hip_dispatch_seeds", "ribbit_hip_guard_hits",
+    "ribbit_hip_debug_stream_read",
 ]
 
 
@@ -101,6 +102,7 @@ def load_library():
     L.ribbit_hip_plane_words.argtypes = [vp]
     L.ribbit_hip_packed_plane.argtypes = [vp, C.c_int, vp]
     L.ribbit_hip_last_timing_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    L.ribbit_hip_debug_stream_read.argtypes = [vp, i64, C.POINTER(i64)]
     L.ribbit_hip_last_event_count.restype = i64
     L.ribbit_hip_last_event_count.argtypes = [vp]
     _lib = L
@@ -291,6 +293,11 @@ class Scanner:
         ms = C.c_double()
         self._check(self._L.ribbit_hip_last_timing_ms(self._h, what, C.byref(ms)))
         return ms.value
+
+    def debug_stream_read(self, nbytes: int) -> int:
+        n = C.c_int64()
+        self._check(self._L.ribbit_hip_debug_stream_read(self._h, nbytes, C.byref(n)))
+        return n.value
 
     def last_event_count(self) -> int:
         return int(self._L.ribbit_hip_last_event_count(self._h))

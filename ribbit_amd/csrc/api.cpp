@@ -788,6 +788,23 @@ int ribbit_hip_last_timing_ms(const RibbitHandle *h, int what, double *ms) {
     return RIBBIT_OK;
 }
 
+int ribbit_hip_debug_stream_read(RibbitHandle *h, int64_t nbytes, int64_t *bytes_read) {
+    if (!h || !bytes_read) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    if ((rc = h->d_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
+    // the event buffer is the largest resident allocation; fall back to the hi plane
+    const uint32_t *src = h->d_events.p ? (const uint32_t *)h->d_events.p : h->d_hi.p;
+    const int64_t avail = h->d_events.p ? (int64_t)h->d_events.cap * 8 : h->total_words * 4;
+    const int64_t n = std::max<int64_t>(0, std::min(nbytes, avail)) / 4;
+    rb::launch_calib_stream_read(src, n, h->d_counters.p + rb::EV_SUMMARY + 8, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *bytes_read = n * 4;
+    return RIBBIT_OK;
+}
+
 int64_t ribbit_hip_last_event_count(const RibbitHandle *h) { return h ? h->last_event_count : 0; }
 
 }  // extern "C"

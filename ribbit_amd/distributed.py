@@ -1,0 +1,50 @@
+"""Exchange step of the multi-GPU path: an all-gather-v of sparse 16-byte records (runs, calls or
+seeds) across ranks -- one process per GPU, torch.distributed with backend "nccl" (= RCCL over xGMI on
+ROCm) on GPUs or "gloo" in the CPU tests.  The scan itself shards by record with no collective; this is
+the only communication on the path (BASELINE.json north_star: "RCCL all-gatherv of candidate seed
+intervals before host-side merge").  Payloads are KB-MB, i.e. latency-bound: one count all-gather plus
+one padded all-gather, nothing ring-shaped to tune."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def allgather_records(records: np.ndarray, device: torch.device | None = None) -> list[np.ndarray]:
+    """Gather a structured array of 16-byte records (four int32 fields) from every rank.
+
+    Returns one array per rank (same dtype), identical on all ranks.  `device` selects where the
+    staging tensors live: the rank's GPU for nccl, CPU (None) for gloo.
+    """
+    assert records.dtype.itemsize == 16, "records are four int32 fields"
+    world = dist.get_world_size()
+    dev = device if device is not None else torch.device("cpu")
+    n = torch.tensor([len(records)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    buf = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    if len(records):
+        flat = np.ascontiguousarray(records).view("<i4").reshape(-1, 4)
+        buf[:len(records)] = torch.from_numpy(flat).to(dev)
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf)
+    out = []
+    for r in range(world):
+        arr = gathered[r][:counts[r]].cpu().numpy()
+        out.append(np.ascontiguousarray(arr).view(records.dtype).reshape(-1))
+    return out
+
+
+def shard_records(n_records: int, lengths: list[int], world: int) -> list[list[int]]:
+    """Longest-first bin packing of record indices over ranks (option 1)."""
+    order = sorted(range(n_records), key=lambda i: -lengths[i])
+    load = [0] * world
+    bins: list[list[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: load[k])
+        bins[r].append(i)
+        load[r] += lengths[i]
+    return bins

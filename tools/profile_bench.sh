@@ -1,0 +1,16 @@
+#!/bin/bash
+# Profiles bench.py on the GPU box: kernel trace + stats, then FETCH_SIZE and WRITE_SIZE in separate
+# PMC passes (gfx950: they do not fit in one pass).  Output under gpurun_out/<tag>/; copy the
+# summaries you want judged into profiles/.
+# Usage (on the GPU box, from the repo root):  bash tools/profile_bench.sh <tag>
+set -e
+TAG=${1:-prof}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --calibrate"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/bench_write.err
+find $OUT -name "*.csv" | head -20

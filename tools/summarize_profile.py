@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/<tag>/ (written by tools/profile_bench.sh on the GPU box) into the committed
+summaries under profiles/: kernel stats, per-kernel PMC means, and traffic.json (HBM bytes per
+scan_perfect_kernel launch, corrected as MI355X_MICROARCH.md's HBM section prescribes).
+Usage: python tools/summarize_profile.py <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench_trace.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
+
+pmc = {}
+for name in ("pmc_fetch", "pmc_write"):
+    f = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), v in agg.items():
+        pmc.setdefault(k, {})[c] = {"launches": len(v), "mean_kb": sum(v) / len(v)}
+with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as fh:
+    json.dump(pmc, fh, indent=1, sort_keys=True)
+
+# calibration: calib_stream_read_kernel reads a known byte count (one coalesced dword per lane)
+bench = json.load(open(os.path.join(src, "bench_fetch.json")))
+calib = pmc["rb::calib_stream_read_kernel"]["FETCH_SIZE"]["mean_kb"] * 1024
+events_cap = max(1 << 20, bench["config"]["bases_per_gpu"] // 4)
+events_cap = (events_cap + 63) // 64 * 64
+known = min(256 << 20, events_cap * 8)
+factor = known / calib
+scan = pmc["rb::scan_perfect_kernel"]
+fetch = scan["FETCH_SIZE"]["mean_kb"] * 1024 * factor
+write = scan["WRITE_SIZE"]["mean_kb"] * 1024
+out = {
+    "tag": tag,
+    "fetch_size_correction": factor,
+    "calibration": {"kernel": "calib_stream_read_kernel", "known_bytes": known, "FETCH_SIZE_bytes": calib},
+    "scan_perfect_kernel_hbm_read_bytes_per_launch": fetch,
+    "scan_perfect_kernel_hbm_write_bytes_per_launch": write,
+    "scan_perfect_kernel_hbm_bytes_per_launch": fetch + write,
+    "algorithmic_read_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+    "events_per_launch": bench["device_events_per_step"],
+}
+with open(os.path.join(dst, "traffic.json"), "w") as fh:
+    json.dump(out, fh, indent=1)
+print(json.dumps(out, indent=1))
