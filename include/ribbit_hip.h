@@ -152,6 +152,59 @@ int ribbit_hip_seeds_anchored(RibbitHandle *h, const RibbitSeed **perfect, size_
  */
 int ribbit_hip_dispatch_seeds(RibbitHandle *h, const RibbitSeed **out, size_t *n);
 
+/*
+ * Thresholds the refinement scans read from the reference's globals: MINIMUM_LENGTH / PERFECT_UNITS
+ * (global_variables.h:36-38, filled at ribbit.cpp:143-174,219-235; index = motif size, 0 = the value
+ * operator[] default-inserts for a missing key), PURITY_THRESHOLD (always 0.85, -p is ignored) and
+ * cones_threshold (3, ribbit.cpp:191).
+ */
+#define RIBBIT_TABLE 1024
+typedef struct RibbitRefineParams {
+    int32_t min_length[RIBBIT_TABLE];
+    int32_t perfect_units[RIBBIT_TABLE];
+    float purity_threshold;
+    int32_t continuous_ones_threshold;
+} RibbitRefineParams;
+/* defaults for -m min_motif -M max_motif with no -l / --min-units / --perfect-units */
+void ribbit_refine_params_default(RibbitRefineParams *p, int32_t min_motif, int32_t max_motif);
+
+/*
+ * One Smith-Waterman job as processSeedMotifWise (parse_smallmotif_seed.cpp:255-270) or the first level
+ * of processSeed (parse_seed.cpp:379-404) sets it up: query = sequence.substr(query_start, query_length);
+ * reference = the motif (motif_pool + motif_offset, `atomicity` characters) repeated until longer than
+ * ppr_length; Align(query, ref, ppr_length, filter, &alignment, 15).
+ */
+typedef struct RibbitAlignJob {
+    int32_t seed_index;      /* index into the dispatch list */
+    int32_t seed_type, motif_length, atomicity;
+    int32_t query_start, query_length, ppr_length;
+    int32_t small;           /* 1: processSeedMotifWise (m <= 10); 0: processSeed */
+    int32_t motif_offset;
+} RibbitAlignJob;
+
+/* longestContinuousMatches (parse_seed.cpp:26-44; calls at parse_seed.cpp:366, parse_smallmotif_seed.cpp:234)
+ * for every dispatched seed at once, on the GPU: out[i] belongs to dispatch seed i. */
+int ribbit_hip_seed_longest_runs(RibbitHandle *h, const int32_t **out, size_t *n);
+
+/*
+ * The refinement scans between dispatch and alignment for every dispatched seed: seed validity,
+ * possibleMotifs / calculateRepeatClass / calculateAtomicity (parse_smallmotif_seed.cpp:76-188,
+ * bitseq_utils.cpp:139-221) for m <= 10, mostFrequentLongerMotif / calculateAtomicityLongMotif
+ * (parse_seed.cpp:153-256, bitseq_utils.cpp:116-137) for m > 10, calculateMotif (bitseq_utils.cpp:14-38).
+ * Jobs come in the order the reference would run its alignments (the recursion of processSeed on
+ * flanks happens after alignment and is not part of this list).
+ */
+int ribbit_hip_refine_jobs(RibbitHandle *h, const RibbitRefineParams *prm, const RibbitAlignJob **jobs, size_t *n,
+                           const char **motif_pool);
+
+/* Host-only variant (no GPU): same jobs from a dispatch list and host planes; *jobs and *motif_pool are
+ * malloc'ed, release with ribbit_refine_jobs_free(). */
+int ribbit_host_refine_jobs(const RibbitScanParams *params, const RibbitRefineParams *prm, int64_t length,
+                            const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
+                            const uint32_t *xa, size_t xa_stride, const RibbitSeed *dispatch, size_t n_dispatch,
+                            RibbitAlignJob **jobs, size_t *n_jobs, char **motif_pool, size_t *pool_len);
+void ribbit_refine_jobs_free(RibbitAlignJob *jobs, char *motif_pool);
+
 /* How often the defined-divergence guards fired in the merges of this record (the
  * reference has undefined behaviour there; 0 on ordinary inputs). */
 int64_t ribbit_hip_guard_hits(const RibbitHandle *h);

@@ -76,6 +76,30 @@ int64_t rbo_guard_hits(const rbo_ctx *c);
 /* statistics: range popcounts requested by the merges so far */
 int64_t rbo_range_queries(const rbo_ctx *c);
 
+/* ---- refinement front half (rows a13-a15), ribbit_oracle_refine.cpp ---- */
+#define RBO_TABLE 1024
+typedef struct {
+    int32_t min_length[RBO_TABLE];      /* MINIMUM_LENGTH[k]; 0 = the value operator[] default-inserts (Q13) */
+    int32_t perfect_units[RBO_TABLE];   /* PERFECT_UNITS[k] */
+    float purity_threshold;             /* PURITY_THRESHOLD, always 0.85 in the reference (Q1) */
+    int32_t continuous_ones_threshold;  /* cones_threshold = 3, ribbit.cpp:191 */
+} rbo_refine_params_t;
+
+/* one Smith-Waterman job as processSeedMotifWise (parse_smallmotif_seed.cpp:255-270) or the first level
+ * of processSeed (parse_seed.cpp:379-404) sets it up: query = sequence.substr(query_start, query_length),
+ * reference = the motif (pool + motif_offset, `atomicity` characters) repeated past ppr_length */
+typedef struct {
+    int32_t seed_index;     /* index into the dispatch list */
+    int32_t seed_type, motif_length, atomicity;
+    int32_t query_start, query_length, ppr_length;
+    int32_t small;          /* 1: processSeedMotifWise (m <= 10), 0: processSeed */
+    int32_t motif_offset;
+} rbo_job_t;
+
+void rbo_refine_params_default(rbo_refine_params_t *p, int m_lo, int m_hi);
+/* needs rbo_run_dispatch() to have run; arrays stay valid until the next call */
+int64_t rbo_refine_jobs(rbo_ctx *c, const rbo_refine_params_t *prm, const rbo_job_t **jobs, const char **pool);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,13 +13,16 @@ import os
 import numpy as np
 
 __all__ = ["RibbitHipError", "ScanParams", "Scanner", "library_path", "load_library", "host_replay_calls", "pack_planes", "pack_bit_planes",
-           "RUN_DT", "CALL_DT", "SEED_DT", "RANK", "TERM"]
+           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 RANK = {"P": 5, "Q": 4, "S": 3, "F": 2, "C": 1, "A": 0, "N": -1}     # global_variables.cpp:28-34
 TERM = {"ZERO": 0, "N": 1, "EOS": 2}
 
+JOB_DT = np.dtype([("seed_index", "<i4"), ("seed_type", "<i4"), ("motif_length", "<i4"), ("atomicity", "<i4"),
+                   ("query_start", "<i4"), ("query_length", "<i4"), ("ppr_length", "<i4"), ("small", "<i4"),
+                   ("motif_offset", "<i4")])
 RUN_DT = np.dtype([("start", "<i4"), ("end", "<i4"), ("mlen", "<i4"), ("term", "<i4")])
 CALL_DT = np.dtype([("pos", "<i4"), ("mlen", "<i4"), ("start", "<i4"), ("end", "<i4")])
 SEED_DT = np.dtype([("start", "<i4"), ("end", "<i4"), ("mlen", "<i4"), ("type", "<i4")])
@@ -36,6 +39,8 @@ ABI_SYMBOLS = [
     "ribbit_host_replay_calls", "ribbit_seed_lists_free",
     "ribbit_hip_anchored_calls", "ribbit_hip_seeds_anchored", "ribbit_hip_dispatch_seeds", "ribbit_hip_guard_hits",
     "ribbit_hip_debug_stream_read",
+    "ribbit_refine_params_default", "ribbit_hip_seed_longest_runs", "ribbit_hip_refine_jobs",
+    "ribbit_host_refine_jobs", "ribbit_refine_jobs_free",
 ]
 
 
@@ -47,6 +52,12 @@ class ScanParams(C.Structure):
     """RibbitScanParams (ribbit.cpp:191,240-243; fasta_utils.cpp:165)."""
     _fields_ = [("min_motif", C.c_int32), ("max_motif", C.c_int32), ("window_length", C.c_int32),
                 ("subst_threshold", C.c_int32), ("anchor_threshold", C.c_int32), ("anchor_length", C.c_int32)]
+
+
+class RefineParams(C.Structure):
+    """RibbitRefineParams (MINIMUM_LENGTH / PERFECT_UNITS tables, purity, cones threshold)."""
+    _fields_ = [("min_length", C.c_int32 * 1024), ("perfect_units", C.c_int32 * 1024),
+                ("purity_threshold", C.c_float), ("continuous_ones_threshold", C.c_int32)]
 
 
 class SeedLists(C.Structure):
@@ -102,6 +113,15 @@ def load_library():
     L.ribbit_hip_plane_words.argtypes = [vp]
     L.ribbit_hip_packed_plane.argtypes = [vp, C.c_int, vp]
     L.ribbit_hip_last_timing_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    L.ribbit_refine_params_default.restype = None
+    L.ribbit_refine_params_default.argtypes = [C.POINTER(RefineParams), i32, i32]
+    L.ribbit_hip_seed_longest_runs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ribbit_hip_refine_jobs.argtypes = [vp, C.POINTER(RefineParams), C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
+    L.ribbit_host_refine_jobs.argtypes = [C.POINTER(ScanParams), C.POINTER(RefineParams), i64, vp, vp, vp, C.c_size_t,
+                                          vp, C.c_size_t, vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t),
+                                          C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ribbit_refine_jobs_free.restype = None
+    L.ribbit_refine_jobs_free.argtypes = [vp, vp]
     L.ribbit_hip_debug_stream_read.argtypes = [vp, i64, C.POINTER(i64)]
     L.ribbit_hip_last_event_count.restype = i64
     L.ribbit_hip_last_event_count.argtypes = [vp]
@@ -171,6 +191,34 @@ def host_replay_calls(min_motif: int, max_motif: int, sequence: bytes, perfect_c
                 "guard_hits": int(out.guard_hits)}
     finally:
         L.ribbit_seed_lists_free(C.byref(out))
+
+
+def _jobs_with_motifs(jobs, pool: bytes):
+    """-> list of (job record, motif string)"""
+    return [(j, pool[int(j["motif_offset"]):int(j["motif_offset"]) + int(j["atomicity"])].decode()) for j in jobs]
+
+
+def host_refine_jobs(min_motif: int, max_motif: int, sequence: bytes, xa, xa_stride: int, dispatch, refine_params=None):
+    """ribbit_host_refine_jobs: dispatch seeds + planes -> (jobs array, motif pool bytes). No GPU needed."""
+    L = load_library()
+    params = ScanParams()
+    L.ribbit_scan_params_default(C.byref(params), min_motif, max_motif)
+    rp = refine_params
+    if rp is None:
+        rp = RefineParams()
+        L.ribbit_refine_params_default(C.byref(rp), min_motif, max_motif)
+    hi, lo, brk = pack_planes(sequence, max_motif)
+    d = np.ascontiguousarray(dispatch, dtype=SEED_DT)
+    jobs, nj, pool, npool = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+    rc = L.ribbit_host_refine_jobs(C.byref(params), C.byref(rp), len(sequence), hi.ctypes.data, lo.ctypes.data, brk.ctypes.data,
+                                   len(hi), xa.ctypes.data, xa_stride, d.ctypes.data, len(d),
+                                   C.byref(jobs), C.byref(nj), C.byref(pool), C.byref(npool))
+    if rc != 0:
+        raise RibbitHipError(f"ribbit_host_refine_jobs error {rc}: {L.ribbit_hip_last_error().decode()}")
+    try:
+        return _copy(jobs.value, nj.value, JOB_DT), C.string_at(pool.value, npool.value)
+    finally:
+        L.ribbit_refine_jobs_free(jobs, pool)
 
 
 class Scanner:
@@ -267,6 +315,23 @@ class Scanner:
 
     def dispatch_seeds(self):
         return self._list(self._L.ribbit_hip_dispatch_seeds, SEED_DT)
+
+    # parse_seed.cpp:26-44 (batched on the GPU), parse_smallmotif_seed.cpp:76-270, parse_seed.cpp:153-404 ----
+    def seed_longest_runs(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.ribbit_hip_seed_longest_runs(self._h, C.byref(p), C.byref(n)))
+        return _copy(p.value, n.value, np.dtype("<i4"))
+
+    def refine_jobs(self, refine_params=None):
+        rp = refine_params
+        if rp is None:
+            rp = RefineParams()
+            self._L.ribbit_refine_params_default(C.byref(rp), self.params.min_motif, self.params.max_motif)
+        jobs, n, pool = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        self._check(self._L.ribbit_hip_refine_jobs(self._h, C.byref(rp), C.byref(jobs), C.byref(n), C.byref(pool)))
+        arr = _copy(jobs.value, n.value, JOB_DT)
+        size = int((arr["motif_offset"] + arr["atomicity"]).max()) if len(arr) else 0
+        return arr, (C.string_at(pool.value, size) if size else b"")
 
     def guard_hits(self) -> int:
         return int(self._L.ribbit_hip_guard_hits(self._h))

@@ -17,6 +17,7 @@
 #include "device_planes.h"
 #include "host_planes.h"
 #include "kernels.h"
+#include "refine.h"
 #include "ribbit_hip.h"
 #include "seed_lists.h"
 #include "window_fsm.h"
@@ -124,6 +125,12 @@ struct RibbitHandle {
     bool anchored_calls_valid = false;
     std::vector<RibbitCall> anchored_calls;
     std::vector<RibbitSeed> dispatch;
+    bool longest_valid = false;
+    std::vector<int32_t> longest_runs;
+    DevBuf<RibbitSeed> d_seeds;
+    DevBuf<int32_t> d_longest;
+    std::vector<RibbitAlignJob> jobs;
+    std::string motif_pool;
     int stage_done = STAGE_NONE;          // how far the seed lists have been advanced
     rb::SeedLists lists;
 
@@ -155,6 +162,7 @@ int is_gfx950(int device) {
 int pack_loaded_ascii(RibbitHandle *h, const uint8_t *dev_ascii, int64_t length) {
     h->loaded = false;
     h->runs_valid = h->calls_valid = h->subst_calls_valid = h->anchored_calls_valid = false;
+    h->longest_valid = false;
     h->host_planes_valid = false;
     h->stage_done = STAGE_NONE;
     h->length = length;
@@ -465,6 +473,39 @@ int advance_to_anchored(RibbitHandle *h) {
     return RIBBIT_OK;
 }
 
+// longestContinuousMatches of every dispatched seed, one GPU launch (a13)
+int build_longest_runs(RibbitHandle *h) {
+    if (h->longest_valid) return RIBBIT_OK;
+    int rc = advance_to_anchored(h);
+    if (rc) return rc;
+    if ((rc = bind_device(h))) return rc;
+    const size_t n = h->dispatch.size();
+    h->longest_runs.assign(n, 0);
+    if (n) {
+        if ((rc = h->d_seeds.ensure(n))) return rc;
+        if ((rc = h->d_longest.ensure(n))) return rc;
+        HIP_TRY(hipMemcpyAsync(h->d_seeds.p, h->dispatch.data(), n * sizeof(RibbitSeed), hipMemcpyHostToDevice, h->stream));
+        rb::launch_seed_longest_runs(h->d_xa.p, h->xa_stride, h->params.min_motif, h->d_seeds.p, (int64_t)n, h->d_longest.p, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->longest_runs.data(), h->d_longest.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    h->longest_valid = true;
+    return RIBBIT_OK;
+}
+
+void fill_refine_defaults(RibbitRefineParams *p, int min_motif, int max_motif) {
+    std::memset(p, 0, sizeof *p);
+    p->purity_threshold = 0.85f;             // global_variables.cpp:44 (the -p option is never read)
+    p->continuous_ones_threshold = 3;        // ribbit.cpp:191
+    std::vector<char> known(RIBBIT_TABLE, 0);
+    for (int k = min_motif; k <= max_motif && k < RIBBIT_TABLE; ++k) { p->min_length[k] = std::max(12, 2 * k); known[k] = 1; }   // ribbit.cpp:153-159
+    for (int m = 1; m <= max_motif && m < RIBBIT_TABLE; ++m) p->perfect_units[m] = m == 1 ? 8 : m == 2 ? 4 : m == 3 ? 3 : 2;     // :166-173
+    for (int m = min_motif; m <= max_motif && m < RIBBIT_TABLE; ++m)                                                            // :219-235
+        for (int f = 1; f <= m / 2; ++f)
+            if (m % f == 0 && !known[f]) { p->min_length[f] = p->min_length[m]; known[f] = 1; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -527,7 +568,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ascii.release(); h->d_hi.release(); h->d_lo.release(); h->d_brk.release();
-    h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release();
+    h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release();
     h->h_events.release(); h->h_counters.release(); h->h_query.release();
     for (int i = 0; i < 6; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -644,6 +685,73 @@ int ribbit_hip_dispatch_seeds(RibbitHandle *h, const RibbitSeed **out, size_t *n
     *out = h->dispatch.data();
     *n = h->dispatch.size();
     return RIBBIT_OK;
+}
+
+void ribbit_refine_params_default(RibbitRefineParams *p, int32_t min_motif, int32_t max_motif) {
+    if (p) fill_refine_defaults(p, min_motif, max_motif);
+}
+
+int ribbit_hip_seed_longest_runs(RibbitHandle *h, const int32_t **out, size_t *n) {
+    if (!h || !out || !n) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    int rc = build_longest_runs(h);
+    if (rc) return rc;
+    *out = h->longest_runs.data();
+    *n = h->longest_runs.size();
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_refine_jobs(RibbitHandle *h, const RibbitRefineParams *prm, const RibbitAlignJob **jobs, size_t *n,
+                           const char **motif_pool) {
+    if (!h || !prm || !jobs || !n || !motif_pool) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    int rc = build_longest_runs(h);
+    if (rc) return rc;
+    rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->jobs, h->motif_pool);
+    *jobs = h->jobs.data();
+    *n = h->jobs.size();
+    *motif_pool = h->motif_pool.c_str();
+    return RIBBIT_OK;
+}
+
+int ribbit_host_refine_jobs(const RibbitScanParams *params, const RibbitRefineParams *prm, int64_t length,
+                            const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
+                            const uint32_t *xa, size_t xa_stride, const RibbitSeed *dispatch, size_t n_dispatch,
+                            RibbitAlignJob **jobs, size_t *n_jobs, char **motif_pool, size_t *pool_len) {
+    if (!params || !prm || !jobs || !n_jobs || !motif_pool || !pool_len || (n_dispatch && !dispatch)) return fail(RIBBIT_E_ARG, "null argument");
+    if (length > 0 && (!hi || !lo || !brk || !xa)) return fail(RIBBIT_E_ARG, "null plane");
+    if (nwords < (size_t)(length / 32 + 1) || xa_stride < (size_t)(length / 32 + 1)) return fail(RIBBIT_E_ARG, "planes too short");
+    rb::HostPlanes hp;
+    hp.resize(length, nwords);
+    if (nwords) {
+        std::memcpy(hp.hi.data(), hi, nwords * sizeof(uint32_t));
+        std::memcpy(hp.lo.data(), lo, nwords * sizeof(uint32_t));
+        std::memcpy(hp.brk.data(), brk, nwords * sizeof(uint32_t));
+    }
+    const size_t nm = (size_t)(params->max_motif - params->min_motif + 1);
+    if (xa) hp.xa.assign(xa, xa + nm * xa_stride);
+    hp.xa_stride = (int64_t)xa_stride;
+    hp.xa_m_lo = params->min_motif;
+    hp.xa_m_hi = params->max_motif;
+    std::vector<RibbitSeed> seeds(dispatch, dispatch + n_dispatch);
+    std::vector<int32_t> longest(n_dispatch);
+    for (size_t i = 0; i < n_dispatch; ++i) longest[i] = rb::longest_run_host(hp, seeds[i].mlen, seeds[i].start, seeds[i].end);
+    std::vector<RibbitAlignJob> out;
+    std::string pool;
+    rb::build_align_jobs(hp, *prm, seeds, longest.data(), out, pool);
+    *n_jobs = out.size();
+    *pool_len = pool.size();
+    *jobs = (RibbitAlignJob *)std::malloc(std::max<size_t>(out.size(), 1) * sizeof(RibbitAlignJob));
+    *motif_pool = (char *)std::malloc(pool.size() + 1);
+    if (!*jobs || !*motif_pool) { std::free(*jobs); std::free(*motif_pool); return fail(RIBBIT_E_NOMEM, "out of host memory"); }
+    if (!out.empty()) std::memcpy(*jobs, out.data(), out.size() * sizeof(RibbitAlignJob));
+    std::memcpy(*motif_pool, pool.c_str(), pool.size() + 1);
+    return RIBBIT_OK;
+}
+
+void ribbit_refine_jobs_free(RibbitAlignJob *jobs, char *motif_pool) {
+    std::free(jobs);
+    std::free(motif_pool);
 }
 
 int64_t ribbit_hip_guard_hits(const RibbitHandle *h) { return h ? h->lists.guard_hits : 0; }

@@ -45,6 +45,10 @@ void launch_compact_events(const uint64_t *events, uint32_t ev_cap, uint32_t *co
 void launch_plane_words(const DevicePlanes &pl, int shift, int64_t w0, int64_t nw, uint32_t *out_words,
                         int64_t p0, int64_t p1, uint32_t *count, hipStream_t stream);
 
+// longestContinuousMatches (parse_seed.cpp:26-44) of n seeds {start,end,mlen,type} on the composed planes
+void launch_seed_longest_runs(const uint32_t *xa, int64_t xa_stride, int m_lo, const void *seeds, int64_t n, int32_t *out,
+                              hipStream_t stream);
+
 // profiling aid: reads nwords dwords of src with one coalesced dword per lane (known byte count)
 void launch_calib_stream_read(const uint32_t *src, int64_t nwords, uint32_t *sink, hipStream_t stream);
 

@@ -776,6 +776,44 @@ void launch_plane_words(const DevicePlanes &pl, int shift, int64_t w0, int64_t n
                        p0, p1, count);
 }
 
+// ------------------------------------------------------- longestContinuousMatches, batched (a13)
+// parse_seed.cpp:26-44 for every dispatched seed at once: longest run of ones of the composed plane
+// XA_mlen over [start, end).  One thread per seed (seeds are a few words long); word-parallel:
+// leading / trailing ones by ctz / clz, the longest interior run by the y &= y << 1 peel.
+__global__ __launch_bounds__(256) void seed_longest_run_kernel(const uint32_t *__restrict__ xa, int64_t xa_stride, int m_lo,
+                                                               const int4 *__restrict__ seeds, int64_t n,
+                                                               int32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 seed = seeds[i];                       // start, end, mlen, type
+    const int start = seed.x, end = seed.y;
+    int best = 0;
+    if (end > start) {
+        const uint32_t *w = xa + (int64_t)(seed.z - m_lo) * xa_stride;
+        const int w0 = start >> 5, w1 = (end - 1) >> 5;
+        int run = 0;
+        for (int k = w0; k <= w1; ++k) {
+            uint32_t x = w[k];
+            if (k == w0) x &= 0xffffffffu << (start & 31);
+            if (k == w1) { const int top = ((end - 1) & 31) + 1; if (top < 32) x &= (1u << top) - 1u; }
+            if (x == 0xffffffffu) { run += 32; best = max(best, run); continue; }
+            best = max(best, run + (int)__builtin_ctz(~x));
+            int inner = 0;
+            for (uint32_t y = x; y; y &= y << 1) ++inner;
+            best = max(best, inner);
+            run = __builtin_clz(~x);
+        }
+    }
+    out[i] = best;
+}
+
+void launch_seed_longest_runs(const uint32_t *xa, int64_t xa_stride, int m_lo, const void *seeds, int64_t n, int32_t *out,
+                              hipStream_t stream) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(seed_longest_run_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, xa, xa_stride, m_lo,
+                       (const int4 *)seeds, n, out);
+}
+
 // ------------------------------------------------------------------- PMC calibration
 // Streams `nwords` dwords with the same access shape as the scan kernels' staging loads (one
 // coalesced dword per lane).  rocprofv3's FETCH_SIZE is only calibrated for 16-byte-per-lane

@@ -1,0 +1,243 @@
+#include "refine.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <unordered_map>
+
+namespace rb {
+
+namespace {
+
+// 256-bit unsigned with wrap-around, the arithmetic the reference gets from an unchecked
+// boost::multiprecision::uint256_t (motifs longer than 128 bases lose their head)
+struct Wide {
+    uint64_t limb[4] = {0, 0, 0, 0};
+    void push_base(unsigned code) {           // unit = (unit << 2) | code
+        limb[3] = (limb[3] << 2) | (limb[2] >> 62);
+        limb[2] = (limb[2] << 2) | (limb[1] >> 62);
+        limb[1] = (limb[1] << 2) | (limb[0] >> 62);
+        limb[0] = (limb[0] << 2) | code;
+    }
+    unsigned base_at(int index_from_low) const {       // 2-bit field number index_from_low
+        const int bit = 2 * index_from_low;
+        return bit >= 256 ? 0u : (unsigned)(limb[bit >> 6] >> (bit & 63)) & 3u;
+    }
+};
+
+struct Bases {
+    const HostPlanes &hp;
+    int L;
+    explicit Bases(const HostPlanes &p) : hp(p), L((int)p.length) {}
+    unsigned code(int p) const { return (((hp.hi[p >> 5] >> (p & 31)) & 1u) << 1) | ((hp.lo[p >> 5] >> (p & 31)) & 1u); }
+    bool is_n(int p) const { return p < L && ((hp.brk[p >> 5] >> (p & 31)) & 1u); }
+};
+
+// calculateRepeatClass (bitseq_utils.cpp:185-221): lexicographically smallest rotation of an m-base word
+uint32_t smallest_rotation(uint32_t word, int m) {
+    const uint32_t mask = m >= 16 ? 0xffffffffu : (1u << (2 * m)) - 1u;
+    uint32_t best = word, rot = word;
+    for (int i = 1; i < m; ++i) {
+        rot = ((rot << 2) | (rot >> (2 * (m - 1)))) & mask;   // rotate left by one base
+        best = std::min(best, rot);
+    }
+    return best;
+}
+
+// calculateAtomicity(uint32_t&) (bitseq_utils.cpp:139-183): smallest proper divisor period, else m
+int small_atomicity(uint32_t word, int m) {
+    for (int f = 1; 2 * f <= m; ++f) {
+        if (m % f) continue;
+        const uint32_t keep = 2 * (m - f) >= 32 ? 0xffffffffu : (1u << (2 * (m - f))) - 1u;
+        if ((word >> (2 * f)) == (word & keep)) return f;
+    }
+    return m;
+}
+
+// calculateAtomicityLongMotif (bitseq_utils.cpp:116-137): smallest shift f < m - m/3 with
+// unit >> 2f == low 2(m-f) bits of unit, i.e. base i == base i+f for every i with both inside the
+// low m bases ... and every higher 2-bit field of `unit` (beyond base m-1) must be zero, which holds
+// while m <= 128.
+int long_atomicity(const Wide &unit, int m) {
+    for (int f = 1; f < m - m / 3; ++f) {
+        bool same = true;
+        for (int i = 0; i < 128 - f && same; ++i) {
+            const unsigned shifted = unit.base_at(i + f);
+            const unsigned masked = i < m - f ? unit.base_at(i) : 0u;
+            same = shifted == masked;
+        }
+        for (int i = 128 - f; i < 128 && same; ++i) same = (i < m - f ? unit.base_at(i) : 0u) == 0u;
+        if (same) return f;
+    }
+    return m;
+}
+
+std::string spell(const Wide &unit, int m, int take) {       // calculateMotif(...).substr(0, take)
+    std::string s;
+    for (int i = 0; i < take; ++i) s.push_back("ACGT"[unit.base_at(m - 1 - i)]);
+    return s;
+}
+
+// `int x = a + m + ((1 - PURITY_THRESHOLD) * b);` with float PURITY_THRESHOLD: float math, truncation
+int padded_length(int a, int m, int b, float purity) { return (int)((float)(a + m) + (1 - purity) * (float)b); }
+
+// the seed's sequence length: seed + one motif, cut at the first N (parse_seed.cpp:342-349)
+int usable_length(const Bases &b, int start, int end, int m) {
+    for (int s = start; s < end + m; ++s)
+        if (b.is_n(s)) return s - start;
+    return (end - start) + m;
+}
+
+struct Tracked { int first, last_end, units, anchor; uint32_t expect; };
+
+// possibleMotifs (parse_smallmotif_seed.cpp:76-188).  Per rotation class of the rolling m-base window
+// the reference keeps (start, end, units) in global arrays and the latest unit start in an
+// unordered_map; a class that reappears more than 3m past its end is reported (if long enough) and
+// restarted; survivors are reported in the map's iteration order (Q10).
+void discover_small_motifs(const Bases &b, int seed_start, int seq_len, int m, int min_len, int min_units,
+                           std::vector<uint32_t> &classes, std::vector<int> &starts, std::vector<int> &ends) {
+    std::unordered_map<uint32_t, int> unit_start;          // new_motif_start: drives the output order
+    std::unordered_map<uint32_t, Tracked> track;           // MOTIF_START / MOTIF_END / MOTIF_UNITS / MOTIF_NEXT
+    const int stop = std::min(seed_start + seq_len, b.L - 1);
+    const uint32_t mask = m >= 16 ? 0xffffffffu : (1u << (2 * m)) - 1u;
+    uint32_t window = 0;
+    auto qualifies = [&](const Tracked &t) { return t.last_end - t.first >= min_len && t.units >= min_units; };
+    for (int j = seed_start; j < stop; ++j) {
+        window = ((window << 2) | b.code(j)) & mask;
+        if (!(j - seed_start >= 0.9 * m - 1)) continue;
+        const uint32_t cls = smallest_rotation(window, m);
+        const int wstart = j - (m - 1), wend = j + 1;
+        const uint32_t next = ((window << 2) | (window >> (2 * (m - 1)))) & mask;
+        auto it = unit_start.find(cls);
+        if (it == unit_start.end()) {
+            unit_start[cls] = wstart;
+            track[cls] = Tracked{wstart, wend, 1, wstart, next};
+            continue;
+        }
+        Tracked &t = track[cls];
+        if (wstart - t.last_end > 3 * m) {
+            if (qualifies(t)) { classes.push_back(cls); starts.push_back(t.first); ends.push_back(t.last_end); }
+            t = Tracked{wstart, wend, 1, wstart, next};
+            it->second = wstart;
+            continue;
+        }
+        if (wstart - it->second >= m) { it->second = wstart; t.units += 1; }
+        t.last_end = wend;
+        t.expect = next;
+    }
+    for (const auto &kv : unit_start) {
+        const Tracked &t = track[kv.first];
+        if (qualifies(t)) { classes.push_back(kv.first); starts.push_back(t.first); ends.push_back(t.last_end); }
+    }
+}
+
+// mostFrequentLongerMotif (parse_seed.cpp:153-256): every window row_start..row_start+m-1 of the seed is
+// scored by walking down- and upstream in steps of m with a +-2 jitter, counting identical bases on the
+// best-matching diagonal; the best row's bases form the motif.
+Wide consensus_long_motif(const Bases &b, int seed_start, int seq_len, int m) {
+    const int seed_end = std::min(seed_start + seq_len, b.L);
+    auto diagonal = [&](int row0, int col0, int lo, int hi, int n, int step) {
+        // matches between rows row0, row0+step, ... and columns col0, col0+step, ...; stops at the first
+        // column outside [lo, hi)
+        int d = 0;
+        for (int i = 0; i < n; ++i) {
+            const int col = col0 + step * i, row = row0 + step * i;
+            if (col >= hi || col < lo) break;
+            if (!b.is_n(col) && b.code(col) == b.code(row)) ++d;
+        }
+        return d;
+    };
+    int best_row = 0, best_score = 0;
+    for (int row = seed_start; row < seed_end - m + 1; ++row) {
+        int score = 0;
+        for (int col = row + m; col < seed_end;) {                    // downstream copies (:181-198)
+            int pick = -2, top = 0;
+            for (int x = -2; x <= 2; ++x) {
+                const int d = diagonal(row, col + x, INT32_MIN, seed_end, m, 1);
+                if (d > top) { top = d; pick = x; }
+            }
+            score += top;
+            col += pick + m;
+        }
+        int col = row - m;
+        for (; col > seed_start;) {                                   // upstream copies (:200-217)
+            int pick = -2, top = 0;
+            for (int x = -2; x <= 2; ++x) {
+                const int d = diagonal(row, col + x, 0, INT32_MAX, m, 1);
+                if (d > top) { top = d; pick = x; }
+            }
+            score += top;
+            col += pick - m;
+        }
+        if (col < seed_start && std::abs(col - seed_start) < m) {     // partial copy at the seed's head (:219-237)
+            const int rows = m + (col - seed_start);
+            int top = 0;
+            for (int x = -2; x <= 2; ++x)
+                top = std::max(top, diagonal(row + m - 1, seed_start + rows - 1 + x, seed_start, seed_end, rows, -1));
+            score += top;
+        }
+        if (score > best_score) { best_score = score; best_row = row; }
+    }
+    Wide unit;
+    for (int j = best_row; j < best_row + m; ++j) unit.push_base(b.code(j));
+    return unit;
+}
+
+}  // namespace
+
+int longest_run_host(const HostPlanes &hp, int mlen, int start, int end) {
+    const uint32_t *w = hp.xa.data() + (int64_t)(mlen - hp.xa_m_lo) * hp.xa_stride;
+    int best = 0, run = 0;
+    for (int p = start; p < end; ++p) {
+        if ((w[p >> 5] >> (p & 31)) & 1u) { ++run; best = std::max(best, run); }
+        else run = 0;
+    }
+    return best;
+}
+
+void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const std::vector<RibbitSeed> &dispatch,
+                      const int32_t *longest_runs, std::vector<RibbitAlignJob> &jobs, std::string &motif_pool) {
+    jobs.clear();
+    motif_pool.clear();
+    const Bases b(hp);
+    std::vector<uint32_t> classes;
+    std::vector<int> starts, ends;
+    for (size_t i = 0; i < dispatch.size(); ++i) {
+        const RibbitSeed &seed = dispatch[i];
+        const int m = seed.mlen;
+        if (m > 10 && seed.end - seed.start < 0.9 * m) continue;                    // parse_seed.cpp:360
+        if (longest_runs[i] < prm.continuous_ones_threshold) continue;              // :366-367 / smallmotif :234-235
+        const int seq_len = usable_length(b, seed.start, seed.end, m);
+        RibbitAlignJob job{};
+        job.seed_index = (int32_t)i;
+        job.seed_type = seed.type;
+        job.motif_length = m;
+        if (m <= 10) {
+            classes.clear(); starts.clear(); ends.clear();
+            discover_small_motifs(b, seed.start, seq_len, m, prm.min_length[m], prm.perfect_units[m], classes, starts, ends);
+            for (size_t k = 0; k < classes.size(); ++k) {
+                Wide unit; unit.limb[0] = classes[k];
+                job.atomicity = small_atomicity(classes[k], m);
+                job.query_start = starts[k];
+                job.query_length = ends[k] - starts[k];
+                job.ppr_length = padded_length(job.query_length, m, job.query_length, prm.purity_threshold);
+                job.small = 1;
+                job.motif_offset = (int32_t)motif_pool.size();
+                motif_pool += spell(unit, m, job.atomicity);
+                jobs.push_back(job);
+            }
+        } else {
+            const Wide unit = consensus_long_motif(b, seed.start, seq_len, m);
+            job.atomicity = long_atomicity(unit, m);
+            if (m % job.atomicity != 0) continue;                                    // parse_seed.cpp:392
+            job.query_start = seed.start;
+            job.query_length = std::min(seq_len, b.L - seed.start);
+            job.ppr_length = padded_length(seq_len, m, seq_len, prm.purity_threshold);
+            job.small = 0;
+            job.motif_offset = (int32_t)motif_pool.size();
+            motif_pool += spell(unit, m, job.atomicity);
+            jobs.push_back(job);
+        }
+    }
+}
+
+}  // namespace rb

@@ -1,0 +1,27 @@
+// refine.h -- host side of the per-seed refinement scans that sit between seed dispatch and the
+// Smith-Waterman alignment: motif discovery for small motifs
+// (possibleMotifs, parse_smallmotif_seed.cpp:76-188), consensus motif for long ones
+// (mostFrequentLongerMotif, parse_seed.cpp:153-256), atomicity (bitseq_utils.cpp:88-183) and the
+// alignment-job set-up of processSeedMotifWise / processSeed.  Sparse per-seed work: host, as in the
+// reference; the only bit scan (longestContinuousMatches, parse_seed.cpp:26-44) has a batched GPU
+// kernel (seed_longest_run_kernel) and the host only consumes its per-seed results.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "host_planes.h"
+#include "ribbit_hip.h"
+
+namespace rb {
+
+// longest_runs[i] = longestContinuousMatches of dispatch seed i on its composed plane
+void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const std::vector<RibbitSeed> &dispatch,
+                      const int32_t *longest_runs, std::vector<RibbitAlignJob> &jobs, std::string &motif_pool);
+
+// host computation of the same quantity from the host copy of the composed planes (used by
+// ribbit_host_refine_jobs, which has no device)
+int longest_run_host(const HostPlanes &hp, int mlen, int start, int end);
+
+}  // namespace rb

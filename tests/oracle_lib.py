@@ -14,6 +14,9 @@ _ORACLE_DIR = os.path.join(_ROOT, "oracle")
 RANK = {"P": 5, "Q": 4, "S": 3, "F": 2, "C": 1, "A": 0, "N": -1}
 LIST_PERFECT, LIST_SUBST, LIST_ANCHORED = 0, 1, 2
 
+JOB_DT = np.dtype([("seed_index", "<i4"), ("seed_type", "<i4"), ("motif_length", "<i4"), ("atomicity", "<i4"),
+                   ("query_start", "<i4"), ("query_length", "<i4"), ("ppr_length", "<i4"), ("small", "<i4"),
+                   ("motif_offset", "<i4")])
 SEED_DT = np.dtype([("start", "<i4"), ("end", "<i4"), ("mlen", "<i4"), ("type", "<i4")])
 CALL_DT = np.dtype([("pos", "<i4"), ("mlen", "<i4"), ("start", "<i4"), ("end", "<i4")])
 
@@ -59,6 +62,10 @@ def lib():
         L.rbo_calls.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.rbo_dispatch.restype = C.c_int64
         L.rbo_dispatch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.rbo_refine_params_default.restype = None
+        L.rbo_refine_params_default.argtypes = [C.POINTER(RefineParams), C.c_int, C.c_int]
+        L.rbo_refine_jobs.restype = C.c_int64
+        L.rbo_refine_jobs.argtypes = [C.c_void_p, C.POINTER(RefineParams), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         L.rbo_range_count.restype = C.c_int
         L.rbo_range_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         _lib = L
@@ -70,6 +77,11 @@ def _copy(ptr, n, dt):
         return np.zeros(0, dtype=dt)
     buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
     return np.frombuffer(buf, dtype=dt).copy()
+
+
+class RefineParams(C.Structure):
+    _fields_ = [("min_length", C.c_int32 * 1024), ("perfect_units", C.c_int32 * 1024),
+                ("purity_threshold", C.c_float), ("continuous_ones_threshold", C.c_int32)]
 
 
 class Oracle:
@@ -148,6 +160,18 @@ class Oracle:
         p = C.c_void_p()
         n = self._L.rbo_dispatch(self._h, C.byref(p))
         return _copy(p.value, n, SEED_DT)
+
+    def refine_jobs(self, params=None):
+        """(jobs array, motif pool bytes); needs run_dispatch() first"""
+        rp = params
+        if rp is None:
+            rp = RefineParams()
+            self._L.rbo_refine_params_default(C.byref(rp), self.m_lo, self.m_hi)
+        jobs, pool = C.c_void_p(), C.c_void_p()
+        n = self._L.rbo_refine_jobs(self._h, C.byref(rp), C.byref(jobs), C.byref(pool))
+        arr = _copy(jobs.value, n, JOB_DT)
+        size = int((arr["motif_offset"] + arr["atomicity"]).max()) if len(arr) else 0
+        return arr, (C.string_at(pool.value, size) if size else b"")
 
     def range_count(self, shift, start, end):
         return self._L.rbo_range_count(self._h, shift, start, end)

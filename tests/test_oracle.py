@@ -141,6 +141,7 @@ def test_oracle_clean_under_sanitizers():
         "for name, seq, lo, hi in cases.edge_cases():\n"
         "    with oracle_lib.Oracle(seq, lo, hi) as o:\n"
         "        o.run_all()\n"
+        "        o.refine_jobs()\n"
         "print('sanitizer-run-ok')\n"
     ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), so)
     asan_rt = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()

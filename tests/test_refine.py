@@ -1,0 +1,63 @@
+"""CPU tests of the refinement front half (rows a13-a15): the product's host implementation
+(ribbit_amd/csrc/refine.cpp, through ribbit_host_refine_jobs) against the oracle's restatement
+(oracle/ribbit_oracle_refine.cpp) on the oracle's dispatch lists and composed planes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ribbit_amd
+from cases import edge_cases, simulated_cases
+from oracle_lib import Oracle, RefineParams, lib
+
+ALL = edge_cases() + simulated_cases()
+
+
+def _same_jobs(got, gpool, want, wpool):
+    assert len(got) == len(want)
+    for f in ("seed_index", "seed_type", "motif_length", "atomicity", "query_start", "query_length", "ppr_length", "small"):
+        assert np.array_equal(got[f], want[f]), f
+    gm = [m for _, m in ribbit_amd._jobs_with_motifs(got, gpool)]
+    wm = [m for _, m in ribbit_amd._jobs_with_motifs(want, wpool)]
+    assert gm == wm
+
+
+@pytest.mark.parametrize("name,seq,m_lo,m_hi", ALL, ids=[c[0] for c in ALL])
+def test_refine_jobs_match_oracle(name, seq, m_lo, m_hi):
+    with Oracle(seq, m_lo, m_hi) as o:
+        o.run_all()
+        want, wpool = o.refine_jobs()
+        xa, stride = ribbit_amd.pack_bit_planes([o.plane(m) for m in range(m_lo, m_hi + 1)], len(seq))
+        got, gpool = ribbit_amd.host_refine_jobs(m_lo, m_hi, seq, xa, stride, o.dispatch())
+    _same_jobs(got, gpool, want, wpool)
+
+
+def test_defaults_follow_ribbit_cpp():
+    for m_lo, m_hi in ((2, 100), (5, 40), (3, 9), (30, 100)):
+        a = RefineParams()
+        lib().rbo_refine_params_default(C.byref(a), m_lo, m_hi)
+        b = ribbit_amd.RefineParams()
+        ribbit_amd.load_library().ribbit_refine_params_default(C.byref(b), m_lo, m_hi)
+        assert list(a.min_length) == list(b.min_length) and list(a.perfect_units) == list(b.perfect_units)
+        assert a.purity_threshold == b.purity_threshold and a.continuous_ones_threshold == b.continuous_ones_threshold
+    # ribbit.cpp:153-159: 12, or 2*m when that is larger; :166-173: 8/4/3/2; :219-235: factors inherit
+    p = ribbit_amd.RefineParams()
+    ribbit_amd.load_library().ribbit_refine_params_default(C.byref(p), 5, 40)
+    assert p.min_length[5] == 12 and p.min_length[7] == 14 and p.min_length[40] == 80
+    assert p.min_length[1] == 12 and p.min_length[2] == 12 and p.min_length[4] == 16 and p.min_length[3] == 12
+    assert [p.perfect_units[k] for k in (1, 2, 3, 4, 40)] == [8, 4, 3, 2, 2]
+
+
+def test_jobs_are_plausible_on_simulated_repeats():
+    # sanity (not parity): most planted small-motif loci produce a job whose motif is a rotation of the planted one
+    from ribbit_amd.simulate import simulate_sequence
+    seq, truth = simulate_sequence(120_000, 9, 2, 8)
+    with Oracle(seq, 2, 8) as o:
+        o.run_all()
+        jobs, pool = o.refine_jobs()
+    motifs = ribbit_amd._jobs_with_motifs(jobs, pool)
+    hits = 0
+    for (ts, te, m, motif) in truth:
+        rots = {motif[i:] + motif[:i] for i in range(m)}
+        hits += any(int(j["query_start"]) < te and int(j["query_start"]) + int(j["query_length"]) > ts and mot in rots for j, mot in motifs)
+    assert hits >= 0.85 * len(truth), (hits, len(truth))
