@@ -24,8 +24,8 @@ CALL_DT = np.dtype([("pos", "<i4"), ("mlen", "<i4"), ("start", "<i4"), ("end", "
 def build(asan: bool = False) -> str:
     name = "libribbit_oracle_asan.so" if asan else "libribbit_oracle.so"
     path = os.path.join(_ORACLE_DIR, name)
-    src = os.path.join(_ORACLE_DIR, "ribbit_oracle.c")
-    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("ribbit_oracle.c", "ribbit_oracle_refine.cpp", "ribbit_oracle.h", "Makefile")]
+    if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR, path])
     return path
 
