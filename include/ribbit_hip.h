@@ -97,7 +97,7 @@ int ribbit_hip_load_record_device(RibbitHandle *h, const void *dev_ascii, int64_
 
 /*
  * Device hot loop of processShiftXORsPerfect (parse_perfect_shiftxor.cpp:173-223) without the
- * addSeed merge: all maximal runs with length >= min(cutoff, 16), sorted by (mlen, start).
+ * addSeed merge: all maximal runs with length >= min(cutoff, 32), sorted by (mlen, start).
  */
 int ribbit_hip_scan_perfect_runs(RibbitHandle *h, const RibbitRun **out, size_t *n);
 

@@ -125,9 +125,18 @@ template <typename EndKind>
 __device__ __forceinline__ void stage_events(const uint32_t (&S)[WORDS_PER_LANE], const uint32_t (&E)[WORDS_PER_LANE],
                                              uint32_t word0, uint32_t mlen, const EventSink &sink,
                                              volatile uint64_t *stage, int &staged, int lane, EndKind end_kind) {
+    // The caller reaches this on a rarely taken, wave-uniform branch.  hipcc otherwise speculates the
+    // popcounts and the DPP scan below into the caller's hot loop (45 of its 217 VALU ops); reading
+    // the bitmaps through an empty asm makes them opaque at this point and keeps the work here.
+    uint32_t Sv[WORDS_PER_LANE], Ev[WORDS_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < WORDS_PER_LANE; k++) {
+        Sv[k] = S[k]; Ev[k] = E[k];
+        asm volatile("" : "+v"(Sv[k]), "+v"(Ev[k]));
+    }
     int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < WORDS_PER_LANE; k++) cnt += __popc(S[k]) + __popc(E[k]);
+    for (int k = 0; k < WORDS_PER_LANE; k++) cnt += __popc(Sv[k]) + __popc(Ev[k]);
     const int incl = wave_inclusive_scan(cnt);
     const int total = __builtin_amdgcn_readlane(incl, 63);
     if (staged + total > EV_STAGE) sink_flush(sink, stage, staged, lane);
@@ -144,12 +153,12 @@ __device__ __forceinline__ void stage_events(const uint32_t (&S)[WORDS_PER_LANE]
     }
 #pragma unroll
     for (int k = 0; k < WORDS_PER_LANE; k++) {
-        uint32_t both = S[k] | E[k];
+        uint32_t both = Sv[k] | Ev[k];
         while (both) {
             const uint32_t b = (uint32_t)__builtin_ctz(both);
             both &= both - 1u;
             const uint32_t pos = ((word0 + (uint32_t)k) << 5) + b;
-            const uint32_t kind = ((S[k] >> b) & 1u) ? (uint32_t)EV_START : end_kind(k, b, pos);
+            const uint32_t kind = ((Sv[k] >> b) & 1u) ? (uint32_t)EV_START : end_kind(k, b, pos);
             const uint64_t e = ev_pack(pos, mlen, kind);
             if (direct) { if (idx < sink.region_cap) gdst[idx] = e; }
             else stage[idx] = e;
@@ -168,9 +177,9 @@ constexpr int LDS_EXTRA = 40;   // halo + shifted-operand words (supports shifts
 // For motif m the reference walks maximal runs of X_m ones over non-N bases.  With
 // Z = mismatch | brk those are maximal zero runs of Z.  The run-length cut-offs are
 // c1 = (m<=6 ? 12-m : m) for a run closed by a mismatch (:193) and >= c1 otherwise (:179),
-// so only runs of at least sp = min(c1, 16) zeros can matter; the host applies the exact
+// so only runs of at least sp = min(c1, 32) zeros can matter; the host applies the exact
 // cut-off.  Per lane and motif:
-//   D[p]  = OR of Z[p .. p+sp-1]          (3-4 OR-doubling funnel steps)
+//   D[p]  = OR of Z[p .. p+sp-1]          (3-5 OR-doubling funnel steps)
 //   START = Z[p-1] & ~D[p]                 run of >= sp zeros begins at p
 //   END   = Z[p]  & ~D[p-sp]               run of >= sp zeros ends just before p
 // Every qualifying run yields exactly one START and one END (position L for an open run,
@@ -234,9 +243,10 @@ __global__ __launch_bounds__(256) void scan_perfect_kernel(DevicePlanes pl, Perf
             for (int j = 0; j < K + 3; j++) { Hq[j] = s_hi[lb + j + q]; Lq[j] = s_lo[lb + j + q]; }
         }
         const int c1 = (m <= 6) ? 12 - m : m;
-        const int sp = min(c1, 16);
+        const int sp = min(c1, 32);
         const uint32_t t3 = (uint32_t)min(4, sp - 4);
-        const uint32_t t4 = (uint32_t)(sp - 4) - t3;
+        const uint32_t t4 = (uint32_t)min(8, sp - 4 - (int)t3);
+        const uint32_t t5 = (uint32_t)(sp - 4) - t3 - t4;
 
         // Z = mismatch | break, words k = -1 .. K
         uint32_t Z[K + 2], D[K + 2];
@@ -246,7 +256,18 @@ __global__ __launch_bounds__(256) void scan_perfect_kernel(DevicePlanes pl, Perf
             const uint32_t ls = funnel(Lq[j + 1], Lq[j], r);
             Z[j] = ((H[j] ^ hs) | (Lo[j] ^ ls)) | Bk[j];
         }
-        // OR-doubling towards higher positions: spans 2, 4, 4+t3, 4+t3+t4 = sp
+        // Cheap necessary condition before the doubling chain (which is ~2/3 of this loop's VALU ops):
+        // a run of >= 15 zeros covers an aligned byte completely, a run of >= 31 an aligned halfword.
+        // On random DNA 96 % of the (tile, motif) pairs with sp >= 15 have no all-zero byte at all.
+        if (sp >= 15) {
+            const uint32_t ones = sp >= 31 ? 0x00010001u : 0x01010101u;
+            const uint32_t tops = sp >= 31 ? 0x80008000u : 0x80808080u;
+            uint32_t hit = 0;
+#pragma unroll
+            for (int j = 0; j < K + 2; j++) hit |= (Z[j] - ones) & ~Z[j];
+            if (__ballot((hit & tops) != 0) == 0ull) continue;
+        }
+        // OR-doubling towards higher positions: spans 2, 4, 4+t3, 4+t3+t4, 4+t3+t4+t5 = sp
 #pragma unroll
         for (int j = 0; j < K + 1; j++) D[j] = Z[j] | funnel(Z[j + 1], Z[j], 1);
         D[K + 1] = Z[K + 1] | (Z[K + 1] >> 1);
@@ -258,6 +279,11 @@ __global__ __launch_bounds__(256) void scan_perfect_kernel(DevicePlanes pl, Perf
         D[K + 1] = D[K + 1] | (D[K + 1] >> t3);
 #pragma unroll
         for (int j = 0; j < K + 1; j++) D[j] = D[j] | funnel(D[j + 1], D[j], t4);
+        if (t5) {   // wave-uniform: only motifs with a cut-off above 16
+            D[K + 1] = D[K + 1] | (D[K + 1] >> t4);
+#pragma unroll
+            for (int j = 0; j < K + 1; j++) D[j] = D[j] | funnel(D[j + 1], D[j], t5);
+        }
 
         uint32_t SQ[K], EQ[K];
         uint32_t any = 0;

@@ -23,12 +23,12 @@ def _unpack(words, n):
 
 
 def _expected_runs(o, m_lo, m_hi):
-    """all maximal runs of X_m & ~N with length >= min(c1, 16), from the oracle's planes"""
+    """all maximal runs of X_m & ~N with length >= min(c1, 32), from the oracle's planes"""
     nmask = o.nmask()
     L = len(nmask)
     out = []
     for m in range(m_lo, m_hi + 1):
-        sp = min(12 - m if m <= 6 else m, 16)
+        sp = min(12 - m if m <= 6 else m, 32)
         y = o.plane(m) & (1 - nmask)
         for s, e in pyref.runs_of_ones(y):
             if e - s >= sp:
