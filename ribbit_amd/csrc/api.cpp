@@ -369,6 +369,76 @@ int advance_to_perfect(RibbitHandle *h) {
     return RIBBIT_OK;
 }
 
+// Replay of the per-motif window state machines over the indexed events, tile by tile, producing the
+// call list in the reference's call order (scan position major, motif minor, end-of-sequence flush
+// last) without a global sort: every tile's calls are generated motif by motif, pending groups are
+// settled as soon as their reporting window is known to precede the next tile, and the batch is
+// ordered with two stable counting sorts (motif, then position).  O(events + calls).
+int replay_window_events(RibbitHandle *h, uint32_t tile_bases, std::vector<RibbitCall> &calls) {
+    calls.clear();
+    const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
+    const int32_t m_lo = h->params.min_motif;
+    std::vector<rb::WindowFsm> fsm;
+    fsm.reserve(nm);
+    for (size_t mi = 0; mi < nm; ++mi) fsm.emplace_back(h->host, m_lo + (int32_t)mi);
+    struct Chunk { uint32_t off, n; };
+    const Chunk *table = reinterpret_cast<const Chunk *>(h->chunk_table.data());
+    const uint64_t *ev = h->h_events.p;
+    std::vector<RibbitCall> batch, by_motif, carry;
+    std::vector<uint32_t> count;
+    int64_t flushed_below = 0;   // every call with pos < flushed_below has been written to `calls`
+    for (size_t t = 0; t < h->table_ntile; ++t) {
+        const int64_t next_tile = (int64_t)(t + 1) * tile_bases;
+        batch.swap(carry);
+        carry.clear();
+        for (size_t mi = 0; mi < nm; ++mi) {
+            rb::WindowFsm &f = fsm[mi];
+            f.set_output(&batch);
+            const Chunk c = table[mi * h->table_ntile + t];
+            for (uint32_t i = c.off; i < c.off + c.n; ++i)
+                if (!f.event((int64_t)rb::ev_pos(ev[i]), rb::ev_kind(ev[i])))
+                    return fail(RIBBIT_E_INTERNAL, "window START/END events of motif %d do not alternate", m_lo + (int)mi);
+            f.settle_up_to(next_tile);
+        }
+        // calls generated from here on have pos >= next_tile + 7, so everything below next_tile is final
+        if (batch.empty()) { flushed_below = next_tile; continue; }
+        by_motif.resize(batch.size());
+        count.assign(nm + 1, 0);
+        for (const RibbitCall &c : batch) ++count[(size_t)(c.mlen - m_lo) + 1];
+        for (size_t k = 0; k < nm; ++k) count[k + 1] += count[k];
+        for (const RibbitCall &c : batch) by_motif[count[(size_t)(c.mlen - m_lo)]++] = c;
+        const int64_t span = next_tile - flushed_below;
+        count.assign((size_t)span + 2, 0);
+        for (const RibbitCall &c : by_motif) {
+            if (c.pos < flushed_below) return fail(RIBBIT_E_INTERNAL, "call generated out of order (pos %d)", c.pos);
+            if (c.pos < next_tile) ++count[(size_t)(c.pos - flushed_below) + 1];
+        }
+        for (int64_t k = 0; k < span; ++k) count[(size_t)k + 1] += count[(size_t)k];
+        const size_t base = calls.size();
+        calls.resize(base + count[(size_t)span]);
+        for (const RibbitCall &c : by_motif) {
+            if (c.pos < next_tile) calls[base + count[(size_t)(c.pos - flushed_below)]++] = c;
+            else carry.push_back(c);
+        }
+        flushed_below = next_tile;
+    }
+    // leftovers beyond the last tile boundary (pos up to L-1), then the end-of-sequence flush in motif order
+    std::stable_sort(carry.begin(), carry.end(), [](const RibbitCall &a, const RibbitCall &b) {
+        return a.pos != b.pos ? a.pos < b.pos : a.mlen < b.mlen;
+    });
+    calls.insert(calls.end(), carry.begin(), carry.end());
+    batch.clear();
+    for (size_t mi = 0; mi < nm; ++mi) {
+        fsm[mi].set_output(&batch);
+        if (!fsm[mi].finish()) return fail(RIBBIT_E_INTERNAL, "window event stream of motif %d ends inside a streak", m_lo + (int)mi);
+    }
+    std::stable_sort(batch.begin(), batch.end(), [](const RibbitCall &a, const RibbitCall &b) {
+        return a.pos != b.pos ? a.pos < b.pos : a.mlen < b.mlen;
+    });
+    calls.insert(calls.end(), batch.begin(), batch.end());
+    return RIBBIT_OK;
+}
+
 // window scan (1 mismatch) + per-motif state machine -> the addSeed call list of
 // processShiftXORswithSubstitutions (parse_substitute_shiftxor.cpp:430-574)
 int build_subst_calls(RibbitHandle *h) {
@@ -378,18 +448,23 @@ int build_subst_calls(RibbitHandle *h) {
     if (rc) return rc;
     if ((rc = collect_events(h, 1))) return rc;
     const double t0 = now_ms();
-    h->subst_calls.clear();
-    const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
-    for (size_t mi = 0; mi < nm; ++mi) {
-        const int32_t mlen = h->params.min_motif + (int32_t)mi;
-        rb::WindowFsm fsm(h->host, mlen, h->subst_calls);
-        bool ok = for_each_event(h, mi, [&](int64_t pos, uint32_t kind) { return fsm.event(pos, kind); });
-        if (!ok || !fsm.finish()) return fail(RIBBIT_E_INTERNAL, "window START/END events of motif %d do not alternate", mlen);
-    }
-    sort_calls(h->subst_calls);
+    if ((rc = replay_window_events(h, (uint32_t)rb::TILE_BASES, h->subst_calls))) return rc;
     h->host_ms = now_ms() - t0;
     h->subst_calls_valid = true;
     return RIBBIT_OK;
+}
+
+// Calls that fail the length filter only move the perfect-list cursor (parse_substitute_shiftxor.cpp:34-44);
+// their effect is folded into one advance with the running maximum of their ends (see advance_cursor).
+void replay_subst_calls(rb::SeedLists &lists, const RibbitCall *calls, size_t n) {
+    int from_index = 0;
+    int pending_end = -1;
+    for (size_t i = 0; i < n; ++i) {
+        const RibbitCall &c = calls[i];
+        if (c.end - c.start < rb::subst_seedlen_cutoff(c.mlen)) { pending_end = std::max(pending_end, c.end); continue; }
+        if (pending_end >= 0) { from_index = rb::advance_cursor(lists.perfect, from_index, pending_end); pending_end = -1; }
+        from_index = rb::subst_add(lists, c.start, c.end, c.mlen, from_index, RIBBIT_RANK_S);
+    }
 }
 
 int advance_to_subst(RibbitHandle *h) {
@@ -400,8 +475,7 @@ int advance_to_subst(RibbitHandle *h) {
     const rb::HostPlanes *hp = &h->host;
     h->lists.range_count = [hp](int shift, int start, int end) { return hp->range_count(shift, start, end); };
     h->lists.subst.clear();
-    int from_index = 0;
-    for (const RibbitCall &c : h->subst_calls) from_index = rb::subst_add(h->lists, c.start, c.end, c.mlen, from_index, RIBBIT_RANK_S);
+    replay_subst_calls(h->lists, h->subst_calls.data(), h->subst_calls.size());
     h->stage_done = STAGE_SUBST;
     return RIBBIT_OK;
 }
@@ -428,14 +502,7 @@ int build_anchored_calls(RibbitHandle *h) {
     HIP_TRY(hipMemcpyAsync(h->host.xa.data(), h->d_xa.p, nm * (size_t)h->xa_stride * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const double t0 = now_ms();
-    h->anchored_calls.clear();
-    for (size_t mi = 0; mi < nm; ++mi) {
-        const int32_t mlen = h->params.min_motif + (int32_t)mi;
-        rb::WindowFsm fsm(h->host, mlen, h->anchored_calls);
-        bool ok = for_each_event(h, mi, [&](int64_t pos, uint32_t kind) { return fsm.event(pos, kind); });
-        if (!ok || !fsm.finish()) return fail(RIBBIT_E_INTERNAL, "anchored START/END events of motif %d do not alternate", mlen);
-    }
-    sort_calls(h->anchored_calls);
+    if ((rc = replay_window_events(h, (uint32_t)rb::ATILE_BASES, h->anchored_calls))) return rc;
     h->host_ms = now_ms() - t0;
     h->anchored_calls_valid = true;
     return RIBBIT_OK;
@@ -447,12 +514,25 @@ int build_anchored_calls(RibbitHandle *h) {
 // (parse_anchored_shiftxor.cpp:713 vs :688,:697,:706,:717).
 void replay_anchored_calls(rb::SeedLists &lists, const std::vector<RibbitCall> &calls, int64_t length) {
     rb::Cursor2 cur;
+    int pending_end = -1;   // largest seed_end among in-loop calls that only moved the cursors (:133-153)
+    auto catch_up = [&]() {
+        if (pending_end < 0) return;
+        cur.perfect = rb::advance_cursor(lists.perfect, cur.perfect, pending_end);
+        cur.subst = rb::advance_cursor(lists.subst, cur.subst, pending_end);
+        pending_end = -1;
+    };
     for (size_t i = 0; i < calls.size(); ++i) {
         const RibbitCall &c = calls[i];
-        const rb::Cursor2 next = rb::anchored_add(lists, c.start, c.end, c.mlen, cur, RIBBIT_RANK_A);
         const bool flush = c.pos == (int32_t)length;
         const bool first_of_two = flush && i + 1 < calls.size() && calls[i + 1].pos == c.pos && calls[i + 1].mlen == c.mlen;
-        if (!flush || first_of_two) cur = next;
+        const bool keeps_cursor = !flush || first_of_two;
+        if (c.end - c.start < rb::anchored_seedlen_cutoff(c.mlen)) {
+            if (keeps_cursor) pending_end = std::max(pending_end, c.end);
+            continue;
+        }
+        catch_up();
+        const rb::Cursor2 next = rb::anchored_add(lists, c.start, c.end, c.mlen, cur, RIBBIT_RANK_A);
+        if (keeps_cursor) cur = next;
     }
 }
 
@@ -782,9 +862,7 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
     sl.min_shift = (params->min_motif > 2) ? params->min_motif - 2 : 1;
     sl.range_count = [&hp](int shift, int start, int end) { return hp.range_count(shift, start, end); };
     for (size_t i = 0; i < n_perfect_calls; ++i) rb::perfect_add(sl, perfect_calls[i].start, perfect_calls[i].end, perfect_calls[i].mlen);
-    int from_index = 0;
-    for (size_t i = 0; i < n_subst_calls; ++i)
-        from_index = rb::subst_add(sl, subst_calls[i].start, subst_calls[i].end, subst_calls[i].mlen, from_index, RIBBIT_RANK_S);
+    replay_subst_calls(sl, subst_calls, n_subst_calls);
     if (xa) {
         const size_t nm = (size_t)(params->max_motif - params->min_motif + 1);
         hp.xa.assign(xa, xa + nm * xa_stride);

@@ -31,6 +31,16 @@ inline int subst_seedlen_cutoff(int mlen) { return mlen > 30 ? mlen / 3 : 10; }
 // seedlen_cutoffs of processShiftXORsAnchored (parse_anchored_shiftxor.cpp:572-573)
 inline int anchored_seedlen_cutoff(int mlen) { return mlen >= 10 ? (int)(0.9 * mlen) : (mlen > 6 ? mlen : 10); }
 
+// The cursor loop that opens addSeedToSeedPositionsSubstitutions / ...Anchored
+// (parse_substitute_shiftxor.cpp:34-42): first index >= from whose start exceeds seed_end, capped at the
+// last element.  advance(advance(i, a), b) == advance(i, max(a, b)) for any list whose starts do not
+// change in between, so a run of calls that only move the cursor (they fail the length filter right
+// after this loop, :44) can be replaced by one advance with the largest seed_end among them.
+inline int advance_cursor(const std::vector<RibbitSeed> &list, int from, int seed_end) {
+    while ((size_t)from < list.size() && list[from].start <= seed_end && (size_t)from != list.size() - 1) ++from;
+    return from;
+}
+
 // addSeedToSeedPositionsSubstitutions, parse_substitute_shiftxor.cpp:18-388; returns the new cursor
 int subst_add(SeedLists &sl, int seed_start, int seed_end, int mlen, int from_index, int seed_type);
 
