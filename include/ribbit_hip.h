@@ -205,6 +205,23 @@ int ribbit_host_refine_jobs(const RibbitScanParams *params, const RibbitRefinePa
                             RibbitAlignJob **jobs, size_t *n_jobs, char **motif_pool, size_t *pool_len);
 void ribbit_refine_jobs_free(RibbitAlignJob *jobs, char *motif_pool);
 
+/*
+ * The alignment step of refinement: StripedSmithWaterman::Aligner().Align(query, ref, ref_len, Filter(),
+ * &alignment, mask_len) as called at parse_seed.cpp:404 and parse_smallmotif_seed.cpp:270 (default scores:
+ * match 2, mismatch 2, gap open 3, gap extend 1).  Own implementation with the library's exact results
+ * (scores, coordinates, CIGAR with = X I D S).  Host function, no GPU needed.  The CIGAR is written to
+ * cigar[0..cap) NUL-terminated; cigar_len receives its full length (> cap-1 means truncated).
+ */
+typedef struct RibbitAlignment {
+    int32_t sw_score, sw_score_next_best;
+    int32_t ref_begin, ref_end, query_begin, query_end, ref_end_next_best;
+    int32_t mismatches;
+    int32_t flag;        /* Align's return value */
+    int32_t cigar_len;
+} RibbitAlignment;
+int ribbit_ssw_align(const char *query, int32_t query_len, const char *ref, int32_t ref_len, int32_t mask_len,
+                     RibbitAlignment *out, char *cigar, size_t cap);
+
 /* How often the defined-divergence guards fired in the merges of this record (the
  * reference has undefined behaviour there; 0 on ordinary inputs). */
 int64_t ribbit_hip_guard_hits(const RibbitHandle *h);

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 __all__ = ["RibbitHipError", "ScanParams", "Scanner", "library_path", "load_library", "host_replay_calls", "pack_planes", "pack_bit_planes",
-           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs"]
+           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "ssw_align"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_anchored_calls", "ribbit_hip_seeds_anchored", "ribbit_hip_dispatch_seeds", "ribbit_hip_guard_hits",
     "ribbit_hip_debug_stream_read",
     "ribbit_refine_params_default", "ribbit_hip_seed_longest_runs", "ribbit_hip_refine_jobs",
-    "ribbit_host_refine_jobs", "ribbit_refine_jobs_free",
+    "ribbit_host_refine_jobs", "ribbit_refine_jobs_free", "ribbit_ssw_align",
 ]
 
 
@@ -58,6 +58,12 @@ class RefineParams(C.Structure):
     """RibbitRefineParams (MINIMUM_LENGTH / PERFECT_UNITS tables, purity, cones threshold)."""
     _fields_ = [("min_length", C.c_int32 * 1024), ("perfect_units", C.c_int32 * 1024),
                 ("purity_threshold", C.c_float), ("continuous_ones_threshold", C.c_int32)]
+
+
+class Alignment(C.Structure):
+    """RibbitAlignment (StripedSmithWaterman::Alignment without the strings)."""
+    _fields_ = [(n, C.c_int32) for n in ("sw_score", "sw_score_next_best", "ref_begin", "ref_end", "query_begin",
+                                         "query_end", "ref_end_next_best", "mismatches", "flag", "cigar_len")]
 
 
 class SeedLists(C.Structure):
@@ -122,6 +128,7 @@ def load_library():
                                           C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.ribbit_refine_jobs_free.restype = None
     L.ribbit_refine_jobs_free.argtypes = [vp, vp]
+    L.ribbit_ssw_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, C.POINTER(Alignment), C.c_char_p, C.c_size_t]
     L.ribbit_hip_debug_stream_read.argtypes = [vp, i64, C.POINTER(i64)]
     L.ribbit_hip_last_event_count.restype = i64
     L.ribbit_hip_last_event_count.argtypes = [vp]
@@ -191,6 +198,18 @@ def host_replay_calls(min_motif: int, max_motif: int, sequence: bytes, perfect_c
                 "guard_hits": int(out.guard_hits)}
     finally:
         L.ribbit_seed_lists_free(C.byref(out))
+
+
+def ssw_align(query: bytes, ref: bytes, ref_len: int | None = None, mask_len: int = 15):
+    """ribbit_ssw_align -> (dict of alignment fields, cigar string)"""
+    L = load_library()
+    out = Alignment()
+    cap = 16 * (len(query) + len(ref)) + 64
+    buf = C.create_string_buffer(cap)
+    rc = L.ribbit_ssw_align(query, len(query), ref, len(ref) if ref_len is None else ref_len, mask_len, C.byref(out), buf, cap)
+    if rc != 0:
+        raise RibbitHipError(f"ribbit_ssw_align error {rc}: {L.ribbit_hip_last_error().decode()}")
+    return {n: getattr(out, n) for n, _ in Alignment._fields_}, buf.value.decode()
 
 
 def _jobs_with_motifs(jobs, pool: bytes):

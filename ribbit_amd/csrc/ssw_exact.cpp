@@ -1,0 +1,347 @@
+// ssw_exact.cpp -- own implementation of the striped Smith-Waterman alignment ribbit's refinement
+// relies on (reference: the vendored Complete-Striped-Smith-Waterman-Library v1.2.5, ssw.c /
+// ssw_cpp.cpp, used through Aligner::Align at parse_seed.cpp:404 and parse_smallmotif_seed.cpp:270).
+//
+// BED rows carry the CIGAR, so the result has to be identical to the library's down to its
+// tie-breaks, and those depend on the striped evaluation order: the lazy-F loop
+// stops early and never refreshes E, so scores are a function of the 16-/8-lane striping.  This
+// file therefore evaluates the recurrences in exactly the library's striped order -- vector j,
+// lane l  <->  query position j + l*segLen -- with plain scalar lanes (no intrinsics; the compiler
+// vectorises the lane loops).  Written from the algorithm's description; no library code is used.
+// Pinned in tests/test_ssw.py against the reference library itself (oracle/_ref/libssw_ref.so).
+#include "ssw_exact.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace rb {
+
+namespace {
+
+constexpr int NSYM = 5;                    // A C G T other
+constexpr int MATCH = 2, MISMATCH = 2;     // Aligner(): match 2, mismatch 2, gap open 3, gap extend 1 (ssw_cpp.cpp:230-242)
+constexpr int GAP_OPEN = 3, GAP_EXTEND = 1;
+constexpr int DISTANCE_FILTER = 32767;     // Filter(): score_filter 0, distance_filter 32767 (ssw_cpp.h:58-63)
+
+inline int8_t score_of(int a, int b) { return (a == b && a < 4) ? MATCH : -MISMATCH; }
+
+inline int8_t translate(char c) {          // kBaseTranslation, ssw_cpp.cpp:12-27
+    switch (c) {
+        case 'A': case 'a': case 'U': case 'u': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return 4;
+    }
+}
+
+struct Ends { int score, ref, read, score2, ref2; };
+
+inline uint8_t sat_add_u8(uint8_t a, uint8_t b) { const int s = a + b; return (uint8_t)(s > 255 ? 255 : s); }
+inline uint8_t sat_sub_u8(uint8_t a, uint8_t b) { return (uint8_t)(a > b ? a - b : 0); }
+inline int16_t sat_add_i16(int16_t a, int16_t b) { const int s = a + b; return (int16_t)(s > 32767 ? 32767 : (s < -32768 ? -32768 : s)); }
+inline int16_t sat_sub_u16(int16_t a, int16_t b) {     // _mm_subs_epu16 on the bit patterns
+    const uint16_t x = (uint16_t)a, y = (uint16_t)b;
+    return (int16_t)(uint16_t)(x > y ? x - y : 0);
+}
+
+// 8-bit striped pass (ssw.c:197-386).  dir 0: ref left to right, 1: right to left.
+// Returns score 255 when the byte range overflowed (the caller then switches to 16 bits).
+Ends striped_pass_u8(const int8_t *ref, int dir, int ref_len, const int8_t *read, int read_len, int terminate, int mask_len) {
+    constexpr int W = 16;
+    const uint8_t bias = MISMATCH, gap_o = GAP_OPEN, gap_e = GAP_EXTEND;
+    const int seg = (read_len + W - 1) / W;
+    std::vector<uint8_t> profile((size_t)NSYM * seg * W);
+    for (int nt = 0; nt < NSYM; ++nt)
+        for (int j = 0; j < seg; ++j)
+            for (int l = 0; l < W; ++l) {
+                const int q = j + l * seg;
+                profile[((size_t)nt * seg + j) * W + l] = (uint8_t)(q >= read_len ? bias : score_of(nt, read[q]) + bias);
+            }
+    std::vector<uint8_t> buf_a((size_t)seg * W, 0), buf_b((size_t)seg * W, 0), E((size_t)seg * W, 0), h_best((size_t)seg * W, 0);
+    std::vector<uint8_t> col_max((size_t)ref_len, 0);
+    uint8_t *h_store = buf_a.data(), *h_load = buf_b.data();
+    uint8_t run_max[W] = {0}, run_mark[W] = {0};
+    int best = 0, end_ref = -1;
+    const int begin = dir ? ref_len - 1 : 0, stop = dir ? -1 : ref_len, step = dir ? -1 : 1;
+    for (int i = begin; i != stop; i += step) {
+        uint8_t F[W] = {0}, cmax[W] = {0}, H[W];
+        H[0] = 0;
+        for (int l = 1; l < W; ++l) H[l] = h_store[(size_t)(seg - 1) * W + l - 1];   // last vector shifted up one lane
+        const uint8_t *P = &profile[(size_t)ref[i] * seg * W];
+        std::swap(h_store, h_load);
+        for (int j = 0; j < seg; ++j) {
+            uint8_t *e = &E[(size_t)j * W], *hs = &h_store[(size_t)j * W];
+            const uint8_t *hl = &h_load[(size_t)j * W], *p = P + (size_t)j * W;
+            for (int l = 0; l < W; ++l) {
+                uint8_t h = sat_sub_u8(sat_add_u8(H[l], p[l]), bias);
+                h = std::max(h, e[l]);
+                h = std::max(h, F[l]);
+                cmax[l] = std::max(cmax[l], h);
+                hs[l] = h;
+                h = sat_sub_u8(h, gap_o);
+                e[l] = std::max(sat_sub_u8(e[l], gap_e), h);
+                F[l] = std::max(sat_sub_u8(F[l], gap_e), h);
+                H[l] = hl[l];
+            }
+        }
+        // lazy F: propagate F across the lane boundary until it can no longer raise any H
+        bool settled = false;
+        for (int k = 0; k < W && !settled; ++k) {
+            for (int l = W - 1; l > 0; --l) F[l] = F[l - 1];
+            F[0] = 0;
+            for (int j = 0; j < seg && !settled; ++j) {
+                uint8_t *hs = &h_store[(size_t)j * W];
+                bool none = true;
+                for (int l = 0; l < W; ++l) {
+                    const uint8_t h = std::max(hs[l], F[l]);
+                    cmax[l] = std::max(cmax[l], h);
+                    hs[l] = h;
+                    F[l] = sat_sub_u8(F[l], gap_e);
+                    if (sat_sub_u8(F[l], sat_sub_u8(h, gap_o)) != 0) none = false;
+                }
+                settled = none;
+            }
+        }
+        bool changed = false;
+        for (int l = 0; l < W; ++l) { run_max[l] = std::max(run_max[l], cmax[l]); changed |= run_max[l] != run_mark[l]; }
+        if (changed) {
+            std::memcpy(run_mark, run_max, W);
+            const int top = *std::max_element(run_max, run_max + W);
+            if (top > best) {
+                best = top;
+                if (best + bias >= 255) break;
+                end_ref = i;
+                std::memcpy(h_best.data(), h_store, (size_t)seg * W);
+            }
+        }
+        col_max[(size_t)i] = *std::max_element(cmax, cmax + W);
+        if (col_max[(size_t)i] == (uint8_t)terminate) break;
+    }
+    int end_read = read_len - 1;
+    for (int idx = 0; idx < seg * W; ++idx)
+        if (h_best[(size_t)idx] == best) end_read = std::min(end_read, idx / W + idx % W * seg);
+    Ends r{best + bias >= 255 ? 255 : best, end_ref, end_read, 0, 0};
+    int edge = std::max(end_ref - mask_len, 0);
+    for (int i = 0; i < edge; ++i) if (col_max[(size_t)i] > r.score2) { r.score2 = col_max[(size_t)i]; r.ref2 = i; }
+    edge = std::min(end_ref + mask_len, ref_len);
+    for (int i = edge + 1; i < ref_len; ++i) if (col_max[(size_t)i] > r.score2) { r.score2 = col_max[(size_t)i]; r.ref2 = i; }
+    return r;
+}
+
+// 16-bit striped pass (ssw.c:412-588): signed add / max, unsigned saturating subtract.
+Ends striped_pass_i16(const int8_t *ref, int dir, int ref_len, const int8_t *read, int read_len, int terminate, int mask_len) {
+    constexpr int W = 8;
+    const int16_t gap_o = GAP_OPEN, gap_e = GAP_EXTEND;
+    const int seg = (read_len + W - 1) / W;
+    std::vector<int16_t> profile((size_t)NSYM * seg * W);
+    for (int nt = 0; nt < NSYM; ++nt)
+        for (int j = 0; j < seg; ++j)
+            for (int l = 0; l < W; ++l) {
+                const int q = j + l * seg;
+                profile[((size_t)nt * seg + j) * W + l] = (int16_t)(q >= read_len ? 0 : score_of(nt, read[q]));
+            }
+    std::vector<int16_t> buf_a((size_t)seg * W, 0), buf_b((size_t)seg * W, 0), E((size_t)seg * W, 0), h_best((size_t)seg * W, 0);
+    std::vector<uint16_t> col_max((size_t)ref_len, 0);
+    int16_t *h_store = buf_a.data(), *h_load = buf_b.data();
+    int16_t run_max[W] = {0}, run_mark[W] = {0};
+    int best = 0, end_ref = 0;
+    const int begin = dir ? ref_len - 1 : 0, stop = dir ? -1 : ref_len, step = dir ? -1 : 1;
+    for (int i = begin; i != stop; i += step) {
+        int16_t F[W] = {0}, cmax[W] = {0}, H[W];
+        H[0] = 0;
+        for (int l = 1; l < W; ++l) H[l] = h_store[(size_t)(seg - 1) * W + l - 1];
+        const int16_t *P = &profile[(size_t)ref[i] * seg * W];
+        std::swap(h_store, h_load);
+        for (int j = 0; j < seg; ++j) {
+            int16_t *e = &E[(size_t)j * W], *hs = &h_store[(size_t)j * W];
+            const int16_t *hl = &h_load[(size_t)j * W], *p = P + (size_t)j * W;
+            for (int l = 0; l < W; ++l) {
+                int16_t h = sat_add_i16(H[l], p[l]);
+                h = std::max(h, e[l]);
+                h = std::max(h, F[l]);
+                cmax[l] = std::max(cmax[l], h);
+                hs[l] = h;
+                h = sat_sub_u16(h, gap_o);
+                e[l] = std::max(sat_sub_u16(e[l], gap_e), h);
+                F[l] = std::max(sat_sub_u16(F[l], gap_e), h);
+                H[l] = hl[l];
+            }
+        }
+        bool settled = false;
+        for (int k = 0; k < W && !settled; ++k) {
+            for (int l = W - 1; l > 0; --l) F[l] = F[l - 1];
+            F[0] = 0;
+            for (int j = 0; j < seg && !settled; ++j) {
+                int16_t *hs = &h_store[(size_t)j * W];
+                bool none = true;
+                for (int l = 0; l < W; ++l) {
+                    const int16_t h = std::max(hs[l], F[l]);
+                    cmax[l] = std::max(cmax[l], h);
+                    hs[l] = h;
+                    F[l] = sat_sub_u16(F[l], gap_e);
+                    if (F[l] > sat_sub_u16(h, gap_o)) none = false;
+                }
+                settled = none;
+            }
+        }
+        bool changed = false;
+        for (int l = 0; l < W; ++l) { run_max[l] = std::max(run_max[l], cmax[l]); changed |= run_max[l] != run_mark[l]; }
+        if (changed) {
+            std::memcpy(run_mark, run_max, sizeof run_max);
+            const int top = (uint16_t)*std::max_element(run_max, run_max + W);
+            if (top > best) {
+                best = top;
+                end_ref = i;
+                std::memcpy(h_best.data(), h_store, (size_t)seg * W * sizeof(int16_t));
+            }
+        }
+        col_max[(size_t)i] = (uint16_t)*std::max_element(cmax, cmax + W);
+        if (col_max[(size_t)i] == (uint16_t)terminate) break;
+    }
+    int end_read = read_len - 1;
+    for (int idx = 0; idx < seg * W; ++idx)
+        if ((uint16_t)h_best[(size_t)idx] == (uint16_t)best) end_read = std::min(end_read, idx / W + idx % W * seg);
+    Ends r{best, end_ref, end_read, 0, 0};
+    int edge = std::max(end_ref - mask_len, 0);
+    for (int i = 0; i < edge; ++i) if (col_max[(size_t)i] > r.score2) { r.score2 = col_max[(size_t)i]; r.ref2 = i; }
+    edge = std::min(end_ref + mask_len, ref_len);
+    for (int i = edge; i < ref_len; ++i) if (col_max[(size_t)i] > r.score2) { r.score2 = col_max[(size_t)i]; r.ref2 = i; }
+    return r;
+}
+
+struct Op { char op; int len; };
+
+// Banded global-ish alignment with traceback between the located end points (ssw.c:590-775).  The band
+// doubles until the banded score reaches the striped score.  Returns false on a traceback error.
+bool banded_traceback(const int8_t *ref, const int8_t *read, int ref_len, int read_len, int score, int band, std::vector<Op> &out) {
+    const int len = std::max(ref_len, read_len);
+    std::vector<int32_t> h_b, e_b, h_c;
+    std::vector<int8_t> dir;
+    int best = 0, width = 0, width_d = 0;
+    auto col_u = [](int w, int i, int j) { const int x = std::max(i - w, 0); return j - x + 1; };
+    auto col_d = [](int w, int i, int j, int p) { const int x = std::max(i - w, 0); return (j - x) * 3 + p; };
+    do {
+        width = band * 2 + 3; width_d = band * 2 + 1;
+        h_b.assign((size_t)width + 1, 0); e_b.assign((size_t)width + 1, 0); h_c.assign((size_t)width + 1, 0);
+        dir.assign((size_t)width_d * read_len * 3 + 3, 0);
+        for (int i = 0; i < read_len; ++i) {
+            const int beg = std::max(0, i - band), end = std::min(ref_len - 1, i + band);
+            const int edge = std::min(end + 1, width - 1);
+            int f = 0, u = 0;
+            h_b[0] = e_b[0] = h_b[(size_t)edge] = e_b[(size_t)edge] = h_c[0] = 0;
+            int8_t *line = dir.data() + (size_t)width_d * i * 3;
+            for (int j = beg; j <= end; ++j) {
+                u = col_u(band, i, j);
+                const int e = col_u(band, i - 1, j), b = col_u(band, i, j - 1), d = col_u(band, i - 1, j - 1);
+                const int de = col_d(band, i, j, 0), df = col_d(band, i, j, 1), dh = col_d(band, i, j, 2);
+                int t1 = i == 0 ? -GAP_OPEN : h_b[(size_t)e] - GAP_OPEN;
+                int t2 = i == 0 ? -GAP_EXTEND : e_b[(size_t)e] - GAP_EXTEND;
+                e_b[(size_t)u] = std::max(t1, t2);
+                line[de] = t1 > t2 ? 3 : 2;
+                t1 = h_c[(size_t)b] - GAP_OPEN;
+                t2 = f - GAP_EXTEND;
+                f = std::max(t1, t2);
+                line[df] = t1 > t2 ? 5 : 4;
+                const int e1 = std::max(e_b[(size_t)u], 0), f1 = std::max(f, 0);
+                t1 = std::max(e1, f1);
+                t2 = h_b[(size_t)d] + score_of(ref[j], read[i]);
+                h_c[(size_t)u] = std::max(t1, t2);
+                best = std::max(best, h_c[(size_t)u]);
+                line[dh] = t1 <= t2 ? 1 : (e1 > f1 ? line[de] : line[df]);
+            }
+            for (int j = 1; j <= u; ++j) h_b[(size_t)j] = h_c[(size_t)j];
+        }
+        band *= 2;
+    } while (best < score && band <= len);
+    band /= 2;
+
+    std::vector<Op> rev;
+    int i = read_len - 1, j = ref_len - 1, count = 0, state = 2;
+    char op = 'M', prev = 'M';
+    const int8_t *line = dir.data() + (size_t)width_d * (read_len - 1) * 3;
+    while (i >= 0 && j > 0) {
+        switch (line[col_d(band, i, j, state)]) {
+            case 1: --i; --j; state = 2; line -= width_d * 3; op = 'M'; break;
+            case 2: --i; state = 0; line -= width_d * 3; op = 'I'; break;
+            case 3: --i; state = 2; line -= width_d * 3; op = 'I'; break;
+            case 4: --j; state = 1; op = 'D'; break;
+            case 5: --j; state = 2; op = 'D'; break;
+            default: return false;
+        }
+        if (op == prev) ++count;
+        else { rev.push_back({prev, count}); prev = op; count = 1; }
+    }
+    if (op == 'M') rev.push_back({op, count + 1});
+    else { rev.push_back({op, count}); rev.push_back({'M', 1}); }
+    out.assign(rev.rbegin(), rev.rend());
+    return true;
+}
+
+}  // namespace
+
+void ssw_align(const char *query, int query_len, const char *ref, int ref_len, int mask_len, SswResult &out) {
+    out = SswResult{};
+    out.ref_begin = -1; out.query_begin = -1;
+    if (query_len <= 0) { out.skipped = true; return; }     // Aligner::Align returns before touching `alignment`
+    std::vector<int8_t> q((size_t)query_len), r((size_t)std::max(ref_len, 1));
+    for (int i = 0; i < query_len; ++i) q[(size_t)i] = translate(query[i]);
+    for (int i = 0; i < ref_len; ++i) r[(size_t)i] = translate(ref[i]);
+
+    // forward pass: 8-bit first, 16-bit when it saturates (ssw.c:843-860)
+    bool wide = false;
+    Ends fwd = striped_pass_u8(r.data(), 0, ref_len, q.data(), query_len, 255, mask_len);
+    if (fwd.score == 255) { fwd = striped_pass_i16(r.data(), 0, ref_len, q.data(), query_len, 0xffff, mask_len); wide = true; }
+    out.score = fwd.score; out.ref_end = fwd.ref; out.query_end = fwd.read;
+    if (mask_len >= 15) { out.score2 = fwd.score2; out.ref_end2 = fwd.ref2; } else { out.score2 = 0; out.ref_end2 = -1; }
+
+    if (out.score == 0 || out.ref_end < 0) {
+        // nothing aligned at all.  The library would go on to read ref[-1] here (undefined behaviour);
+        // defined instead as "no alignment": begin positions stay -1, the CIGAR is one soft clip.
+        out.cigar = std::to_string(query_len) + "S";
+        out.ref_end = -1;
+        return;
+    }
+    // reverse pass from the end point locates the beginning (ssw.c:874-891)
+    std::vector<int8_t> q_rev(q.begin(), q.begin() + out.query_end + 1);
+    std::reverse(q_rev.begin(), q_rev.end());
+    const Ends rev = wide ? striped_pass_i16(r.data(), 1, out.ref_end + 1, q_rev.data(), out.query_end + 1, out.score, mask_len)
+                          : striped_pass_u8(r.data(), 1, out.ref_end + 1, q_rev.data(), out.query_end + 1, out.score, mask_len);
+    out.ref_begin = rev.ref;
+    out.query_begin = out.query_end - rev.read;
+    if (out.score > rev.score) out.flag = 2;
+
+    std::vector<Op> path;
+    const bool too_far = out.ref_end - out.ref_begin > DISTANCE_FILTER || out.query_end - out.query_begin > DISTANCE_FILTER;
+    if (!too_far) {
+        const int rl = out.ref_end - out.ref_begin + 1, ql = out.query_end - out.query_begin + 1;
+        if (!banded_traceback(r.data() + out.ref_begin, q.data() + out.query_begin, rl, ql, out.score, std::abs(rl - ql) + 1, path)) {
+            out.flag = 1;
+            path.clear();
+        }
+    }
+
+    // CIGAR with '=' / 'X' and soft clips, mismatch count (ssw_cpp.cpp:126-207)
+    std::string &c = out.cigar;
+    auto put = [&](int n, char op) { c += std::to_string(n); c += op; };
+    if (out.query_begin > 0) put(out.query_begin, 'S');
+    const int8_t *rp = r.data() + out.ref_begin, *qp = q.data() + out.query_begin;
+    int run_eq = 0, run_x = 0;
+    auto close_run = [&]() { if (run_eq) put(run_eq, '='); else if (run_x) put(run_x, 'X'); run_eq = run_x = 0; };
+    for (const Op &o : path) {
+        if (o.op == 'M') {
+            for (int k = 0; k < o.len; ++k, ++rp, ++qp) {
+                if (*rp != *qp) { ++out.mismatches; if (run_eq) put(run_eq, '='); run_eq = 0; ++run_x; }
+                else { if (run_x) put(run_x, 'X'); run_x = 0; ++run_eq; }
+            }
+        } else if (o.op == 'I') { qp += o.len; out.mismatches += o.len; close_run(); put(o.len, 'I'); }
+        else if (o.op == 'D') { rp += o.len; out.mismatches += o.len; close_run(); put(o.len, 'D'); }
+    }
+    close_run();
+    const int tail = query_len - out.query_end - 1;
+    if (tail > 0) put(tail, 'S');
+}
+
+}  // namespace rb

@@ -1,0 +1,114 @@
+"""The product's own striped Smith-Waterman (ribbit_amd/csrc/ssw_exact.cpp) against the REFERENCE
+library itself: oracle/_ref/libssw_ref.so is compiled from the reference's vendored ssw.c / ssw_cpp.cpp
+(the only reference code that builds here) and driven through its public Aligner API by
+oracle/ssw_ref_shim.cpp.  This row (f1, alignment) is therefore pinned to real reference outputs."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import ribbit_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libssw_ref.so")
+pytestmark = pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libssw_ref.so not built (needs /root/reference at build time)")
+
+
+class RefResult(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("sw_score", "sw_score_next_best", "ref_begin", "ref_end", "query_begin", "query_end",
+                                         "ref_end_next_best", "mismatches", "flag", "cigar_len")]
+
+
+_ref = None
+
+
+def ref_align(query: bytes, ref: bytes, ref_len=None, mask_len=15):
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(REF_SO)
+        _ref.ref_ssw_align.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(RefResult), C.c_char_p, C.c_int]
+    out = RefResult()
+    cap = 16 * (len(query) + len(ref)) + 64
+    buf = C.create_string_buffer(cap)
+    _ref.ref_ssw_align(query, ref, len(ref) if ref_len is None else ref_len, mask_len, C.byref(out), buf, cap)
+    return {n: getattr(out, n) for n, _ in RefResult._fields_}, buf.value.decode()
+
+
+def _check(query, ref, ref_len=None):
+    want, wc = ref_align(query, ref, ref_len)
+    got, gc = ribbit_amd.ssw_align(query, ref, ref_len)
+    assert gc == wc, (query, ref, ref_len, gc, wc)
+    assert got == want, (query, ref, ref_len, got, want)
+
+
+def _rand(rs, n, alphabet=b"ACGT"):
+    return bytes(np.frombuffer(alphabet, dtype=np.uint8)[rs.randint(0, len(alphabet), size=n)])
+
+
+def _mutate(rs, s: bytes, rate: float) -> bytes:
+    out = bytearray()
+    for c in s:
+        r = rs.random_sample()
+        if r < rate * 0.8:
+            out.append(rs.choice([x for x in b"ACGT" if x != c]))
+        elif r < rate * 0.9:
+            out.append(c); out.append(b"ACGT"[rs.randint(0, 4)])
+        elif r < rate:
+            pass
+        else:
+            out.append(c)
+    return bytes(out)
+
+
+def test_simple_cases():
+    _check(b"ACGTACGTACGT", b"ACGTACGTACGTACGT")
+    _check(b"AAAAAAAAAA", b"AAAAAAAAAAAAAAA")
+    _check(b"ACGT", b"TTTTACGTTTTT")
+    _check(b"ACGTTTACGT", b"ACGTACGT" * 3)
+    _check(b"GATTACA", b"GATTTACAGATTACA")
+    _check(b"CAGCAGCAGCTGCAGCAG", b"CAG" * 9)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_repeat_like_jobs_match_reference(seed):
+    # the shape ribbit produces: query = an impure tandem repeat, reference = the pure motif repeated past ppr_length
+    rs = np.random.RandomState(100 + seed)
+    for _ in range(120):
+        m = int(rs.randint(1, 30))
+        motif = _rand(rs, m)
+        units = int(rs.randint(2, 40))
+        rot = int(rs.randint(0, m))
+        pure = (motif * (units + 2))[rot:rot + m * units + int(rs.randint(0, m))]
+        query = _mutate(rs, pure, float(rs.choice([0.0, 0.03, 0.1, 0.2])))
+        if not query:
+            continue
+        ppr_len = len(query) + m + int(0.15 * len(query))
+        ref = motif * (ppr_len // m + 2)
+        _check(query, ref, ppr_len)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_pairs_match_reference(seed):
+    rs = np.random.RandomState(500 + seed)
+    for _ in range(150):
+        q = _rand(rs, int(rs.randint(1, 120)), b"ACGTN" if rs.random_sample() < 0.2 else b"ACGT")
+        r = _rand(rs, int(rs.randint(1, 200)))
+        _check(q, r)
+
+
+def test_long_alignments_take_the_16bit_path():
+    rs = np.random.RandomState(7)
+    for n in (130, 200, 600, 2500):
+        motif = _rand(rs, int(rs.randint(2, 12)))
+        pure = (motif * (n // len(motif) + 2))[:n]
+        query = _mutate(rs, pure, 0.05)
+        ppr_len = len(query) + len(motif) + int(0.15 * len(query))
+        _check(query, motif * (ppr_len // len(motif) + 2), ppr_len)      # scores > 255
+    q = _rand(rs, 3000)
+    _check(q, _mutate(rs, q, 0.1))
+
+
+def test_lowercase_and_unknown_bases():
+    _check(b"acgtacgtnnacgt", b"ACGTACGTACGTACGT")
+    _check(b"ACGTRYACGT", b"ACGTACGTACGT")
