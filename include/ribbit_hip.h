@@ -222,6 +222,23 @@ typedef struct RibbitAlignment {
 int ribbit_ssw_align(const char *query, int32_t query_len, const char *ref, int32_t ref_len, int32_t mask_len,
                      RibbitAlignment *out, char *cigar, size_t cap);
 
+/*
+ * The rest of processSequence (fasta_utils.cpp:211-242): processSeedMotifWise (parse_smallmotif_seed.cpp:190-288)
+ * / processSeed (parse_seed.cpp:318-464) for every dispatched seed -- motif discovery, alignment
+ * (ribbit_ssw_align), processCIGARMotifWise / processCIGARWithPruning (process_cigar.cpp:126-336),
+ * calculateMotifUnits, the recursion on flanks -- and the BED rows they print (11 tab-separated columns,
+ * parse_seed.cpp:434-436).  *text points at handle-owned memory holding the rows of this record.
+ */
+int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const char *sequence_id,
+                          const char **text, size_t *len);
+
+/* Host-only variant (no GPU); *text is malloc'ed, release with ribbit_text_free(). */
+int ribbit_host_refine_bed(const RibbitScanParams *params, const RibbitRefineParams *prm, const char *sequence, int64_t length,
+                           const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
+                           const uint32_t *xa, size_t xa_stride, const RibbitSeed *dispatch, size_t n_dispatch,
+                           const char *sequence_id, char **text, size_t *len);
+void ribbit_text_free(char *text);
+
 /* How often the defined-divergence guards fired in the merges of this record (the
  * reference has undefined behaviour there; 0 on ordinary inputs). */
 int64_t ribbit_hip_guard_hits(const RibbitHandle *h);

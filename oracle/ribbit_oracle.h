@@ -100,6 +100,11 @@ void rbo_refine_params_default(rbo_refine_params_t *p, int m_lo, int m_hi);
 /* needs rbo_run_dispatch() to have run; arrays stay valid until the next call */
 int64_t rbo_refine_jobs(rbo_ctx *c, const rbo_refine_params_t *prm, const rbo_job_t **jobs, const char **pool);
 
+/* Rows f1/f4: the BED text processSequence writes for this record (fasta_utils.cpp:187-242 ->
+ * processSeedMotifWise / processSeed).  Alignments are computed by the REFERENCE's own SSW
+ * (oracle/_ref/libssw_ref.so); everything around them is restated.  seq = the record's bases. */
+const char *rbo_refine_bed(rbo_ctx *c, const rbo_refine_params_t *prm, const char *seq, const char *seq_id, int64_t *len);
+
 #ifdef __cplusplus
 }
 #endif

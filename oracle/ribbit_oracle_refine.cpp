@@ -17,9 +17,13 @@
  *       bases); the reference then calls string::substr with a huge offset and terminates.  The job is
  *       reported with the negative start as computed; consumers must clamp.
  */
+#include <dlfcn.h>
+
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sstream>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -309,6 +313,266 @@ int64_t rbo_refine_jobs(rbo_ctx *c, const rbo_refine_params_t *prm, const rbo_jo
     *jobs = store.jobs.data();
     *pool = store.pool.data();
     return (int64_t)store.jobs.size();
+}
+
+}  // extern "C"
+
+/* ===================================================================================================
+ * Rows f1 / f4: alignment, CIGAR processing and BED rows.  The alignment itself is NOT restated here:
+ * the oracle calls the reference's own vendored SSW, compiled from /root/reference into
+ * oracle/_ref/libssw_ref.so (entry point ref_ssw_align, oracle/ssw_ref_shim.cpp).
+ * =================================================================================================== */
+namespace {
+
+struct ref_ssw_result {
+    int32_t sw_score, sw_score_next_best, ref_begin, ref_end, query_begin, query_end, ref_end_next_best, mismatches;
+    int32_t flag, cigar_len;
+};
+typedef int (*ref_ssw_fn)(const char *, const char *, int, int, ref_ssw_result *, char *, int);
+
+ref_ssw_fn load_ref_ssw() {
+    static ref_ssw_fn fn = nullptr;
+    if (fn) return fn;
+    Dl_info info;
+    std::string dir = ".";
+    if (dladdr((void *)&load_ref_ssw, &info) && info.dli_fname) {
+        dir = info.dli_fname;
+        dir = dir.substr(0, dir.find_last_of('/'));
+    }
+    void *h = dlopen((dir + "/_ref/libssw_ref.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) return nullptr;
+    fn = (ref_ssw_fn)dlsym(h, "ref_ssw_align");
+    return fn;
+}
+
+/* Aligner().Align(query, ref, ref_len, Filter(), &alignment, 15) -> alignment.cigar_string.
+ * An empty query makes Align return before touching `alignment` (ssw_cpp.cpp:365): the caller then sees the
+ * previous call's CIGAR; `stale` carries it. */
+std::string align_cigar(const std::string &query, const std::string &ref, int ref_len, std::string &stale) {
+    if (query.empty()) return stale;
+    ref_ssw_fn fn = load_ref_ssw();
+    if (!fn) { std::fprintf(stderr, "oracle: oracle/_ref/libssw_ref.so is missing\n"); std::abort(); }
+    ref_ssw_result r;
+    std::vector<char> buf(16 * (query.size() + ref.size()) + 64);
+    fn(query.c_str(), ref.c_str(), ref_len, 15, &r, buf.data(), (int)buf.size());
+    stale = buf.data();
+    return stale;
+}
+
+/* cigarSplit, process_cigar.cpp:14-31 */
+void cigar_split(const std::string &cigar, std::vector<int> &lens, std::vector<char> &ops) {
+    std::string num;
+    for (char ch : cigar) {
+        if (ch >= '0' && ch <= '9') num += ch;
+        else { lens.push_back(num.empty() ? 0 : std::stoi(num)); ops.push_back(ch); num.clear(); }
+    }
+}
+
+/* calculateTrimEdges (float overload), process_cigar.cpp:34-86; purity and alignment_length are in/out.
+ * D5: the reference's loop bound is computed in size_t and can wrap when every trim combination is
+ * exhausted; signed arithmetic here (unreachable for CIGARs that start and end with a match block). */
+std::pair<int, int> trim_edges(float threshold, float &purity, const std::vector<int> &cc, int &alignment_length, int min_len) {
+    int trim = 0;
+    std::pair<int, int> edges(0, 0);
+    const long n = (long)cc.size();
+    while (purity < threshold) {
+        trim += 1;
+        float max_purity = 0; int max_alen = 0;
+        for (int i = 0; i <= trim; i++) {
+            int pm = 0, pa = 0;
+            for (long j = 2L * i; j <= (n - 1) - 2L * (trim - i); j++) {
+                if (j % 2 == 0) pm += cc[(size_t)j];
+                pa += cc[(size_t)j];
+            }
+            const float pp = float(pm) / float(pa);
+            if (pp >= threshold && max_alen < pa) { max_purity = pp; max_alen = pa; edges = {i, trim - i}; }
+        }
+        if (max_purity > purity) { purity = max_purity; alignment_length = max_alen; }
+        if (alignment_length < min_len) break;
+        if (2L * trim > n + 2) break;     /* D5 guard */
+    }
+    return edges;
+}
+
+struct Processed { int repeat_start, repeat_end, alignment_length, match_units; std::string cigar; float purity; };
+
+/* processCIGARMotifWise (process_cigar.cpp:254-336) and, with prune, processCIGARWithPruning (:126-251) */
+Processed process_cigar(int seed_start, int seed_sequence_length, const std::string &cigar, int motif_length, bool prune,
+                        const rbo_refine_params_t &prm) {
+    std::vector<int> lens; std::vector<char> ops;
+    cigar_split(cigar, lens, ops);
+    int repeat_start = seed_start, repeat_end = seed_start + seed_sequence_length, alignment_length = 0;
+    int matches = 0, match_units = 0, start_soft_clip = 0;
+    std::vector<int> cc_idx, cc_len;
+    bool mismatch_continue = false;
+    std::string new_cigar;
+    for (size_t c = 0; c < lens.size(); c++) {
+        const int len = lens[c]; const char op = ops[c];
+        switch (op) {
+            case 'S':
+                if (c == 0) { repeat_start += len; start_soft_clip = len; } else repeat_end -= len;
+                break;
+            case 'X': case 'I': case 'D':
+                alignment_length += len;
+                if (mismatch_continue) cc_len.back() += len; else cc_len.push_back(len);
+                cc_idx.push_back((int)cc_len.size() - 1);
+                mismatch_continue = true; new_cigar += std::to_string(len) + op;
+                break;
+            case '=': case 'M':
+                alignment_length += len; matches += len; match_units += len / motif_length;
+                cc_len.push_back(len); cc_idx.push_back((int)cc_len.size() - 1);
+                mismatch_continue = false; new_cigar += std::to_string(len) + op;
+                break;
+            default: break;
+        }
+    }
+    float purity = float(matches) / float(alignment_length);
+    if (prune && purity < prm.purity_threshold) {
+        float thr = prm.purity_threshold;
+        const std::pair<int, int> te = trim_edges(thr, purity, cc_len, alignment_length, prm.min_length[motif_length]);
+        new_cigar.clear(); matches = 0; match_units = 0;
+        for (size_t i = 0; i < cc_idx.size(); i++) {
+            const int ccidx = cc_idx[i];
+            const size_t src = start_soft_clip ? i + 1 : i;
+            const int len = lens[src]; const char op = ops[src];
+            if (ccidx < 2 * te.first) {
+                if (op != 'D') repeat_start += len;
+            } else if (ccidx >= 2 * te.first && (long)ccidx <= (long)cc_len.size() - 1 - 2L * te.second) {
+                new_cigar += std::to_string(len) + op;
+                if (op == 'M' || op == '=') { matches += len; match_units += len / motif_length; }
+            } else {
+                if (op != 'D') repeat_end -= len;
+            }
+        }
+    }
+    return Processed{repeat_start, repeat_end, alignment_length, match_units, new_cigar, purity};
+}
+
+/* calculateMotifUnits, parse_smallmotif_seed.cpp:26-72 */
+int motif_units_of(const View &v, int start, int length, int m, uint32_t unit) {
+    std::unordered_map<uint32_t, int> pos, units;
+    int seed_end = start + length;
+    if (seed_end > v.L - 1) seed_end = v.L - 1;
+    const uint32_t wmask = (m >= 16) ? 0xffffffffu : ((1u << (2 * m)) - 1u);
+    uint32_t window = 0;
+    for (int j = start; j < seed_end; j++) {
+        window = (window & ~3u) | v.code[j];
+        if (j - start >= (0.9 * m) - 1) {
+            const uint32_t motif = repeat_class(window, m);
+            if (pos.find(motif) == pos.end()) { pos[motif] = j - (m - 1); units[motif] = 1; }
+            else if ((j - (m - 1)) - pos[motif] >= m) { pos[motif] = j - (m - 1); units[motif] += 1; }
+        }
+        window = (window << 2) & wmask;
+    }
+    return units[unit];
+}
+
+struct BedOut {
+    std::ostringstream os;
+    std::string id;
+    std::string stale_cigar;      /* Alignment object shared by all seeds of a record (fasta_utils.cpp:177) */
+    void row(int start, int end, const std::string &motif, int atom, int m, float purity, int type, const std::string &cigar) {
+        os << id << "\t" << start << "\t" << end << "\t" << motif << "\t" << atom << " | " << m << "\t" << end - start << "\t"
+           << (end - start) / atom << "\t" << purity << "\t" << "+\tSEED-" << type << "\t" << cigar << "\n";
+    }
+};
+
+std::string substr_clamped(const char *seq, int L, int start, int len) {     /* std::string::substr; D4: start < 0 clamps to 0 */
+    if (start < 0) { len += start; start = 0; }
+    if (start >= L || len <= 0) return std::string();
+    if (start + len > L) len = L - start;
+    return std::string(seq + start, (size_t)len);
+}
+
+std::string repeat_past(const std::string &motif, int ppr_len) {            /* while (ppr.length() <= ppr_length) ppr += motif; */
+    std::string s;
+    while ((long)s.size() <= (long)ppr_len) s += motif;
+    return s;
+}
+
+/* processSeedMotifWise, parse_smallmotif_seed.cpp:190-288 */
+void refine_small(const View &v, const char *seq, const uint8_t *plane, int start, int end, int m, int type,
+                  const rbo_refine_params_t &prm, BedOut &out) {
+    const int ssl = seed_sequence_length(v, start, end, m);
+    if (longest_run(plane, start, end) < prm.continuous_ones_threshold) return;
+    std::vector<SmallMotif> found;
+    possible_motifs(v, start, ssl, m, prm, found);
+    for (const SmallMotif &sm : found) {
+        const int atom = atomicity_small(sm.motif, m);
+        const std::string motif = motif_string(sm.motif, m).substr(0, atom);
+        const uint32_t unit = sm.motif >> (2 * (m - atom));
+        const std::string query = substr_clamped(seq, v.L, sm.start, sm.end - sm.start);
+        const int ppr_len = ppr_length(sm.end - sm.start, m, sm.end - sm.start, prm.purity_threshold);
+        const std::string cigar = align_cigar(query, repeat_past(motif, ppr_len), ppr_len, out.stale_cigar);
+        const Processed p = process_cigar(sm.start, sm.end - sm.start, cigar, atom, false, prm);
+        const int repeat_length = p.repeat_end - p.repeat_start;
+        const int units = motif_units_of(v, p.repeat_start, repeat_length, atom, unit);
+        if (units >= prm.perfect_units[atom] && repeat_length >= prm.min_length[atom])
+            out.row(p.repeat_start, p.repeat_end, motif, atom, m, p.purity, type, p.cigar);
+    }
+}
+
+/* processSeed, parse_seed.cpp:318-464 (recursive on the flanks of the aligned repeat) */
+void refine_long(const View &v, const char *seq, const uint8_t *plane, int start, int end, int m, int type,
+                 const rbo_refine_params_t &prm, BedOut &out, int depth) {
+    if (depth > 10000) return;
+    const int ssl = seed_sequence_length(v, start, end, m);
+    if (end - start < 0.9 * m) return;
+    if (longest_run(plane, start, end) < prm.continuous_ones_threshold) return;
+    const int ppr_len = ppr_length(ssl, m, ssl, prm.purity_threshold);
+    const u256 unit = most_frequent_longer_motif(v, start, ssl, m);
+    const int atom = atomicity_long(unit, m);
+    if (m % atom != 0) return;
+    const std::string motif = motif_string(unit, m).substr(0, atom);
+    const std::string query = substr_clamped(seq, v.L, start, ssl);
+    const std::string cigar = align_cigar(query, repeat_past(motif, ppr_len), ppr_len, out.stale_cigar);
+    const Processed p = process_cigar(start, ssl, cigar, atom, true, prm);
+    if (p.alignment_length >= prm.min_length[atom]) {
+        if (p.repeat_end - p.repeat_start >= prm.min_length[m])
+            out.row(p.repeat_start, p.repeat_end, motif, atom, m, p.purity, type, p.cigar);
+    }
+    /* one locus (repeat_start, repeat_end - atomicity); flanks of at least MINIMUM_LENGTH[m] are re-processed (:443-463) */
+    int locus_first = p.repeat_start;
+    const int locus_second = p.repeat_end - atom;
+    int flank_start = start;
+    if (flank_start >= locus_first) {
+        flank_start = locus_second;
+    } else {
+        if (locus_first - flank_start >= prm.min_length[m]) {
+            if (locus_first > end) locus_first = end;
+            if (!(flank_start == start && locus_first == end))
+                refine_long(v, seq, plane, flank_start, locus_first, m, type, prm, out, depth + 1);
+        }
+        flank_start = locus_second;
+    }
+    if (end - flank_start >= prm.min_length[m]) {
+        if (flank_start < start) flank_start = start;
+        if (flank_start != start) refine_long(v, seq, plane, flank_start, end, m, type, prm, out, depth + 1);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* fasta_utils.cpp:187-242 + processSeedMotifWise / processSeed: BED text of one record.  Returns a pointer to
+ * an internal buffer (valid until the next call) and its length.  Needs rbo_run_dispatch(). */
+const char *rbo_refine_bed(rbo_ctx *c, const rbo_refine_params_t *prm, const char *seq, const char *seq_id, int64_t *len) {
+    static std::string text;
+    BedOut out;
+    out.id = seq_id;
+    const rbo_seed_t *seeds;
+    const int64_t n = rbo_dispatch(c, &seeds);
+    View v{rbo_codes(c), rbo_nmask(c), (int)rbo_length(c)};
+    for (int64_t si = 0; si < n; si++) {
+        const rbo_seed_t &s = seeds[si];
+        const uint8_t *plane = rbo_plane(c, s.mlen);
+        if (s.mlen <= 10) refine_small(v, seq, plane, s.start, s.end, s.mlen, s.type, *prm, out);
+        else refine_long(v, seq, plane, s.start, s.end, s.mlen, s.type, *prm, out, 0);
+    }
+    text = out.os.str();
+    *len = (int64_t)text.size();
+    return text.c_str();
 }
 
 }  // extern "C"

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 __all__ = ["RibbitHipError", "ScanParams", "Scanner", "library_path", "load_library", "host_replay_calls", "pack_planes", "pack_bit_planes",
-           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "ssw_align"]
+           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "host_refine_bed", "ssw_align"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_debug_stream_read",
     "ribbit_refine_params_default", "ribbit_hip_seed_longest_runs", "ribbit_hip_refine_jobs",
     "ribbit_host_refine_jobs", "ribbit_refine_jobs_free", "ribbit_ssw_align",
+    "ribbit_hip_refine_bed", "ribbit_host_refine_bed", "ribbit_text_free",
 ]
 
 
@@ -128,6 +129,11 @@ def load_library():
                                           C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.ribbit_refine_jobs_free.restype = None
     L.ribbit_refine_jobs_free.argtypes = [vp, vp]
+    L.ribbit_hip_refine_bed.argtypes = [vp, C.POINTER(RefineParams), C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ribbit_host_refine_bed.argtypes = [C.POINTER(ScanParams), C.POINTER(RefineParams), C.c_char_p, i64, vp, vp, vp, C.c_size_t,
+                                         vp, C.c_size_t, vp, C.c_size_t, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ribbit_text_free.restype = None
+    L.ribbit_text_free.argtypes = [vp]
     L.ribbit_ssw_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, C.POINTER(Alignment), C.c_char_p, C.c_size_t]
     L.ribbit_hip_debug_stream_read.argtypes = [vp, i64, C.POINTER(i64)]
     L.ribbit_hip_last_event_count.restype = i64
@@ -238,6 +244,30 @@ def host_refine_jobs(min_motif: int, max_motif: int, sequence: bytes, xa, xa_str
         return _copy(jobs.value, nj.value, JOB_DT), C.string_at(pool.value, npool.value)
     finally:
         L.ribbit_refine_jobs_free(jobs, pool)
+
+
+def host_refine_bed(min_motif: int, max_motif: int, sequence: bytes, xa, xa_stride: int, dispatch, sequence_id: str = "seq",
+                    refine_params=None) -> str:
+    """ribbit_host_refine_bed: dispatch seeds + planes -> BED text.  No GPU needed."""
+    L = load_library()
+    params = ScanParams()
+    L.ribbit_scan_params_default(C.byref(params), min_motif, max_motif)
+    rp = refine_params
+    if rp is None:
+        rp = RefineParams()
+        L.ribbit_refine_params_default(C.byref(rp), min_motif, max_motif)
+    hi, lo, brk = pack_planes(sequence, max_motif)
+    d = np.ascontiguousarray(dispatch, dtype=SEED_DT)
+    text, n = C.c_void_p(), C.c_size_t()
+    rc = L.ribbit_host_refine_bed(C.byref(params), C.byref(rp), sequence, len(sequence), hi.ctypes.data, lo.ctypes.data,
+                                  brk.ctypes.data, len(hi), xa.ctypes.data, xa_stride, d.ctypes.data, len(d),
+                                  sequence_id.encode(), C.byref(text), C.byref(n))
+    if rc != 0:
+        raise RibbitHipError(f"ribbit_host_refine_bed error {rc}: {L.ribbit_hip_last_error().decode()}")
+    try:
+        return C.string_at(text.value, n.value).decode()
+    finally:
+        L.ribbit_text_free(text)
 
 
 class Scanner:
@@ -351,6 +381,16 @@ class Scanner:
         arr = _copy(jobs.value, n.value, JOB_DT)
         size = int((arr["motif_offset"] + arr["atomicity"]).max()) if len(arr) else 0
         return arr, (C.string_at(pool.value, size) if size else b"")
+
+    def refine_bed(self, sequence_id: str = "seq", refine_params=None) -> str:
+        """BED rows of the loaded record (fasta_utils.cpp:211-242 and everything below it)"""
+        rp = refine_params
+        if rp is None:
+            rp = RefineParams()
+            self._L.ribbit_refine_params_default(C.byref(rp), self.params.min_motif, self.params.max_motif)
+        text, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.ribbit_hip_refine_bed(self._h, C.byref(rp), sequence_id.encode(), C.byref(text), C.byref(n)))
+        return C.string_at(text.value, n.value).decode()
 
     def guard_hits(self) -> int:
         return int(self._L.ribbit_hip_guard_hits(self._h))

@@ -132,6 +132,10 @@ struct RibbitHandle {
     DevBuf<int32_t> d_longest;
     std::vector<RibbitAlignJob> jobs;
     std::string motif_pool;
+    std::string host_ascii;   // the record's bases on the host (refinement slices them for the aligner)
+    bool host_ascii_valid = false;
+    const uint8_t *dev_ascii_src = nullptr;
+    std::string bed;
     int stage_done = STAGE_NONE;          // how far the seed lists have been advanced
     rb::SeedLists lists;
 
@@ -162,6 +166,7 @@ int is_gfx950(int device) {
 
 int pack_loaded_ascii(RibbitHandle *h, const uint8_t *dev_ascii, int64_t length) {
     h->loaded = false;
+    h->dev_ascii_src = dev_ascii;
     h->runs_valid = h->calls_valid = h->subst_calls_valid = h->anchored_calls_valid = false;
     h->longest_valid = false;
     h->host_planes_valid = false;
@@ -670,7 +675,9 @@ int ribbit_hip_load_record(RibbitHandle *h, const char *ascii, int64_t length) {
     if ((rc = bind_device(h))) return rc;
     if ((rc = h->d_ascii.ensure((size_t)std::max<int64_t>(length, 16)))) return rc;
     if (length) HIP_TRY(hipMemcpyAsync(h->d_ascii.p, ascii, (size_t)length, hipMemcpyHostToDevice, h->stream));
-    return pack_loaded_ascii(h, h->d_ascii.p, length);
+    rc = pack_loaded_ascii(h, h->d_ascii.p, length);
+    if (rc == RIBBIT_OK) { h->host_ascii.assign(ascii, (size_t)length); h->host_ascii_valid = true; }
+    return rc;
 }
 
 int ribbit_hip_load_record_device(RibbitHandle *h, const void *dev_ascii, int64_t length) {
@@ -678,6 +685,7 @@ int ribbit_hip_load_record_device(RibbitHandle *h, const void *dev_ascii, int64_
     if (length < 0 || length >= ((int64_t)1 << 31) - 64) return fail(RIBBIT_E_ARG, "record length %lld not supported", (long long)length);
     int rc;
     if ((rc = bind_device(h))) return rc;
+    h->host_ascii_valid = false;
     return pack_loaded_ascii(h, (const uint8_t *)dev_ascii, length);
 }
 
@@ -829,6 +837,60 @@ int ribbit_host_refine_jobs(const RibbitScanParams *params, const RibbitRefinePa
     std::memcpy(*motif_pool, pool.c_str(), pool.size() + 1);
     return RIBBIT_OK;
 }
+
+int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const char *sequence_id,
+                          const char **text, size_t *len) {
+    if (!h || !prm || !sequence_id || !text || !len) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    int rc = build_longest_runs(h);
+    if (rc) return rc;
+    if (!h->host_ascii_valid) {      // record was loaded from device memory: fetch the bases once
+        h->host_ascii.resize((size_t)h->length);
+        if (h->length) {
+            HIP_TRY(hipMemcpyAsync(&h->host_ascii[0], h->dev_ascii_src, (size_t)h->length, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        h->host_ascii_valid = true;
+    }
+    h->bed.clear();
+    rb::refine_to_bed(h->host, h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), sequence_id, h->bed);
+    *text = h->bed.c_str();
+    *len = h->bed.size();
+    return RIBBIT_OK;
+}
+
+int ribbit_host_refine_bed(const RibbitScanParams *params, const RibbitRefineParams *prm, const char *sequence, int64_t length,
+                           const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
+                           const uint32_t *xa, size_t xa_stride, const RibbitSeed *dispatch, size_t n_dispatch,
+                           const char *sequence_id, char **text, size_t *len) {
+    if (!params || !prm || !text || !len || !sequence_id || (n_dispatch && !dispatch)) return fail(RIBBIT_E_ARG, "null argument");
+    if (length > 0 && (!sequence || !hi || !lo || !brk || !xa)) return fail(RIBBIT_E_ARG, "null plane");
+    if (nwords < (size_t)(length / 32 + 1) || xa_stride < (size_t)(length / 32 + 1)) return fail(RIBBIT_E_ARG, "planes too short");
+    rb::HostPlanes hp;
+    hp.resize(length, nwords);
+    if (nwords) {
+        std::memcpy(hp.hi.data(), hi, nwords * sizeof(uint32_t));
+        std::memcpy(hp.lo.data(), lo, nwords * sizeof(uint32_t));
+        std::memcpy(hp.brk.data(), brk, nwords * sizeof(uint32_t));
+    }
+    const size_t nm = (size_t)(params->max_motif - params->min_motif + 1);
+    if (xa) hp.xa.assign(xa, xa + nm * xa_stride);
+    hp.xa_stride = (int64_t)xa_stride;
+    hp.xa_m_lo = params->min_motif;
+    hp.xa_m_hi = params->max_motif;
+    std::vector<RibbitSeed> seeds(dispatch, dispatch + n_dispatch);
+    std::vector<int32_t> longest(n_dispatch);
+    for (size_t i = 0; i < n_dispatch; ++i) longest[i] = rb::longest_run_host(hp, seeds[i].mlen, seeds[i].start, seeds[i].end);
+    std::string bed;
+    rb::refine_to_bed(hp, sequence, *prm, seeds, longest.data(), sequence_id, bed);
+    *len = bed.size();
+    *text = (char *)std::malloc(bed.size() + 1);
+    if (!*text) return fail(RIBBIT_E_NOMEM, "out of host memory");
+    std::memcpy(*text, bed.c_str(), bed.size() + 1);
+    return RIBBIT_OK;
+}
+
+void ribbit_text_free(char *text) { std::free(text); }
 
 void ribbit_refine_jobs_free(RibbitAlignJob *jobs, char *motif_pool) {
     std::free(jobs);

@@ -1,7 +1,10 @@
 #include "refine.h"
 
+#include "ssw_exact.h"
+
 #include <algorithm>
 #include <cstdlib>
+#include <sstream>
 #include <unordered_map>
 
 namespace rb {
@@ -238,6 +241,191 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
             jobs.push_back(job);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Alignment post-processing and BED rows
+namespace {
+
+struct CigarOp { int len; char op; };
+
+std::vector<CigarOp> parse_cigar(const std::string &text) {        // cigarSplit, process_cigar.cpp:14-31
+    std::vector<CigarOp> ops;
+    int n = 0;
+    for (char ch : text) {
+        if (ch >= '0' && ch <= '9') n = n * 10 + (ch - '0');
+        else { ops.push_back({n, ch}); n = 0; }
+    }
+    return ops;
+}
+
+struct Repeat { int start, end, alignment_length, match_units; float purity; std::string cigar; };
+
+// processCIGARMotifWise (process_cigar.cpp:254-336); with prune == true processCIGARWithPruning
+// (:126-251) incl. calculateTrimEdges (:34-86).  The alignment is compressed into alternating blocks
+// match, non-match, match, ...; trimming drops whole block pairs from either end until the purity
+// reaches the threshold (keeping, per trim depth, the longest combination that reaches it).
+Repeat digest_cigar(int seed_start, int seq_len, const std::string &text, int unit_len, bool prune, const RibbitRefineParams &prm) {
+    const std::vector<CigarOp> ops = parse_cigar(text);
+    Repeat r{seed_start, seed_start + seq_len, 0, 0, 0.f, std::string()};
+    std::vector<int> block_of;      // compressed-block index of every aligned (non-S) op
+    std::vector<int> block_len;     // lengths of the alternating blocks
+    int matches = 0, lead_clip = 0;
+    bool in_mismatch = false;
+    for (size_t i = 0; i < ops.size(); ++i) {
+        const CigarOp &o = ops[i];
+        if (o.op == 'S') { if (i == 0) { r.start += o.len; lead_clip = o.len; } else r.end -= o.len; continue; }
+        if (o.op == '=' || o.op == 'M') {
+            matches += o.len; r.match_units += o.len / unit_len;
+            block_len.push_back(o.len); in_mismatch = false;
+        } else if (o.op == 'X' || o.op == 'I' || o.op == 'D') {
+            if (in_mismatch) block_len.back() += o.len; else block_len.push_back(o.len);
+            in_mismatch = true;
+        } else continue;
+        r.alignment_length += o.len;
+        block_of.push_back((int)block_len.size() - 1);
+        r.cigar += std::to_string(o.len) + o.op;
+    }
+    r.purity = float(matches) / float(r.alignment_length);
+    if (!prune || !(r.purity < prm.purity_threshold)) return r;
+
+    // calculateTrimEdges: left/right counts of (match, mismatch) block pairs to drop
+    const long nb = (long)block_len.size();
+    int drop_left = 0, drop_right = 0;
+    for (int depth = 1; r.purity < prm.purity_threshold; ++depth) {
+        float best_purity = 0; int best_len = 0;
+        for (int left = 0; left <= depth; ++left) {
+            int m_sum = 0, a_sum = 0;
+            for (long j = 2L * left; j <= (nb - 1) - 2L * (depth - left); ++j) {
+                if ((j & 1) == 0) m_sum += block_len[(size_t)j];
+                a_sum += block_len[(size_t)j];
+            }
+            const float p = float(m_sum) / float(a_sum);
+            if (p >= prm.purity_threshold && best_len < a_sum) { best_purity = p; best_len = a_sum; drop_left = left; drop_right = depth - left; }
+        }
+        if (best_purity > r.purity) { r.purity = best_purity; r.alignment_length = best_len; }
+        if (r.alignment_length < prm.min_length[unit_len]) break;
+        if (2L * depth > nb + 2) break;       // D5: the reference's unsigned loop bound would wrap here
+    }
+    r.cigar.clear(); r.match_units = 0;
+    const size_t first_aligned = lead_clip ? 1 : 0;      // ops[] index of the first aligned op (:216-217)
+    for (size_t i = 0; i < block_of.size(); ++i) {
+        const CigarOp &o = ops[first_aligned + i];
+        const long b = block_of[i];
+        if (b < 2L * drop_left) { if (o.op != 'D') r.start += o.len; }
+        else if (b <= nb - 1 - 2L * drop_right) {
+            r.cigar += std::to_string(o.len) + o.op;
+            if (o.op == 'M' || o.op == '=') r.match_units += o.len / unit_len;
+        } else if (o.op != 'D') r.end -= o.len;
+    }
+    return r;
+}
+
+// calculateMotifUnits (parse_smallmotif_seed.cpp:26-72): non-overlapping exact occurrences of the unit's
+// rotation class in [start, start+length)
+int count_units(const Bases &b, int start, int length, int m, uint32_t unit) {
+    const int stop = std::min(start + length, b.L - 1);
+    const uint32_t mask = m >= 16 ? 0xffffffffu : (1u << (2 * m)) - 1u;
+    std::unordered_map<uint32_t, std::pair<int, int>> seen;     // class -> (last unit start, units)
+    uint32_t window = 0;
+    for (int j = start; j < stop; ++j) {
+        window = ((window << 2) | b.code(j)) & mask;
+        if (!(j - start >= 0.9 * m - 1)) continue;
+        const uint32_t cls = smallest_rotation(window, m);
+        const int at = j - (m - 1);
+        auto it = seen.find(cls);
+        if (it == seen.end()) seen[cls] = {at, 1};
+        else if (at - it->second.first >= m) { it->second.first = at; it->second.second += 1; }
+    }
+    auto it = seen.find(unit);
+    return it == seen.end() ? 0 : it->second.second;
+}
+
+struct Writer {
+    const Bases &b;
+    const HostPlanes &hp;
+    const char *sequence;
+    const RibbitRefineParams &prm;
+    const std::string &id;
+    std::ostringstream os;
+    std::string last_cigar;     // the Alignment object lives across seeds (fasta_utils.cpp:177): an empty query leaves it untouched
+
+    std::string slice(int start, int len) const {               // sequence.substr(start, len); D4: negative start clamps
+        if (start < 0) { len += start; start = 0; }
+        if (start >= b.L || len <= 0) return std::string();
+        return std::string(sequence + start, (size_t)std::min(len, b.L - start));
+    }
+    std::string align(const std::string &query, const std::string &motif, int ppr_len) {
+        if (query.empty()) return last_cigar;
+        std::string ref;
+        while ((long)ref.size() <= (long)ppr_len) ref += motif;
+        SswResult res;
+        ssw_align(query.data(), (int)query.size(), ref.data(), ppr_len, 15, res);
+        last_cigar = res.cigar;
+        return last_cigar;
+    }
+    void row(const Repeat &r, const std::string &motif, int atom, int m, int type) {   // parse_seed.cpp:434-436
+        os << id << "\t" << r.start << "\t" << r.end << "\t" << motif << "\t" << atom << " | " << m << "\t" << r.end - r.start << "\t"
+           << (r.end - r.start) / atom << "\t" << r.purity << "\t" << "+\tSEED-" << type << "\t" << r.cigar << "\n";
+    }
+
+    void small_seed(const RibbitSeed &seed, int longest) {                              // processSeedMotifWise
+        const int m = seed.mlen;
+        if (longest < prm.continuous_ones_threshold) return;
+        const int seq_len = usable_length(b, seed.start, seed.end, m);
+        std::vector<uint32_t> classes; std::vector<int> starts, ends;
+        discover_small_motifs(b, seed.start, seq_len, m, prm.min_length[m], prm.perfect_units[m], classes, starts, ends);
+        for (size_t k = 0; k < classes.size(); ++k) {
+            const int atom = small_atomicity(classes[k], m);
+            Wide unit; unit.limb[0] = classes[k];
+            const std::string motif = spell(unit, m, atom);
+            const int qlen = ends[k] - starts[k];
+            const std::string cigar = align(slice(starts[k], qlen), motif, padded_length(qlen, m, qlen, prm.purity_threshold));
+            const Repeat r = digest_cigar(starts[k], qlen, cigar, atom, false, prm);
+            const int units = count_units(b, r.start, r.end - r.start, atom, classes[k] >> (2 * (m - atom)));
+            if (units >= prm.perfect_units[atom] && r.end - r.start >= prm.min_length[atom]) row(r, motif, atom, m, seed.type);
+        }
+    }
+
+    void long_seed(int start, int end, int m, int type, int longest, int depth) {       // processSeed
+        if (depth > 10000) return;
+        if (end - start < 0.9 * m) return;
+        if (longest < 0) longest = longest_run_host(hp, m, start, end);
+        if (longest < prm.continuous_ones_threshold) return;
+        const int seq_len = usable_length(b, start, end, m);
+        const Wide unit = consensus_long_motif(b, start, seq_len, m);
+        const int atom = long_atomicity(unit, m);
+        if (m % atom != 0) return;
+        const std::string motif = spell(unit, m, atom);
+        const std::string cigar = align(slice(start, seq_len), motif, padded_length(seq_len, m, seq_len, prm.purity_threshold));
+        const Repeat r = digest_cigar(start, seq_len, cigar, atom, true, prm);
+        if (r.alignment_length >= prm.min_length[atom] && r.end - r.start >= prm.min_length[m]) row(r, motif, atom, m, type);
+        // flanks on either side of the aligned repeat, if at least MINIMUM_LENGTH[m] long (:443-463)
+        const int right_from = r.end - atom;
+        if (start < r.start) {
+            const int left_to = std::min(r.start, end);
+            if (r.start - start >= prm.min_length[m] && !(left_to == end)) long_seed(start, left_to, m, type, -1, depth + 1);
+        }
+        if (end - right_from >= prm.min_length[m]) {
+            const int from = std::max(right_from, start);
+            if (from != start) long_seed(from, end, m, type, -1, depth + 1);
+        }
+    }
+};
+
+}  // namespace
+
+void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
+                   const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const std::string &sequence_id,
+                   std::string &bed) {
+    const Bases b(hp);
+    Writer w{b, hp, sequence, prm, sequence_id, {}, {}};
+    for (size_t i = 0; i < dispatch.size(); ++i) {
+        const RibbitSeed &seed = dispatch[i];
+        if (seed.mlen <= 10) w.small_seed(seed, longest_runs[i]);
+        else w.long_seed(seed.start, seed.end, seed.mlen, seed.type, longest_runs[i], 0);
+    }
+    bed += w.os.str();
 }
 
 }  // namespace rb

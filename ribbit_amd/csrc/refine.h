@@ -24,4 +24,12 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
 // ribbit_host_refine_jobs, which has no device)
 int longest_run_host(const HostPlanes &hp, int mlen, int start, int end);
 
+// Everything processSequence does with the dispatched seeds (fasta_utils.cpp:211-242): processSeedMotifWise
+// (parse_smallmotif_seed.cpp:190-288) for m <= 10, processSeed incl. its recursion on the flanks
+// (parse_seed.cpp:318-464) for m > 10, alignment by ssw_exact, CIGAR processing (process_cigar.cpp:126-336),
+// and the BED rows (11 tab-separated columns) appended to `bed`.  sequence = the record's bases.
+void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
+                   const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const std::string &sequence_id,
+                   std::string &bed);
+
 }  // namespace rb

@@ -1,0 +1,216 @@
+// ribbit_main.cpp -- command-line front end with ribbit's surface (ribbit.cpp): same options, same
+// defaults and quirks, FASTA in, BED out, the reference's progress lines on stderr.  Everything
+// between reading a record and writing its BED rows goes through the C ABI of libribbit_hip.so.
+//
+//   ribbit-hip -i in.fa [-o out.bed] [-m 2] [-M 100] [-p 0.85] [-l N|file] [--min-units N|file] [--perfect-units N|file]
+//
+// Reproduced quirks: -p is accepted and ignored (Q1); without -o the BED rows go to
+// stderr (Q2); --help exits with status 1 (Q3); the record name ends at the first space and the last
+// record is processed even when the file is empty (Q4).
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ribbit_hip.h"
+
+namespace {
+
+struct Options {
+    std::string fasta, out;
+    int min_motif = 2, max_motif = 100;          // global_variables.cpp:21-22
+    bool has_min_length = false, has_min_units = false, has_perfect_units = false;
+    std::string min_length, min_units, perfect_units;
+    int device = 0;
+};
+
+const char *kHelp =
+    "Below are the running options for the tool.:\n"
+    "  -h [ --help ]                 Ribbit tool identifies short tandem repeats with allowed levels of inpurity.\n"
+    "  -i [ --input-file ] arg       File path for the input fasta file.\n"
+    "  -o [ --output-file ] arg      File path for the input fasta file.\n"
+    "  -m [ --min-motif-length ] arg The minimum length of the motif of the repeats to be identified. Default: 2\n"
+    "  -M [ --max-motif-length ] arg The maximum length of the motif of the repeats to be identified, Default: 100\n"
+    "  -p [ --purity ] arg           Threshold value for cotinuous number of ones found in a seed. Default: 0.85\n"
+    "  -l [ --min-length ] arg       The minimum length of the repeat. Default: 12\n"
+    "  --min-units arg               The minimum number of units of the repeat. Integer, or a tab separated file\n"
+    "                                with the motif size and the unit cutoff. Default: 2\n"
+    "  --perfect-units arg           The minimum number of complete units of the repeat. Integer, or a tab\n"
+    "                                separated file with the motif size and the unit cutoff. Default: 2\n";
+
+[[noreturn]] void die(const std::string &msg) {
+    std::cerr << "ribbit-hip: " << msg << "\n";
+    std::exit(1);
+}
+
+// returns 0 for --help (the caller exits 1, as the reference does), 1 on success
+int parse_arguments(int argc, char **argv, Options &o) {
+    static const std::map<std::string, std::string> longs = {
+        {"help", "h"}, {"input-file", "i"}, {"output-file", "o"}, {"min-motif-length", "m"}, {"max-motif-length", "M"},
+        {"purity", "p"}, {"min-length", "l"}, {"min-units", "U"}, {"perfect-units", "P"}, {"device", "D"}};
+    bool help = false;
+    for (int a = 1; a < argc; ++a) {
+        std::string arg = argv[a], key, value;
+        bool has_value = false;
+        if (arg.rfind("--", 0) == 0) {
+            const size_t eq = arg.find('=');
+            const std::string name = arg.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+            auto it = longs.find(name);
+            if (it == longs.end()) die("unrecognised option '" + arg + "'");
+            key = it->second;
+            if (eq != std::string::npos) { value = arg.substr(eq + 1); has_value = true; }
+        } else if (arg.size() >= 2 && arg[0] == '-') {
+            key = arg.substr(1, 1);
+            if (std::string("hiomMpl").find(key) == std::string::npos) die("unrecognised option '" + arg + "'");
+            if (arg.size() > 2) { value = arg.substr(2); has_value = true; }
+        } else {
+            die("too many positional options have been specified on the command line");
+        }
+        if (key == "h") { help = true; continue; }
+        if (!has_value) {
+            if (a + 1 >= argc) die("the required argument for option '" + arg + "' is missing");
+            value = argv[++a];
+        }
+        if (key == "i") o.fasta = value;
+        else if (key == "o") o.out = value;
+        else if (key == "m") o.min_motif = std::atoi(value.c_str());
+        else if (key == "M") o.max_motif = std::atoi(value.c_str());
+        else if (key == "p") { /* declared, never read (ribbit.cpp:92) */ }
+        else if (key == "l") { o.has_min_length = true; o.min_length = value; }
+        else if (key == "U") { o.has_min_units = true; o.min_units = value; }
+        else if (key == "P") { o.has_perfect_units = true; o.perfect_units = value; }
+        else if (key == "D") o.device = std::atoi(value.c_str());
+    }
+    if (help) { std::cerr << kHelp << "\n"; return 0; }                       // ribbit.cpp:114-117
+    if (o.fasta.empty()) { std::cerr << "ERROR: Please specify an input fasta file!\n"; return 0; }   // :122-126
+    return 1;
+}
+
+bool is_number(const std::string &s) { return !s.empty() && std::all_of(s.begin(), s.end(), [](unsigned char c) { return std::isdigit(c); }); }
+
+// parseDualtypeArgs, ribbit.cpp:25-64: one integer for every motif size in range, or a two-column TSV
+void dual_type(const std::string &value, std::map<int, int> &table, int m_lo, int m_hi) {
+    if (is_number(value)) {
+        for (int k = m_lo; k <= m_hi; ++k) table[k] = std::atoi(value.c_str());
+        return;
+    }
+    std::ifstream in(value);
+    std::string line;
+    while (std::getline(in, line)) {
+        const size_t tab = line.find('\t');
+        if (tab == std::string::npos) continue;
+        table[std::atoi(line.substr(0, tab).c_str())] = std::atoi(line.substr(tab + 1).c_str());
+    }
+}
+
+// ribbit.cpp:143-174 and the factor completion of :210-235
+void build_refine_params(const Options &o, RibbitRefineParams &prm) {
+    ribbit_refine_params_default(&prm, o.min_motif, o.max_motif);
+    if (!o.has_min_length && !o.has_min_units && !o.has_perfect_units) return;
+    std::map<int, int> min_length, min_units, perfect_units;
+    if (o.has_min_length) dual_type(o.min_length, min_length, o.min_motif, o.max_motif);
+    else if (o.has_min_units) {
+        dual_type(o.min_units, min_units, o.min_motif, o.max_motif);
+        for (auto &kv : min_units) min_length[kv.first] = kv.first * kv.second;
+    } else {
+        for (int k = o.min_motif; k <= o.max_motif; ++k) min_length[k] = std::max(12, 2 * k);
+    }
+    if (o.has_perfect_units) dual_type(o.perfect_units, perfect_units, o.min_motif, o.max_motif);
+    else for (int m = 1; m <= o.max_motif; ++m) perfect_units[m] = m == 1 ? 8 : m == 2 ? 4 : m == 3 ? 3 : 2;
+    for (int m = o.min_motif; m <= o.max_motif; ++m)
+        for (int f = 1; f <= m / 2; ++f) {
+            if (m % f) continue;
+            if (!min_length.count(f)) min_length[f] = min_length[m];
+            if (!perfect_units.count(f)) perfect_units[f] = perfect_units[m] * (m / f);
+        }
+    std::memset(prm.min_length, 0, sizeof prm.min_length);
+    std::memset(prm.perfect_units, 0, sizeof prm.perfect_units);
+    for (auto &kv : min_length) if (kv.first >= 0 && kv.first < RIBBIT_TABLE) prm.min_length[kv.first] = kv.second;
+    for (auto &kv : perfect_units) if (kv.first >= 0 && kv.first < RIBBIT_TABLE) prm.perfect_units[kv.first] = kv.second;
+}
+
+void check(int rc) {
+    if (rc != RIBBIT_OK) die(std::string("GPU path failed: ") + ribbit_hip_last_error());
+}
+
+size_t count_failed(const RibbitSeed *s, size_t n) {
+    size_t c = 0;
+    for (size_t i = 0; i < n; ++i) c += s[i].type == RIBBIT_RANK_N;
+    return c;
+}
+
+// processSequence (fasta_utils.cpp:59-250) through the C ABI, with the reference's progress lines
+void process_sequence(RibbitHandle *h, const RibbitRefineParams &prm, const std::string &name, const std::string &sequence,
+                      std::ostream &out) {
+    const time_t t0 = time(0);
+    auto secs = [&]() { return difftime(time(0), t0); };
+    check(ribbit_hip_load_record(h, sequence.data(), (int64_t)sequence.size()));
+    std::cerr << "Generated shift XORs!\t Time elapsed:" << secs() << "secs\n";
+    const RibbitSeed *p, *s, *a;
+    size_t np, ns, na;
+    check(ribbit_hip_seeds_perfect(h, &p, &np));
+    std::cerr << "Total number of perfect seeds: " << np << "\t Time elapsed: " << secs() << "secs\n";
+    check(ribbit_hip_seeds_substitutions(h, &p, &np, &s, &ns));
+    std::cerr << "Total number of seeds considering substitutions: " << np + ns - count_failed(p, np) - count_failed(s, ns)
+              << "\t Time elapsed: " << secs() << "secs\n";
+    check(ribbit_hip_seeds_anchored(h, &p, &np, &s, &ns, &a, &na));
+    std::cerr << "Generated anchored shift XORs!\t Time elapsed: " << secs() << "secs\n";
+    std::cerr << "Total number of seeds considering indels: "
+              << np + ns + na - count_failed(p, np) - count_failed(s, ns) - count_failed(a, na) << "\t Time elapsed: " << secs() << "secs\n";
+    const RibbitSeed *d;
+    size_t nd;
+    check(ribbit_hip_dispatch_seeds(h, &d, &nd));
+    const char *text;
+    size_t len;
+    check(ribbit_hip_refine_bed(h, &prm, name.c_str(), &text, &len));
+    out.write(text, (std::streamsize)len);
+    std::cerr << "Total number of seeds that are processed for alignment: " << nd << "\t Time elapsed: " << secs() << "secs\n";
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    Options opt;
+    if (!parse_arguments(argc, argv, opt)) return 1;                          // ribbit.cpp:193-195
+
+    std::ofstream file;
+    if (!opt.out.empty()) file.open(opt.out);
+    std::ostream &out = opt.out.empty() ? std::cerr : file;                   // ribbit.cpp:199-205
+
+    RibbitRefineParams prm;
+    build_refine_params(opt, prm);
+    std::cerr << "Minimum motif:\t" << opt.min_motif << "\n";
+    std::cerr << "Maximum motif:\t" << opt.max_motif << "\n";
+    std::cerr << "Purity threshold: " << 0.85f << "\n";
+
+    RibbitScanParams scan;
+    ribbit_scan_params_default(&scan, opt.min_motif, opt.max_motif);
+    RibbitHandle *h = nullptr;
+    check(ribbit_hip_open(&scan, opt.device, &h));
+
+    std::ifstream in(opt.fasta);
+    std::string line, name, sequence;
+    while (std::getline(in, line)) {                                          // ribbit.cpp:269-279
+        if (!line.empty() && line[0] == '>') {
+            if (!sequence.empty()) {
+                std::cerr << "Processing sequence " << name << "\n";
+                process_sequence(h, prm, name, sequence, out);
+            }
+            const size_t sp = line.find(' ');
+            name = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
+            sequence.clear();
+        } else {
+            sequence += line;
+        }
+    }
+    process_sequence(h, prm, name, sequence, out);                            // :280, also for an empty file (Q4)
+    ribbit_hip_close(h);
+    return 0;
+}

@@ -66,6 +66,8 @@ def lib():
         L.rbo_refine_params_default.argtypes = [C.POINTER(RefineParams), C.c_int, C.c_int]
         L.rbo_refine_jobs.restype = C.c_int64
         L.rbo_refine_jobs.argtypes = [C.c_void_p, C.POINTER(RefineParams), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.rbo_refine_bed.restype = C.c_void_p
+        L.rbo_refine_bed.argtypes = [C.c_void_p, C.POINTER(RefineParams), C.c_char_p, C.c_char_p, C.POINTER(C.c_int64)]
         L.rbo_range_count.restype = C.c_int
         L.rbo_range_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         _lib = L
@@ -172,6 +174,16 @@ class Oracle:
         arr = _copy(jobs.value, n, JOB_DT)
         size = int((arr["motif_offset"] + arr["atomicity"]).max()) if len(arr) else 0
         return arr, (C.string_at(pool.value, size) if size else b"")
+
+    def refine_bed(self, seq_id: str = "seq", params=None) -> str:
+        """BED text of this record (needs run_dispatch()); alignments by the reference's own SSW (oracle/_ref)"""
+        rp = params
+        if rp is None:
+            rp = RefineParams()
+            self._L.rbo_refine_params_default(C.byref(rp), self.m_lo, self.m_hi)
+        n = C.c_int64()
+        p = self._L.rbo_refine_bed(self._h, C.byref(rp), self.seq, seq_id.encode(), C.byref(n))
+        return C.string_at(p, n.value).decode()
 
     def range_count(self, shift, start, end):
         return self._L.rbo_range_count(self._h, shift, start, end)
