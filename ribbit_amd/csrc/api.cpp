@@ -130,6 +130,10 @@ struct RibbitHandle {
     std::vector<int32_t> longest_runs;
     DevBuf<RibbitSeed> d_seeds;
     DevBuf<int32_t> d_longest;
+    DevBuf<uint8_t> d_sym;
+    DevBuf<unsigned long long> d_best;
+    bool best_rows_valid = false;
+    std::vector<int32_t> best_rows;       // per dispatch seed: mostFrequentLongerMotif's window start, or -1
     std::vector<RibbitAlignJob> jobs;
     std::string motif_pool;
     std::string host_ascii;   // the record's bases on the host (refinement slices them for the aligner)
@@ -169,6 +173,7 @@ int pack_loaded_ascii(RibbitHandle *h, const uint8_t *dev_ascii, int64_t length)
     h->dev_ascii_src = dev_ascii;
     h->runs_valid = h->calls_valid = h->subst_calls_valid = h->anchored_calls_valid = false;
     h->longest_valid = false;
+    h->best_rows_valid = false;
     h->host_planes_valid = false;
     h->stage_done = STAGE_NONE;
     h->length = length;
@@ -580,6 +585,41 @@ int build_longest_runs(RibbitHandle *h) {
     return RIBBIT_OK;
 }
 
+// mostFrequentLongerMotif's row selection for every dispatched seed with m > 10 that will reach it
+// (parse_seed.cpp:360-386), one GPU launch (a15)
+int build_best_rows(RibbitHandle *h, const RibbitRefineParams &prm) {
+    if (h->best_rows_valid) return RIBBIT_OK;
+    int rc = build_longest_runs(h);
+    if (rc) return rc;
+    const size_t n = h->dispatch.size();
+    h->best_rows.assign(n, -1);
+    std::vector<RibbitSeed> jobs;          // reused as int4 {seed_start, seed_sequence_length, m, dispatch index}
+    for (size_t i = 0; i < n; ++i) {
+        const RibbitSeed &s = h->dispatch[i];
+        if (s.mlen <= 10 || s.end - s.start < 0.9 * s.mlen || h->longest_runs[i] < prm.continuous_ones_threshold) continue;
+        jobs.push_back(RibbitSeed{s.start, rb::usable_length_host(h->host, s.start, s.end, s.mlen), s.mlen, (int32_t)i});
+    }
+    if (!jobs.empty()) {
+        if ((rc = bind_device(h))) return rc;
+        if ((rc = h->d_sym.ensure((size_t)h->length + 16))) return rc;
+        if ((rc = h->d_seeds.ensure(jobs.size()))) return rc;
+        if ((rc = h->d_best.ensure(jobs.size()))) return rc;
+        rb::launch_sym(h->dev_ascii_src, h->length, h->d_sym.p, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->d_seeds.p, jobs.data(), jobs.size() * sizeof(RibbitSeed), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_best.p, 0, jobs.size() * sizeof(unsigned long long), h->stream));
+        rb::launch_long_motif_rows(h->d_sym.p, h->length, h->d_seeds.p, (int64_t)jobs.size(), h->d_best.p, h->stream);
+        HIP_TRY(hipGetLastError());
+        std::vector<unsigned long long> best(jobs.size());
+        HIP_TRY(hipMemcpyAsync(best.data(), h->d_best.p, jobs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (size_t j = 0; j < jobs.size(); ++j)      // no positive score: mmotif_index keeps its initial 0 (parse_seed.cpp:165)
+            h->best_rows[(size_t)jobs[j].type] = best[j] ? (int32_t)(0xffffffffu - (uint32_t)best[j]) : 0;
+    }
+    h->best_rows_valid = true;
+    return RIBBIT_OK;
+}
+
 void fill_refine_defaults(RibbitRefineParams *p, int min_motif, int max_motif) {
     std::memset(p, 0, sizeof *p);
     p->purity_threshold = 0.85f;             // global_variables.cpp:44 (the -p option is never read)
@@ -654,7 +694,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ascii.release(); h->d_hi.release(); h->d_lo.release(); h->d_brk.release();
-    h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release();
+    h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release();
     h->h_events.release(); h->h_counters.release(); h->h_query.release();
     for (int i = 0; i < 6; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -794,9 +834,10 @@ int ribbit_hip_refine_jobs(RibbitHandle *h, const RibbitRefineParams *prm, const
                            const char **motif_pool) {
     if (!h || !prm || !jobs || !n || !motif_pool) return fail(RIBBIT_E_ARG, "null argument");
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
-    int rc = build_longest_runs(h);
+    h->best_rows_valid = false;            // depends on prm's thresholds
+    int rc = build_best_rows(h, *prm);
     if (rc) return rc;
-    rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->jobs, h->motif_pool);
+    rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), h->jobs, h->motif_pool);
     *jobs = h->jobs.data();
     *n = h->jobs.size();
     *motif_pool = h->motif_pool.c_str();
@@ -827,7 +868,7 @@ int ribbit_host_refine_jobs(const RibbitScanParams *params, const RibbitRefinePa
     for (size_t i = 0; i < n_dispatch; ++i) longest[i] = rb::longest_run_host(hp, seeds[i].mlen, seeds[i].start, seeds[i].end);
     std::vector<RibbitAlignJob> out;
     std::string pool;
-    rb::build_align_jobs(hp, *prm, seeds, longest.data(), out, pool);
+    rb::build_align_jobs(hp, *prm, seeds, longest.data(), nullptr, out, pool);
     *n_jobs = out.size();
     *pool_len = pool.size();
     *jobs = (RibbitAlignJob *)std::malloc(std::max<size_t>(out.size(), 1) * sizeof(RibbitAlignJob));
@@ -842,7 +883,8 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
                           const char **text, size_t *len) {
     if (!h || !prm || !sequence_id || !text || !len) return fail(RIBBIT_E_ARG, "null argument");
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
-    int rc = build_longest_runs(h);
+    h->best_rows_valid = false;
+    int rc = build_best_rows(h, *prm);
     if (rc) return rc;
     if (!h->host_ascii_valid) {      // record was loaded from device memory: fetch the bases once
         h->host_ascii.resize((size_t)h->length);
@@ -853,7 +895,7 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
         h->host_ascii_valid = true;
     }
     h->bed.clear();
-    rb::refine_to_bed(h->host, h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), sequence_id, h->bed);
+    rb::refine_to_bed(h->host, h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sequence_id, h->bed);
     *text = h->bed.c_str();
     *len = h->bed.size();
     return RIBBIT_OK;
@@ -882,7 +924,7 @@ int ribbit_host_refine_bed(const RibbitScanParams *params, const RibbitRefinePar
     std::vector<int32_t> longest(n_dispatch);
     for (size_t i = 0; i < n_dispatch; ++i) longest[i] = rb::longest_run_host(hp, seeds[i].mlen, seeds[i].start, seeds[i].end);
     std::string bed;
-    rb::refine_to_bed(hp, sequence, *prm, seeds, longest.data(), sequence_id, bed);
+    rb::refine_to_bed(hp, sequence, *prm, seeds, longest.data(), nullptr, sequence_id, bed);
     *len = bed.size();
     *text = (char *)std::malloc(bed.size() + 1);
     if (!*text) return fail(RIBBIT_E_NOMEM, "out of host memory");

@@ -13,6 +13,8 @@
 //     written out, compacted in position order with a wave prefix sum.
 #include <hip/hip_runtime.h>
 
+#include <climits>
+
 #include "kernels.h"
 
 namespace rb {
@@ -838,6 +840,87 @@ void launch_seed_longest_runs(const uint32_t *xa, int64_t xa_stride, int m_lo, c
     if (n <= 0) return;
     hipLaunchKernelGGL(seed_longest_run_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, xa, xa_stride, m_lo,
                        (const int4 *)seeds, n, out);
+}
+
+// ------------------------------------------------- mostFrequentLongerMotif, batched (a15)
+// parse_seed.cpp:153-256 for every dispatched seed with m > 10 at once.  Every window
+// row_start .. row_start+m-1 of a seed is scored independently (walk down- and upstream in steps of
+// m with a +-2 jitter, count identical bases on the best diagonal), so the rows are the parallel
+// axis: one workgroup per seed, threads stride over its rows; the seed's best (score, smallest row)
+// is kept with a 64-bit atomicMax.  sym = one byte per base: 0..3 = A C G T, 4 = N.
+__global__ __launch_bounds__(256) void sym_kernel(const uint8_t *__restrict__ ascii, int64_t length, uint8_t *__restrict__ sym) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= length) return;
+    const uint32_t c = ascii[i], u = c | 0x20u;
+    const bool valid = (u == 'a') | (u == 'c') | (u == 'g') | (u == 't');
+    sym[i] = valid ? (uint8_t)(((c >> 1) & 3u) ^ ((c >> 2) & 1u)) : (uint8_t)4;
+}
+
+__device__ __forceinline__ int diag_matches(const uint8_t *__restrict__ sym, int row0, int col0, int lo, int hi, int n, int step) {
+    int d = 0;
+    for (int i = 0; i < n; ++i) {
+        const int col = col0 + step * i;
+        if (col >= hi || col < lo) break;
+        const uint8_t a = sym[col];
+        d += (a == sym[row0 + step * i]) & (a < 4);
+    }
+    return d;
+}
+
+__global__ __launch_bounds__(64) void long_motif_rows_kernel(const uint8_t *__restrict__ sym, int64_t length,
+                                                             const int4 *__restrict__ jobs, int64_t njobs,
+                                                             unsigned long long *__restrict__ best) {
+    const int64_t job = blockIdx.x;
+    if (job >= njobs) return;
+    const int4 jb = jobs[job];                 // seed_start, seed_sequence_length, m, unused
+    const int seed_start = jb.x, m = jb.z;
+    int seed_end = jb.x + jb.y;
+    if (seed_end > (int)length) seed_end = (int)length;
+    unsigned long long mine = 0;
+    for (int row = seed_start + (int)threadIdx.x; row < seed_end - m + 1; row += 64) {
+        int score = 0;
+        for (int col = row + m; col < seed_end;) {
+            int pick = -2, top = 0;
+            for (int x = -2; x <= 2; ++x) {
+                const int d = diag_matches(sym, row, col + x, INT_MIN, seed_end, m, 1);
+                if (d > top) { top = d; pick = x; }
+            }
+            score += top;
+            col += pick + m;
+        }
+        int col = row - m;
+        for (; col > seed_start;) {
+            int pick = -2, top = 0;
+            for (int x = -2; x <= 2; ++x) {
+                const int d = diag_matches(sym, row, col + x, 0, INT_MAX, m, 1);
+                if (d > top) { top = d; pick = x; }
+            }
+            score += top;
+            col += pick - m;
+        }
+        if (col < seed_start && abs(col - seed_start) < m) {
+            const int rows = m + (col - seed_start);
+            int top = 0;
+            for (int x = -2; x <= 2; ++x)
+                top = max(top, diag_matches(sym, row + m - 1, seed_start + rows - 1 + x, seed_start, seed_end, rows, -1));
+            score += top;
+        }
+        // larger score wins; among equal scores the smallest row (the reference keeps the first strict maximum)
+        const unsigned long long key = ((unsigned long long)(unsigned)score << 32) | (0xffffffffu - (unsigned)row);
+        if (score > 0 && key > mine) mine = key;
+    }
+    if (mine) atomicMax(&best[job], mine);
+}
+
+void launch_sym(const uint8_t *ascii, int64_t length, uint8_t *sym, hipStream_t stream) {
+    if (length <= 0) return;
+    hipLaunchKernelGGL(sym_kernel, dim3((unsigned)((length + 255) / 256)), dim3(256), 0, stream, ascii, length, sym);
+}
+
+void launch_long_motif_rows(const uint8_t *sym, int64_t length, const void *jobs, int64_t njobs, unsigned long long *best,
+                            hipStream_t stream) {
+    if (njobs <= 0) return;
+    hipLaunchKernelGGL(long_motif_rows_kernel, dim3((unsigned)njobs), dim3(64), 0, stream, sym, length, (const int4 *)jobs, njobs, best);
 }
 
 // ------------------------------------------------------------------- PMC calibration

@@ -3,6 +3,8 @@
 #include "ssw_exact.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <sstream>
 #include <unordered_map>
@@ -27,12 +29,19 @@ struct Wide {
     }
 };
 
+// one byte per base, decoded once per record from the planes the GPU packed: 0..3 = A C G T, 4 = N
 struct Bases {
-    const HostPlanes &hp;
     int L;
-    explicit Bases(const HostPlanes &p) : hp(p), L((int)p.length) {}
-    unsigned code(int p) const { return (((hp.hi[p >> 5] >> (p & 31)) & 1u) << 1) | ((hp.lo[p >> 5] >> (p & 31)) & 1u); }
-    bool is_n(int p) const { return p < L && ((hp.brk[p >> 5] >> (p & 31)) & 1u); }
+    std::vector<uint8_t> sym;
+    explicit Bases(const HostPlanes &hp) : L((int)hp.length), sym((size_t)hp.length + 1, 4) {
+        for (int p = 0; p < L; ++p) {
+            const uint32_t bit = 1u << (p & 31);
+            const size_t w = (size_t)(p >> 5);
+            sym[(size_t)p] = (hp.brk[w] & bit) ? 4 : (uint8_t)((((hp.hi[w] & bit) != 0) << 1) | ((hp.lo[w] & bit) != 0));
+        }
+    }
+    unsigned code(int p) const { return sym[(size_t)p] & 3u; }       // N encodes as 00 (fasta_utils.cpp:111-113)
+    bool is_n(int p) const { return p < L && sym[(size_t)p] == 4; }
 };
 
 // calculateRepeatClass (bitseq_utils.cpp:185-221): lexicographically smallest rotation of an m-base word
@@ -136,7 +145,13 @@ void discover_small_motifs(const Bases &b, int seed_start, int seq_len, int m, i
 // mostFrequentLongerMotif (parse_seed.cpp:153-256): every window row_start..row_start+m-1 of the seed is
 // scored by walking down- and upstream in steps of m with a +-2 jitter, counting identical bases on the
 // best-matching diagonal; the best row's bases form the motif.
-Wide consensus_long_motif(const Bases &b, int seed_start, int seq_len, int m) {
+Wide unit_at(const Bases &b, int row, int m) {                           // parse_seed.cpp:246-253
+    Wide unit;
+    for (int j = row; j < row + m; ++j) unit.push_base(b.code(j));
+    return unit;
+}
+
+int consensus_row(const Bases &b, int seed_start, int seq_len, int m) {
     const int seed_end = std::min(seed_start + seq_len, b.L);
     auto diagonal = [&](int row0, int col0, int lo, int hi, int n, int step) {
         // matches between rows row0, row0+step, ... and columns col0, col0+step, ...; stops at the first
@@ -145,7 +160,7 @@ Wide consensus_long_motif(const Bases &b, int seed_start, int seq_len, int m) {
         for (int i = 0; i < n; ++i) {
             const int col = col0 + step * i, row = row0 + step * i;
             if (col >= hi || col < lo) break;
-            if (!b.is_n(col) && b.code(col) == b.code(row)) ++d;
+            d += b.sym[(size_t)col] == b.sym[(size_t)row] && b.sym[(size_t)col] < 4;
         }
         return d;
     };
@@ -180,9 +195,7 @@ Wide consensus_long_motif(const Bases &b, int seed_start, int seq_len, int m) {
         }
         if (score > best_score) { best_score = score; best_row = row; }
     }
-    Wide unit;
-    for (int j = best_row; j < best_row + m; ++j) unit.push_base(b.code(j));
-    return unit;
+    return best_row;
 }
 
 }  // namespace
@@ -197,8 +210,16 @@ int longest_run_host(const HostPlanes &hp, int mlen, int start, int end) {
     return best;
 }
 
+int usable_length_host(const HostPlanes &hp, int start, int end, int m) {
+    const int L = (int)hp.length;
+    for (int s = start; s < end + m; ++s)
+        if (s < L && ((hp.brk[(size_t)(s >> 5)] >> (s & 31)) & 1u)) return s - start;
+    return (end - start) + m;
+}
+
 void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const std::vector<RibbitSeed> &dispatch,
-                      const int32_t *longest_runs, std::vector<RibbitAlignJob> &jobs, std::string &motif_pool) {
+                      const int32_t *longest_runs, const int32_t *best_rows, std::vector<RibbitAlignJob> &jobs,
+                      std::string &motif_pool) {
     jobs.clear();
     motif_pool.clear();
     const Bases b(hp);
@@ -229,7 +250,8 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
                 jobs.push_back(job);
             }
         } else {
-            const Wide unit = consensus_long_motif(b, seed.start, seq_len, m);
+            const int row = (best_rows && best_rows[i] >= 0) ? best_rows[i] : consensus_row(b, seed.start, seq_len, m);
+            const Wide unit = unit_at(b, row, m);
             job.atomicity = long_atomicity(unit, m);
             if (m % job.atomicity != 0) continue;                                    // parse_seed.cpp:392
             job.query_start = seed.start;
@@ -246,6 +268,16 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
 // ---------------------------------------------------------------------------------------------------
 // Alignment post-processing and BED rows
 namespace {
+
+// RIBBIT_PROFILE=1: wall-clock split of the refinement stages on stderr
+struct Stopwatch {
+    double *acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit Stopwatch(double *a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~Stopwatch() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+double g_t_align = 0, g_t_small = 0, g_t_long = 0, g_t_digest = 0;
+long g_n_align = 0;
 
 struct CigarOp { int len; char op; };
 
@@ -360,7 +392,7 @@ struct Writer {
         std::string ref;
         while ((long)ref.size() <= (long)ppr_len) ref += motif;
         SswResult res;
-        ssw_align(query.data(), (int)query.size(), ref.data(), ppr_len, 15, res);
+        { Stopwatch sw(&g_t_align); ++g_n_align; ssw_align(query.data(), (int)query.size(), ref.data(), ppr_len, 15, res); }
         last_cigar = res.cigar;
         return last_cigar;
     }
@@ -374,7 +406,7 @@ struct Writer {
         if (longest < prm.continuous_ones_threshold) return;
         const int seq_len = usable_length(b, seed.start, seed.end, m);
         std::vector<uint32_t> classes; std::vector<int> starts, ends;
-        discover_small_motifs(b, seed.start, seq_len, m, prm.min_length[m], prm.perfect_units[m], classes, starts, ends);
+        { Stopwatch sw(&g_t_small); discover_small_motifs(b, seed.start, seq_len, m, prm.min_length[m], prm.perfect_units[m], classes, starts, ends); }
         for (size_t k = 0; k < classes.size(); ++k) {
             const int atom = small_atomicity(classes[k], m);
             Wide unit; unit.limb[0] = classes[k];
@@ -387,13 +419,14 @@ struct Writer {
         }
     }
 
-    void long_seed(int start, int end, int m, int type, int longest, int depth) {       // processSeed
+    void long_seed(int start, int end, int m, int type, int longest, int known_row, int depth) {       // processSeed
         if (depth > 10000) return;
         if (end - start < 0.9 * m) return;
         if (longest < 0) longest = longest_run_host(hp, m, start, end);
         if (longest < prm.continuous_ones_threshold) return;
         const int seq_len = usable_length(b, start, end, m);
-        const Wide unit = consensus_long_motif(b, start, seq_len, m);
+        Wide unit;
+        { Stopwatch sw(&g_t_long); unit = unit_at(b, known_row >= 0 ? known_row : consensus_row(b, start, seq_len, m), m); }
         const int atom = long_atomicity(unit, m);
         if (m % atom != 0) return;
         const std::string motif = spell(unit, m, atom);
@@ -404,11 +437,11 @@ struct Writer {
         const int right_from = r.end - atom;
         if (start < r.start) {
             const int left_to = std::min(r.start, end);
-            if (r.start - start >= prm.min_length[m] && !(left_to == end)) long_seed(start, left_to, m, type, -1, depth + 1);
+            if (r.start - start >= prm.min_length[m] && !(left_to == end)) long_seed(start, left_to, m, type, -1, -1, depth + 1);
         }
         if (end - right_from >= prm.min_length[m]) {
             const int from = std::max(right_from, start);
-            if (from != start) long_seed(from, end, m, type, -1, depth + 1);
+            if (from != start) long_seed(from, end, m, type, -1, -1, depth + 1);
         }
     }
 };
@@ -416,16 +449,19 @@ struct Writer {
 }  // namespace
 
 void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
-                   const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const std::string &sequence_id,
-                   std::string &bed) {
+                   const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
+                   const std::string &sequence_id, std::string &bed) {
     const Bases b(hp);
     Writer w{b, hp, sequence, prm, sequence_id, {}, {}};
     for (size_t i = 0; i < dispatch.size(); ++i) {
         const RibbitSeed &seed = dispatch[i];
         if (seed.mlen <= 10) w.small_seed(seed, longest_runs[i]);
-        else w.long_seed(seed.start, seed.end, seed.mlen, seed.type, longest_runs[i], 0);
+        else w.long_seed(seed.start, seed.end, seed.mlen, seed.type, longest_runs[i], best_rows ? best_rows[i] : -1, 0);
     }
     bed += w.os.str();
+    if (std::getenv("RIBBIT_PROFILE"))
+        std::fprintf(stderr, "[refine] seeds %zu  alignments %ld  align %.2fs  small-motif discovery %.2fs  long-motif consensus %.2fs\n",
+                     dispatch.size(), g_n_align, g_t_align, g_t_small, g_t_long);
 }
 
 }  // namespace rb

@@ -16,9 +16,15 @@
 
 namespace rb {
 
-// longest_runs[i] = longestContinuousMatches of dispatch seed i on its composed plane
+// longest_runs[i] = longestContinuousMatches of dispatch seed i on its composed plane.
+// best_rows (may be null): for seeds with m > 10, the window start mostFrequentLongerMotif selects
+// (computed by long_motif_rows_kernel), or -1 to compute it on the host.
 void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const std::vector<RibbitSeed> &dispatch,
-                      const int32_t *longest_runs, std::vector<RibbitAlignJob> &jobs, std::string &motif_pool);
+                      const int32_t *longest_runs, const int32_t *best_rows, std::vector<RibbitAlignJob> &jobs,
+                      std::string &motif_pool);
+
+// seed_sequence_length of parse_seed.cpp:342-349: seed + one motif, cut at the first N
+int usable_length_host(const HostPlanes &hp, int start, int end, int m);
 
 // host computation of the same quantity from the host copy of the composed planes (used by
 // ribbit_host_refine_jobs, which has no device)
@@ -29,7 +35,7 @@ int longest_run_host(const HostPlanes &hp, int mlen, int start, int end);
 // (parse_seed.cpp:318-464) for m > 10, alignment by ssw_exact, CIGAR processing (process_cigar.cpp:126-336),
 // and the BED rows (11 tab-separated columns) appended to `bed`.  sequence = the record's bases.
 void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
-                   const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const std::string &sequence_id,
-                   std::string &bed);
+                   const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
+                   const std::string &sequence_id, std::string &bed);
 
 }  // namespace rb

@@ -6,10 +6,12 @@
 // tie-breaks, and those depend on the striped evaluation order: the lazy-F loop
 // stops early and never refreshes E, so scores are a function of the 16-/8-lane striping.  This
 // file therefore evaluates the recurrences in exactly the library's striped order -- vector j,
-// lane l  <->  query position j + l*segLen -- with plain scalar lanes (no intrinsics; the compiler
-// vectorises the lane loops).  Written from the algorithm's description; no library code is used.
+// lane l  <->  query position j + l*segLen.  Written from the algorithm's description (host SSE2);
+// no library code is used.
 // Pinned in tests/test_ssw.py against the reference library itself (oracle/_ref/libssw_ref.so).
 #include "ssw_exact.h"
+
+#include <emmintrin.h>
 
 #include <algorithm>
 #include <cstdlib>
@@ -39,90 +41,96 @@ inline int8_t translate(char c) {          // kBaseTranslation, ssw_cpp.cpp:12-2
 
 struct Ends { int score, ref, read, score2, ref2; };
 
-inline uint8_t sat_add_u8(uint8_t a, uint8_t b) { const int s = a + b; return (uint8_t)(s > 255 ? 255 : s); }
-inline uint8_t sat_sub_u8(uint8_t a, uint8_t b) { return (uint8_t)(a > b ? a - b : 0); }
-inline int16_t sat_add_i16(int16_t a, int16_t b) { const int s = a + b; return (int16_t)(s > 32767 ? 32767 : (s < -32768 ? -32768 : s)); }
-inline int16_t sat_sub_u16(int16_t a, int16_t b) {     // _mm_subs_epu16 on the bit patterns
-    const uint16_t x = (uint16_t)a, y = (uint16_t)b;
-    return (int16_t)(uint16_t)(x > y ? x - y : 0);
+
+// The two striped passes below are the inner loops of refinement (two of them per alignment over the
+// whole pseudo-perfect repeat), so they are written with SSE2 intrinsics: one __m128i = one stripe of 16
+// (8-bit pass) or 8 (16-bit pass) query positions, exactly the lane order described at the top.
+
+inline int hmax_u8(__m128i v) {
+    v = _mm_max_epu8(v, _mm_srli_si128(v, 8));
+    v = _mm_max_epu8(v, _mm_srli_si128(v, 4));
+    v = _mm_max_epu8(v, _mm_srli_si128(v, 2));
+    v = _mm_max_epu8(v, _mm_srli_si128(v, 1));
+    return _mm_extract_epi16(v, 0) & 0xff;
+}
+inline int hmax_i16(__m128i v) {
+    v = _mm_max_epi16(v, _mm_srli_si128(v, 8));
+    v = _mm_max_epi16(v, _mm_srli_si128(v, 4));
+    v = _mm_max_epi16(v, _mm_srli_si128(v, 2));
+    return _mm_extract_epi16(v, 0) & 0xffff;
 }
 
 // 8-bit striped pass (ssw.c:197-386).  dir 0: ref left to right, 1: right to left.
 // Returns score 255 when the byte range overflowed (the caller then switches to 16 bits).
 Ends striped_pass_u8(const int8_t *ref, int dir, int ref_len, const int8_t *read, int read_len, int terminate, int mask_len) {
     constexpr int W = 16;
-    const uint8_t bias = MISMATCH, gap_o = GAP_OPEN, gap_e = GAP_EXTEND;
+    const uint8_t bias = MISMATCH;
     const int seg = (read_len + W - 1) / W;
-    std::vector<uint8_t> profile((size_t)NSYM * seg * W);
-    for (int nt = 0; nt < NSYM; ++nt)
-        for (int j = 0; j < seg; ++j)
-            for (int l = 0; l < W; ++l) {
-                const int q = j + l * seg;
-                profile[((size_t)nt * seg + j) * W + l] = (uint8_t)(q >= read_len ? bias : score_of(nt, read[q]) + bias);
-            }
-    std::vector<uint8_t> buf_a((size_t)seg * W, 0), buf_b((size_t)seg * W, 0), E((size_t)seg * W, 0), h_best((size_t)seg * W, 0);
+    std::vector<__m128i> profile((size_t)NSYM * seg);
+    {
+        uint8_t *t = reinterpret_cast<uint8_t *>(profile.data());
+        for (int nt = 0; nt < NSYM; ++nt)
+            for (int j = 0; j < seg; ++j)
+                for (int l = 0; l < W; ++l) {
+                    const int q = j + l * seg;
+                    *t++ = (uint8_t)(q >= read_len ? bias : score_of(nt, read[q]) + bias);
+                }
+    }
+    const __m128i zero = _mm_setzero_si128();
+    std::vector<__m128i> buf_a((size_t)seg, zero), buf_b((size_t)seg, zero), E((size_t)seg, zero), h_best((size_t)seg, zero);
     std::vector<uint8_t> col_max((size_t)ref_len, 0);
-    uint8_t *h_store = buf_a.data(), *h_load = buf_b.data();
-    uint8_t run_max[W] = {0}, run_mark[W] = {0};
+    __m128i *h_store = buf_a.data(), *h_load = buf_b.data();
+    const __m128i v_gap_o = _mm_set1_epi8(GAP_OPEN), v_gap_e = _mm_set1_epi8(GAP_EXTEND), v_bias = _mm_set1_epi8((char)bias);
+    __m128i run_max = zero, run_mark = zero;
     int best = 0, end_ref = -1;
     const int begin = dir ? ref_len - 1 : 0, stop = dir ? -1 : ref_len, step = dir ? -1 : 1;
     for (int i = begin; i != stop; i += step) {
-        uint8_t F[W] = {0}, cmax[W] = {0}, H[W];
-        H[0] = 0;
-        for (int l = 1; l < W; ++l) H[l] = h_store[(size_t)(seg - 1) * W + l - 1];   // last vector shifted up one lane
-        const uint8_t *P = &profile[(size_t)ref[i] * seg * W];
+        __m128i F = zero, cmax = zero;
+        __m128i H = _mm_slli_si128(h_store[seg - 1], 1);            // last stripe, moved up one lane
+        const __m128i *P = &profile[(size_t)ref[i] * seg];
         std::swap(h_store, h_load);
         for (int j = 0; j < seg; ++j) {
-            uint8_t *e = &E[(size_t)j * W], *hs = &h_store[(size_t)j * W];
-            const uint8_t *hl = &h_load[(size_t)j * W], *p = P + (size_t)j * W;
-            for (int l = 0; l < W; ++l) {
-                uint8_t h = sat_sub_u8(sat_add_u8(H[l], p[l]), bias);
-                h = std::max(h, e[l]);
-                h = std::max(h, F[l]);
-                cmax[l] = std::max(cmax[l], h);
-                hs[l] = h;
-                h = sat_sub_u8(h, gap_o);
-                e[l] = std::max(sat_sub_u8(e[l], gap_e), h);
-                F[l] = std::max(sat_sub_u8(F[l], gap_e), h);
-                H[l] = hl[l];
-            }
+            H = _mm_subs_epu8(_mm_adds_epu8(H, P[j]), v_bias);
+            __m128i e = E[(size_t)j];
+            H = _mm_max_epu8(_mm_max_epu8(H, e), F);
+            cmax = _mm_max_epu8(cmax, H);
+            h_store[j] = H;
+            H = _mm_subs_epu8(H, v_gap_o);
+            E[(size_t)j] = _mm_max_epu8(_mm_subs_epu8(e, v_gap_e), H);
+            F = _mm_max_epu8(_mm_subs_epu8(F, v_gap_e), H);
+            H = h_load[j];
         }
-        // lazy F: propagate F across the lane boundary until it can no longer raise any H
+        // lazy F: carry F across the lane boundary until it can no longer raise any H (E is not refreshed)
         bool settled = false;
         for (int k = 0; k < W && !settled; ++k) {
-            for (int l = W - 1; l > 0; --l) F[l] = F[l - 1];
-            F[0] = 0;
-            for (int j = 0; j < seg && !settled; ++j) {
-                uint8_t *hs = &h_store[(size_t)j * W];
-                bool none = true;
-                for (int l = 0; l < W; ++l) {
-                    const uint8_t h = std::max(hs[l], F[l]);
-                    cmax[l] = std::max(cmax[l], h);
-                    hs[l] = h;
-                    F[l] = sat_sub_u8(F[l], gap_e);
-                    if (sat_sub_u8(F[l], sat_sub_u8(h, gap_o)) != 0) none = false;
-                }
-                settled = none;
+            F = _mm_slli_si128(F, 1);
+            for (int j = 0; j < seg; ++j) {
+                __m128i h = _mm_max_epu8(h_store[j], F);
+                cmax = _mm_max_epu8(cmax, h);
+                h_store[j] = h;
+                h = _mm_subs_epu8(h, v_gap_o);
+                F = _mm_subs_epu8(F, v_gap_e);
+                if (_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_subs_epu8(F, h), zero)) == 0xffff) { settled = true; break; }
             }
         }
-        bool changed = false;
-        for (int l = 0; l < W; ++l) { run_max[l] = std::max(run_max[l], cmax[l]); changed |= run_max[l] != run_mark[l]; }
-        if (changed) {
-            std::memcpy(run_mark, run_max, W);
-            const int top = *std::max_element(run_max, run_max + W);
+        run_max = _mm_max_epu8(run_max, cmax);
+        if (_mm_movemask_epi8(_mm_cmpeq_epi8(run_mark, run_max)) != 0xffff) {
+            run_mark = run_max;
+            const int top = hmax_u8(run_max);
             if (top > best) {
                 best = top;
                 if (best + bias >= 255) break;
                 end_ref = i;
-                std::memcpy(h_best.data(), h_store, (size_t)seg * W);
+                std::memcpy(h_best.data(), h_store, (size_t)seg * sizeof(__m128i));
             }
         }
-        col_max[(size_t)i] = *std::max_element(cmax, cmax + W);
+        col_max[(size_t)i] = (uint8_t)hmax_u8(cmax);
         if (col_max[(size_t)i] == (uint8_t)terminate) break;
     }
     int end_read = read_len - 1;
+    const uint8_t *hb = reinterpret_cast<const uint8_t *>(h_best.data());
     for (int idx = 0; idx < seg * W; ++idx)
-        if (h_best[(size_t)idx] == best) end_read = std::min(end_read, idx / W + idx % W * seg);
+        if (hb[idx] == best) end_read = std::min(end_read, idx / W + idx % W * seg);
     Ends r{best + bias >= 255 ? 255 : best, end_ref, end_read, 0, 0};
     int edge = std::max(end_ref - mask_len, 0);
     for (int i = 0; i < edge; ++i) if (col_max[(size_t)i] > r.score2) { r.score2 = col_max[(size_t)i]; r.ref2 = i; }
@@ -134,76 +142,70 @@ Ends striped_pass_u8(const int8_t *ref, int dir, int ref_len, const int8_t *read
 // 16-bit striped pass (ssw.c:412-588): signed add / max, unsigned saturating subtract.
 Ends striped_pass_i16(const int8_t *ref, int dir, int ref_len, const int8_t *read, int read_len, int terminate, int mask_len) {
     constexpr int W = 8;
-    const int16_t gap_o = GAP_OPEN, gap_e = GAP_EXTEND;
     const int seg = (read_len + W - 1) / W;
-    std::vector<int16_t> profile((size_t)NSYM * seg * W);
-    for (int nt = 0; nt < NSYM; ++nt)
-        for (int j = 0; j < seg; ++j)
-            for (int l = 0; l < W; ++l) {
-                const int q = j + l * seg;
-                profile[((size_t)nt * seg + j) * W + l] = (int16_t)(q >= read_len ? 0 : score_of(nt, read[q]));
-            }
-    std::vector<int16_t> buf_a((size_t)seg * W, 0), buf_b((size_t)seg * W, 0), E((size_t)seg * W, 0), h_best((size_t)seg * W, 0);
+    std::vector<__m128i> profile((size_t)NSYM * seg);
+    {
+        int16_t *t = reinterpret_cast<int16_t *>(profile.data());
+        for (int nt = 0; nt < NSYM; ++nt)
+            for (int j = 0; j < seg; ++j)
+                for (int l = 0; l < W; ++l) {
+                    const int q = j + l * seg;
+                    *t++ = (int16_t)(q >= read_len ? 0 : score_of(nt, read[q]));
+                }
+    }
+    const __m128i zero = _mm_setzero_si128();
+    std::vector<__m128i> buf_a((size_t)seg, zero), buf_b((size_t)seg, zero), E((size_t)seg, zero), h_best((size_t)seg, zero);
     std::vector<uint16_t> col_max((size_t)ref_len, 0);
-    int16_t *h_store = buf_a.data(), *h_load = buf_b.data();
-    int16_t run_max[W] = {0}, run_mark[W] = {0};
+    __m128i *h_store = buf_a.data(), *h_load = buf_b.data();
+    const __m128i v_gap_o = _mm_set1_epi16(GAP_OPEN), v_gap_e = _mm_set1_epi16(GAP_EXTEND);
+    __m128i run_max = zero, run_mark = zero;
     int best = 0, end_ref = 0;
     const int begin = dir ? ref_len - 1 : 0, stop = dir ? -1 : ref_len, step = dir ? -1 : 1;
     for (int i = begin; i != stop; i += step) {
-        int16_t F[W] = {0}, cmax[W] = {0}, H[W];
-        H[0] = 0;
-        for (int l = 1; l < W; ++l) H[l] = h_store[(size_t)(seg - 1) * W + l - 1];
-        const int16_t *P = &profile[(size_t)ref[i] * seg * W];
+        __m128i F = zero, cmax = zero;
+        __m128i H = _mm_slli_si128(h_store[seg - 1], 2);
+        const __m128i *P = &profile[(size_t)ref[i] * seg];
         std::swap(h_store, h_load);
         for (int j = 0; j < seg; ++j) {
-            int16_t *e = &E[(size_t)j * W], *hs = &h_store[(size_t)j * W];
-            const int16_t *hl = &h_load[(size_t)j * W], *p = P + (size_t)j * W;
-            for (int l = 0; l < W; ++l) {
-                int16_t h = sat_add_i16(H[l], p[l]);
-                h = std::max(h, e[l]);
-                h = std::max(h, F[l]);
-                cmax[l] = std::max(cmax[l], h);
-                hs[l] = h;
-                h = sat_sub_u16(h, gap_o);
-                e[l] = std::max(sat_sub_u16(e[l], gap_e), h);
-                F[l] = std::max(sat_sub_u16(F[l], gap_e), h);
-                H[l] = hl[l];
-            }
+            H = _mm_adds_epi16(H, P[j]);
+            __m128i e = E[(size_t)j];
+            H = _mm_max_epi16(_mm_max_epi16(H, e), F);
+            cmax = _mm_max_epi16(cmax, H);
+            h_store[j] = H;
+            H = _mm_subs_epu16(H, v_gap_o);
+            E[(size_t)j] = _mm_max_epi16(_mm_subs_epu16(e, v_gap_e), H);
+            F = _mm_max_epi16(_mm_subs_epu16(F, v_gap_e), H);
+            H = h_load[j];
         }
         bool settled = false;
         for (int k = 0; k < W && !settled; ++k) {
-            for (int l = W - 1; l > 0; --l) F[l] = F[l - 1];
-            F[0] = 0;
-            for (int j = 0; j < seg && !settled; ++j) {
-                int16_t *hs = &h_store[(size_t)j * W];
-                bool none = true;
-                for (int l = 0; l < W; ++l) {
-                    const int16_t h = std::max(hs[l], F[l]);
-                    cmax[l] = std::max(cmax[l], h);
-                    hs[l] = h;
-                    F[l] = sat_sub_u16(F[l], gap_e);
-                    if (F[l] > sat_sub_u16(h, gap_o)) none = false;
-                }
-                settled = none;
+            F = _mm_slli_si128(F, 2);
+            for (int j = 0; j < seg; ++j) {
+                __m128i h = _mm_max_epi16(h_store[j], F);
+                cmax = _mm_max_epi16(cmax, h);
+                h_store[j] = h;
+                h = _mm_subs_epu16(h, v_gap_o);
+                F = _mm_subs_epu16(F, v_gap_e);
+                if (!_mm_movemask_epi8(_mm_cmpgt_epi16(F, h))) { settled = true; break; }
             }
         }
-        bool changed = false;
-        for (int l = 0; l < W; ++l) { run_max[l] = std::max(run_max[l], cmax[l]); changed |= run_max[l] != run_mark[l]; }
-        if (changed) {
-            std::memcpy(run_mark, run_max, sizeof run_max);
-            const int top = (uint16_t)*std::max_element(run_max, run_max + W);
+        run_max = _mm_max_epi16(run_max, cmax);
+        if (_mm_movemask_epi8(_mm_cmpeq_epi16(run_mark, run_max)) != 0xffff) {
+            run_mark = run_max;
+            const int top = hmax_i16(run_max);
             if (top > best) {
                 best = top;
                 end_ref = i;
-                std::memcpy(h_best.data(), h_store, (size_t)seg * W * sizeof(int16_t));
+                std::memcpy(h_best.data(), h_store, (size_t)seg * sizeof(__m128i));
             }
         }
-        col_max[(size_t)i] = (uint16_t)*std::max_element(cmax, cmax + W);
+        col_max[(size_t)i] = (uint16_t)hmax_i16(cmax);
         if (col_max[(size_t)i] == (uint16_t)terminate) break;
     }
     int end_read = read_len - 1;
+    const uint16_t *hb = reinterpret_cast<const uint16_t *>(h_best.data());
     for (int idx = 0; idx < seg * W; ++idx)
-        if ((uint16_t)h_best[(size_t)idx] == (uint16_t)best) end_read = std::min(end_read, idx / W + idx % W * seg);
+        if (hb[idx] == (uint16_t)best) end_read = std::min(end_read, idx / W + idx % W * seg);
     Ends r{best, end_ref, end_read, 0, 0};
     int edge = std::max(end_ref - mask_len, 0);
     for (int i = 0; i < edge; ++i) if (col_max[(size_t)i] > r.score2) { r.score2 = col_max[(size_t)i]; r.ref2 = i; }
