@@ -6,7 +6,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <sstream>
+#include <thread>
 #include <unordered_map>
 
 namespace rb {
@@ -276,7 +278,8 @@ struct Stopwatch {
     explicit Stopwatch(double *a) : acc(a), t0(std::chrono::steady_clock::now()) {}
     ~Stopwatch() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
-double g_t_align = 0, g_t_small = 0, g_t_long = 0, g_t_digest = 0;
+// (profiling only; the sums are racy across threads and therefore approximate)
+double g_t_align = 0, g_t_small = 0, g_t_long = 0;
 long g_n_align = 0;
 
 struct CigarOp { int len; char op; };
@@ -387,8 +390,9 @@ struct Writer {
         if (start >= b.L || len <= 0) return std::string();
         return std::string(sequence + start, (size_t)std::min(len, b.L - start));
     }
+    bool saw_empty_query = false;   // the one order dependence between seeds: see refine_to_bed
     std::string align(const std::string &query, const std::string &motif, int ppr_len) {
-        if (query.empty()) return last_cigar;
+        if (query.empty()) { saw_empty_query = true; return last_cigar; }
         std::string ref;
         while ((long)ref.size() <= (long)ppr_len) ref += motif;
         SswResult res;
@@ -452,16 +456,50 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
                    const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
                    const std::string &sequence_id, std::string &bed) {
     const Bases b(hp);
-    Writer w{b, hp, sequence, prm, sequence_id, {}, {}};
-    for (size_t i = 0; i < dispatch.size(); ++i) {
-        const RibbitSeed &seed = dispatch[i];
-        if (seed.mlen <= 10) w.small_seed(seed, longest_runs[i]);
-        else w.long_seed(seed.start, seed.end, seed.mlen, seed.type, longest_runs[i], best_rows ? best_rows[i] : -1, 0);
+    auto run_range = [&](size_t lo, size_t hi, Writer &w) {
+        for (size_t i = lo; i < hi; ++i) {
+            const RibbitSeed &seed = dispatch[i];
+            if (seed.mlen <= 10) w.small_seed(seed, longest_runs[i]);
+            else w.long_seed(seed.start, seed.end, seed.mlen, seed.type, longest_runs[i], best_rows ? best_rows[i] : -1, 0);
+        }
+    };
+    // Seeds are refined independently of each other, except that an alignment with an EMPTY query leaves the
+    // reference's shared Alignment object untouched and so sees the previous seed's CIGAR.  Chunks of seeds
+    // therefore run on host threads with their own writers, concatenated in seed order; if any chunk met an
+    // empty query the record is redone sequentially.
+    unsigned threads = std::thread::hardware_concurrency();
+    if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
+    threads = std::max(1u, std::min(threads, 64u));
+    if (dispatch.size() < 4096) threads = 1;
+    bool sequential = threads == 1;
+    if (!sequential) {
+        const size_t chunk = 2048;
+        const size_t nchunks = (dispatch.size() + chunk - 1) / chunk;
+        std::vector<std::string> parts(nchunks);
+        std::atomic<size_t> next{0};
+        std::atomic<bool> empty_seen{false};
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t)
+            pool.emplace_back([&]() {
+                for (size_t c; (c = next.fetch_add(1)) < nchunks;) {
+                    Writer w{b, hp, sequence, prm, sequence_id, {}, {}};
+                    run_range(c * chunk, std::min(dispatch.size(), (c + 1) * chunk), w);
+                    if (w.saw_empty_query) empty_seen = true;
+                    parts[c] = w.os.str();
+                }
+            });
+        for (std::thread &th : pool) th.join();
+        if (empty_seen) sequential = true;
+        else for (const std::string &p : parts) bed += p;
     }
-    bed += w.os.str();
+    if (sequential) {
+        Writer w{b, hp, sequence, prm, sequence_id, {}, {}};
+        run_range(0, dispatch.size(), w);
+        bed += w.os.str();
+    }
     if (std::getenv("RIBBIT_PROFILE"))
-        std::fprintf(stderr, "[refine] seeds %zu  alignments %ld  align %.2fs  small-motif discovery %.2fs  long-motif consensus %.2fs\n",
-                     dispatch.size(), g_n_align, g_t_align, g_t_small, g_t_long);
+        std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld  (summed over threads) align %.2fs  small-motif discovery %.2fs  long-motif consensus %.2fs\n",
+                     dispatch.size(), threads, g_n_align, g_t_align, g_t_small, g_t_long);
 }
 
 }  // namespace rb
