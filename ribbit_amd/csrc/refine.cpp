@@ -467,9 +467,9 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
     // reference's shared Alignment object untouched and so sees the previous seed's CIGAR.  Chunks of seeds
     // therefore run on host threads with their own writers, concatenated in seed order; if any chunk met an
     // empty query the record is redone sequentially.
-    unsigned threads = std::thread::hardware_concurrency();
+    unsigned threads = std::min(std::thread::hardware_concurrency(), 16u);      // one GPU's share of the host by default
     if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
-    threads = std::max(1u, std::min(threads, 64u));
+    threads = std::max(1u, std::min(threads, 256u));
     if (dispatch.size() < 4096) threads = 1;
     bool sequential = threads == 1;
     if (!sequential) {
