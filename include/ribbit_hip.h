@@ -286,6 +286,44 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
                              RibbitSeedLists *out);
 void ribbit_seed_lists_free(RibbitSeedLists *lists);
 
+/*
+ * ---- chunk-sharded operation: one long record scanned by several GPUs ----------------------------
+ * Every scan kernel's output is a stream of events whose values depend on the sequence only within a
+ * bounded distance (perfect: 32 + M+2 bases to the right, 33 to the left; window scans: 8 + M+2 / 1;
+ * anchored: 4*(M+2) + 16 / 2*(M+2) + 8).  A rank therefore loads its chunk plus halos as a record of
+ * its own, scans it, and keeps only the events whose position lies in the range it owns; the ranks'
+ * events are exchanged (all-gather-v over RCCL) and one host replays pairing, state machines and the
+ * order-dependent merges on the union exactly as for a single GPU.
+ *
+ * Events are 64-bit: bits 0-31 position, 32-47 motif length, 48-51 kind (0 START, 1 END closed by a
+ * mismatch / failing window, 2 END at an N, 3 END at the end of the loaded record).
+ */
+#define RIBBIT_EVENT_POS(e)  ((uint32_t)(e))
+#define RIBBIT_EVENT_MLEN(e) ((uint32_t)((e) >> 32) & 0xffffu)
+#define RIBBIT_EVENT_KIND(e) ((uint32_t)((e) >> 48) & 0xfu)
+enum { RIBBIT_STAGE_PERFECT = 0, RIBBIT_STAGE_SUBST = 1, RIBBIT_STAGE_ANCHORED = 2 };
+
+/* Run stage's scan kernel on the loaded (sub)record and return the events with local position in
+ * [own_lo, own_hi), motif-major and position-ordered, positions shifted by pos_offset.
+ * per_motif_counts receives max_motif-min_motif+1 counts.  Handle-owned memory. */
+int ribbit_hip_stage_events(RibbitHandle *h, int stage, int64_t own_lo, int64_t own_hi, int64_t pos_offset,
+                            const uint64_t **events, size_t *n, const uint64_t **per_motif_counts);
+
+/* Words [word_lo, word_hi) of every composed plane XA_m (after the anchored stage's kernel ran),
+ * motif-major, into out[(max_motif-min_motif+1) * (word_hi-word_lo)]. */
+int ribbit_hip_xa_words(RibbitHandle *h, int64_t word_lo, int64_t word_hi, uint32_t *out);
+
+/* Host-only: the whole path from gathered events.  ev_* hold nparts parts back to back (each part
+ * motif-major), cnt_*[part * nm + motif_index] their per-motif counts; parts must own increasing,
+ * disjoint position ranges.  Planes cover the whole record (see ribbit_host_replay_calls). */
+int ribbit_host_scan_from_events(const RibbitScanParams *params, int64_t length,
+                                 const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
+                                 const uint32_t *xa, size_t xa_stride, size_t nparts,
+                                 const uint64_t *ev_perfect, const uint64_t *cnt_perfect,
+                                 const uint64_t *ev_subst, const uint64_t *cnt_subst,
+                                 const uint64_t *ev_anchored, const uint64_t *cnt_anchored,
+                                 RibbitSeedLists *out);
+
 /* Timing of the last call, milliseconds.  what: 0 pack kernel, 1 last scan kernel, 2 GPU side of
  * the last scan (kernel + compaction + read-back), all by HIP events on the launch stream;
  * 3 host post-processing of the last scan (wall clock). */

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "device_planes.h"
+#include "event_stream.h"
 #include "host_planes.h"
 #include "kernels.h"
 #include "refine.h"
@@ -136,6 +137,7 @@ struct RibbitHandle {
     std::vector<int32_t> best_rows;       // per dispatch seed: mostFrequentLongerMotif's window start, or -1
     std::vector<RibbitAlignJob> jobs;
     std::string motif_pool;
+    std::vector<uint64_t> export_events, export_counts;
     std::string host_ascii;   // the record's bases on the host (refinement slices them for the aligner)
     bool host_ascii_valid = false;
     const uint8_t *dev_ascii_src = nullptr;
@@ -292,80 +294,35 @@ int collect_events(RibbitHandle *h, int which) {
     return RIBBIT_OK;
 }
 
-// Visit the events of motif index mi in position order: fn(pos, kind) -> false aborts.
-template <typename Fn>
-bool for_each_event(const RibbitHandle *h, size_t mi, Fn fn) {
-    struct Chunk { uint32_t off, n; };
-    const Chunk *table = reinterpret_cast<const Chunk *>(h->chunk_table.data()) + mi * h->table_ntile;
-    const uint64_t *ev = h->h_events.p;
-    for (size_t t = 0; t < h->table_ntile; ++t) {
-        const Chunk c = table[t];
-        for (uint32_t i = c.off; i < c.off + c.n; ++i)
-            if (!fn((int64_t)rb::ev_pos(ev[i]), rb::ev_kind(ev[i]))) return false;
-    }
-    return true;
+rb::EventSource event_source(const RibbitHandle *h) {
+    rb::EventSource src;
+    src.ev = h->h_events.p;
+    src.segs = reinterpret_cast<const rb::Seg *>(h->chunk_table.data());
+    src.segs_per_motif = h->table_ntile;
+    src.nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
+    src.m_lo = h->params.min_motif;
+    return src;
 }
-
-// c1 / c2 of parse_perfect_shiftxor.cpp:193 / :179
-inline int cutoff_zero(int m) { return (m <= 6) ? 12 - m : m; }
-inline int cutoff_n(int m, int min_shift) { return (m <= 6) ? 12 - m : m + (m - min_shift); }
 
 int run_perfect_scan(RibbitHandle *h) {
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
     if (h->runs_valid) return RIBBIT_OK;
-    h->runs.clear();
     int rc = collect_events(h, 0);
     if (rc) return rc;
     const double t0 = now_ms();
-    const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
+    std::string why;
     h->runs.reserve(h->produced / 2);
-    for (size_t mi = 0; mi < nm; ++mi) {
-        const int32_t mlen = h->params.min_motif + (int32_t)mi;
-        int64_t open = -1;
-        bool bad = false;
-        for_each_event(h, mi, [&](int64_t pos, uint32_t kind) {
-            if (kind == rb::EV_START) {
-                if (open != -1) { bad = true; return false; }
-                open = pos;
-            } else {
-                if (open == -1 || pos <= open) { bad = true; return false; }
-                const int term = kind == rb::EV_END_ZERO ? RIBBIT_TERM_ZERO : kind == rb::EV_END_N ? RIBBIT_TERM_N : RIBBIT_TERM_EOS;
-                h->runs.push_back(RibbitRun{(int32_t)open, (int32_t)pos, mlen, term});
-                open = -1;
-            }
-            return true;
-        });
-        if (bad || open != -1) return fail(RIBBIT_E_INTERNAL, "run START/END events of motif %d do not alternate", mlen);
-    }
+    if (!rb::pair_perfect_runs(event_source(h), h->runs, &why)) return fail(RIBBIT_E_INTERNAL, "%s", why.c_str());
     h->host_ms = now_ms() - t0;
     h->runs_valid = true;
     return RIBBIT_OK;
-}
-
-void sort_calls(std::vector<RibbitCall> &calls) {
-    // reference call order: scan position major, motif minor; the end-of-sequence flush (pos == L) last
-    std::stable_sort(calls.begin(), calls.end(), [](const RibbitCall &a, const RibbitCall &b) {
-        return a.pos != b.pos ? a.pos < b.pos : a.mlen < b.mlen;
-    });
 }
 
 int build_perfect_calls(RibbitHandle *h) {
     if (h->calls_valid) return RIBBIT_OK;
     int rc = run_perfect_scan(h);
     if (rc) return rc;
-    h->perfect_calls.clear();
-    const int32_t L = (int32_t)h->length;
-    for (const RibbitRun &r : h->runs) {
-        const int len = r.end - r.start;
-        if (r.term == RIBBIT_TERM_ZERO) {                       // parse_perfect_shiftxor.cpp:199-205
-            if (len >= cutoff_zero(r.mlen)) h->perfect_calls.push_back(RibbitCall{r.end, r.mlen, r.start, r.end});
-        } else if (r.term == RIBBIT_TERM_N) {                   // :175-186
-            if (len >= cutoff_n(r.mlen, h->min_shift)) h->perfect_calls.push_back(RibbitCall{r.end, r.mlen, r.start, r.end});
-        } else {                                                // :213-223, flushed with end = L-1
-            if ((L - 1) - r.start >= cutoff_zero(r.mlen)) h->perfect_calls.push_back(RibbitCall{L, r.mlen, r.start, L - 1});
-        }
-    }
-    sort_calls(h->perfect_calls);
+    rb::perfect_calls_from_runs(h->runs, h->length, h->min_shift, h->perfect_calls);
     h->calls_valid = true;
     return RIBBIT_OK;
 }
@@ -380,76 +337,6 @@ int advance_to_perfect(RibbitHandle *h) {
     return RIBBIT_OK;
 }
 
-// Replay of the per-motif window state machines over the indexed events, tile by tile, producing the
-// call list in the reference's call order (scan position major, motif minor, end-of-sequence flush
-// last) without a global sort: every tile's calls are generated motif by motif, pending groups are
-// settled as soon as their reporting window is known to precede the next tile, and the batch is
-// ordered with two stable counting sorts (motif, then position).  O(events + calls).
-int replay_window_events(RibbitHandle *h, uint32_t tile_bases, std::vector<RibbitCall> &calls) {
-    calls.clear();
-    const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
-    const int32_t m_lo = h->params.min_motif;
-    std::vector<rb::WindowFsm> fsm;
-    fsm.reserve(nm);
-    for (size_t mi = 0; mi < nm; ++mi) fsm.emplace_back(h->host, m_lo + (int32_t)mi);
-    struct Chunk { uint32_t off, n; };
-    const Chunk *table = reinterpret_cast<const Chunk *>(h->chunk_table.data());
-    const uint64_t *ev = h->h_events.p;
-    std::vector<RibbitCall> batch, by_motif, carry;
-    std::vector<uint32_t> count;
-    int64_t flushed_below = 0;   // every call with pos < flushed_below has been written to `calls`
-    for (size_t t = 0; t < h->table_ntile; ++t) {
-        const int64_t next_tile = (int64_t)(t + 1) * tile_bases;
-        batch.swap(carry);
-        carry.clear();
-        for (size_t mi = 0; mi < nm; ++mi) {
-            rb::WindowFsm &f = fsm[mi];
-            f.set_output(&batch);
-            const Chunk c = table[mi * h->table_ntile + t];
-            for (uint32_t i = c.off; i < c.off + c.n; ++i)
-                if (!f.event((int64_t)rb::ev_pos(ev[i]), rb::ev_kind(ev[i])))
-                    return fail(RIBBIT_E_INTERNAL, "window START/END events of motif %d do not alternate", m_lo + (int)mi);
-            f.settle_up_to(next_tile);
-        }
-        // calls generated from here on have pos >= next_tile + 7, so everything below next_tile is final
-        if (batch.empty()) { flushed_below = next_tile; continue; }
-        by_motif.resize(batch.size());
-        count.assign(nm + 1, 0);
-        for (const RibbitCall &c : batch) ++count[(size_t)(c.mlen - m_lo) + 1];
-        for (size_t k = 0; k < nm; ++k) count[k + 1] += count[k];
-        for (const RibbitCall &c : batch) by_motif[count[(size_t)(c.mlen - m_lo)]++] = c;
-        const int64_t span = next_tile - flushed_below;
-        count.assign((size_t)span + 2, 0);
-        for (const RibbitCall &c : by_motif) {
-            if (c.pos < flushed_below) return fail(RIBBIT_E_INTERNAL, "call generated out of order (pos %d)", c.pos);
-            if (c.pos < next_tile) ++count[(size_t)(c.pos - flushed_below) + 1];
-        }
-        for (int64_t k = 0; k < span; ++k) count[(size_t)k + 1] += count[(size_t)k];
-        const size_t base = calls.size();
-        calls.resize(base + count[(size_t)span]);
-        for (const RibbitCall &c : by_motif) {
-            if (c.pos < next_tile) calls[base + count[(size_t)(c.pos - flushed_below)]++] = c;
-            else carry.push_back(c);
-        }
-        flushed_below = next_tile;
-    }
-    // leftovers beyond the last tile boundary (pos up to L-1), then the end-of-sequence flush in motif order
-    std::stable_sort(carry.begin(), carry.end(), [](const RibbitCall &a, const RibbitCall &b) {
-        return a.pos != b.pos ? a.pos < b.pos : a.mlen < b.mlen;
-    });
-    calls.insert(calls.end(), carry.begin(), carry.end());
-    batch.clear();
-    for (size_t mi = 0; mi < nm; ++mi) {
-        fsm[mi].set_output(&batch);
-        if (!fsm[mi].finish()) return fail(RIBBIT_E_INTERNAL, "window event stream of motif %d ends inside a streak", m_lo + (int)mi);
-    }
-    std::stable_sort(batch.begin(), batch.end(), [](const RibbitCall &a, const RibbitCall &b) {
-        return a.pos != b.pos ? a.pos < b.pos : a.mlen < b.mlen;
-    });
-    calls.insert(calls.end(), batch.begin(), batch.end());
-    return RIBBIT_OK;
-}
-
 // window scan (1 mismatch) + per-motif state machine -> the addSeed call list of
 // processShiftXORswithSubstitutions (parse_substitute_shiftxor.cpp:430-574)
 int build_subst_calls(RibbitHandle *h) {
@@ -459,7 +346,8 @@ int build_subst_calls(RibbitHandle *h) {
     if (rc) return rc;
     if ((rc = collect_events(h, 1))) return rc;
     const double t0 = now_ms();
-    if ((rc = replay_window_events(h, (uint32_t)rb::TILE_BASES, h->subst_calls))) return rc;
+    std::string why;
+    if (!rb::replay_window_events(event_source(h), h->host, h->subst_calls, &why)) return fail(RIBBIT_E_INTERNAL, "%s", why.c_str());
     h->host_ms = now_ms() - t0;
     h->subst_calls_valid = true;
     return RIBBIT_OK;
@@ -513,7 +401,8 @@ int build_anchored_calls(RibbitHandle *h) {
     HIP_TRY(hipMemcpyAsync(h->host.xa.data(), h->d_xa.p, nm * (size_t)h->xa_stride * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const double t0 = now_ms();
-    if ((rc = replay_window_events(h, (uint32_t)rb::ATILE_BASES, h->anchored_calls))) return rc;
+    std::string why;
+    if (!rb::replay_window_events(event_source(h), h->host, h->anchored_calls, &why)) return fail(RIBBIT_E_INTERNAL, "%s", why.c_str());
     h->host_ms = now_ms() - t0;
     h->anchored_calls_valid = true;
     return RIBBIT_OK;
@@ -958,6 +847,129 @@ int ribbit_ssw_align(const char *query, int32_t query_len, const char *ref, int3
 }
 
 int64_t ribbit_hip_guard_hits(const RibbitHandle *h) { return h ? h->lists.guard_hits : 0; }
+
+int ribbit_hip_stage_events(RibbitHandle *h, int stage, int64_t own_lo, int64_t own_hi, int64_t pos_offset,
+                            const uint64_t **events, size_t *n, const uint64_t **per_motif_counts) {
+    if (!h || !events || !n || !per_motif_counts) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    if (stage < 0 || stage > 2) return fail(RIBBIT_E_ARG, "stage must be 0, 1 or 2");
+    int rc;
+    if (stage == 2) {
+        if (h->params.max_motif > rb::ANCHORED_MAX_MOTIF)
+            return fail(RIBBIT_E_ARG, "the anchored stage of this build supports max_motif <= %d", rb::ANCHORED_MAX_MOTIF);
+        const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
+        h->xa_stride = ((h->length / 32 + 1) + 7) / 8 * 8 + 16;
+        if ((rc = h->d_xa.ensure(nm * (size_t)h->xa_stride))) return rc;
+    }
+    if ((rc = collect_events(h, stage))) return rc;
+    h->runs_valid = h->calls_valid = h->subst_calls_valid = h->anchored_calls_valid = false;   // the event buffer is shared
+    const rb::EventSource src = event_source(h);
+    h->export_events.clear();
+    h->export_counts.assign(src.nm, 0);
+    for (size_t mi = 0; mi < src.nm; ++mi) {
+        for (rb::MotifCursor c(src, mi); !c.done(); c.next()) {
+            const uint64_t e = c.peek();
+            const int64_t pos = rb::ev_pos(e);
+            if (pos < own_lo || pos >= own_hi) continue;
+            h->export_events.push_back(rb::ev_pack((uint32_t)(pos + pos_offset), rb::ev_mlen(e), rb::ev_kind(e)));
+            ++h->export_counts[mi];
+        }
+    }
+    *events = h->export_events.data();
+    *n = h->export_events.size();
+    *per_motif_counts = h->export_counts.data();
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_xa_words(RibbitHandle *h, int64_t word_lo, int64_t word_hi, uint32_t *out) {
+    if (!h || !out) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded || !h->d_xa.p || h->xa_stride == 0) return fail(RIBBIT_E_STATE, "the anchored kernel has not run on this record");
+    if (word_lo < 0 || word_hi < word_lo || word_hi > h->xa_stride) return fail(RIBBIT_E_ARG, "word range outside the planes");
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
+    const size_t w = (size_t)(word_hi - word_lo);
+    if (w == 0) return RIBBIT_OK;
+    HIP_TRY(hipMemcpy2DAsync(out, w * sizeof(uint32_t), h->d_xa.p + word_lo, (size_t)h->xa_stride * sizeof(uint32_t),
+                             w * sizeof(uint32_t), nm, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RIBBIT_OK;
+}
+
+int ribbit_host_scan_from_events(const RibbitScanParams *params, int64_t length,
+                                 const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
+                                 const uint32_t *xa, size_t xa_stride, size_t nparts,
+                                 const uint64_t *ev_perfect, const uint64_t *cnt_perfect,
+                                 const uint64_t *ev_subst, const uint64_t *cnt_subst,
+                                 const uint64_t *ev_anchored, const uint64_t *cnt_anchored,
+                                 RibbitSeedLists *out) {
+    if (!params || !out || !cnt_perfect || !cnt_subst || (length > 0 && (!hi || !lo || !brk))) return fail(RIBBIT_E_ARG, "null argument");
+    const size_t need = (size_t)(length / 32 + 1) + (size_t)(params->max_motif + 2) / 32 + 2;
+    if (nwords < need) return fail(RIBBIT_E_ARG, "planes too short: %zu words, need %zu", nwords, need);
+    if (cnt_anchored && (!xa || xa_stride < (size_t)(length / 32 + 1))) return fail(RIBBIT_E_ARG, "anchored events need the composed planes (xa)");
+    std::memset(out, 0, sizeof *out);
+    const size_t nm = (size_t)(params->max_motif - params->min_motif + 1);
+    rb::HostPlanes hp;
+    hp.resize(length, nwords);
+    std::memcpy(hp.hi.data(), hi, nwords * sizeof(uint32_t));
+    std::memcpy(hp.lo.data(), lo, nwords * sizeof(uint32_t));
+    std::memcpy(hp.brk.data(), brk, nwords * sizeof(uint32_t));
+    hp.index_breaks();
+    // segment table of one stage: [motif][part] -> {offset, count} into the gathered buffer
+    auto source = [&](const uint64_t *ev, const uint64_t *cnt, std::vector<rb::Seg> &segs) {
+        segs.assign(nm * nparts, rb::Seg{0, 0});
+        uint64_t off = 0;
+        for (size_t p = 0; p < nparts; ++p)
+            for (size_t mi = 0; mi < nm; ++mi) {
+                segs[mi * nparts + p] = rb::Seg{(uint32_t)off, (uint32_t)cnt[p * nm + mi]};
+                off += cnt[p * nm + mi];
+            }
+        rb::EventSource src;
+        src.ev = ev; src.segs = segs.data(); src.segs_per_motif = nparts; src.nm = nm; src.m_lo = params->min_motif;
+        return src;
+    };
+    rb::SeedLists sl;
+    sl.length = length;
+    sl.min_motif = params->min_motif;
+    sl.max_motif = params->max_motif;
+    sl.min_shift = (params->min_motif > 2) ? params->min_motif - 2 : 1;
+    sl.range_count = [&hp](int shift, int start, int end) { return hp.range_count(shift, start, end); };
+    std::vector<rb::Seg> segs;
+    std::string why;
+    std::vector<RibbitRun> runs;
+    std::vector<RibbitCall> calls;
+    if (!rb::pair_perfect_runs(source(ev_perfect, cnt_perfect, segs), runs, &why)) return fail(RIBBIT_E_INTERNAL, "perfect events: %s", why.c_str());
+    rb::perfect_calls_from_runs(runs, length, sl.min_shift, calls);
+    for (const RibbitCall &c : calls) rb::perfect_add(sl, c.start, c.end, c.mlen);
+    if (!rb::replay_window_events(source(ev_subst, cnt_subst, segs), hp, calls, &why)) return fail(RIBBIT_E_INTERNAL, "substitution events: %s", why.c_str());
+    replay_subst_calls(sl, calls.data(), calls.size());
+    std::vector<RibbitSeed> dispatch;
+    if (cnt_anchored) {
+        hp.xa.assign(xa, xa + nm * xa_stride);
+        hp.xa_stride = (int64_t)xa_stride;
+        hp.xa_m_lo = params->min_motif;
+        hp.xa_m_hi = params->max_motif;
+        sl.range_count = [&hp](int shift, int start, int end) {
+            return hp.has_xa(shift) ? hp.range_count_xa(shift, start, end) : hp.range_count(shift, start, end);
+        };
+        if (!rb::replay_window_events(source(ev_anchored, cnt_anchored, segs), hp, calls, &why)) return fail(RIBBIT_E_INTERNAL, "anchored events: %s", why.c_str());
+        replay_anchored_calls(sl, calls, length);
+        rb::dispatch_order(sl, dispatch);
+    }
+    auto give = [](const std::vector<RibbitSeed> &v, RibbitSeed **p, size_t *n) {
+        *n = v.size();
+        *p = (RibbitSeed *)std::malloc(std::max<size_t>(v.size(), 1) * sizeof(RibbitSeed));
+        if (*p && !v.empty()) std::memcpy(*p, v.data(), v.size() * sizeof(RibbitSeed));
+        return *p != nullptr;
+    };
+    if (!give(sl.perfect, &out->perfect, &out->n_perfect) || !give(sl.subst, &out->subst, &out->n_subst) ||
+        !give(sl.anchored, &out->anchored, &out->n_anchored) || !give(dispatch, &out->dispatch, &out->n_dispatch)) {
+        ribbit_seed_lists_free(out);
+        return fail(RIBBIT_E_NOMEM, "out of host memory");
+    }
+    out->guard_hits = sl.guard_hits;
+    return RIBBIT_OK;
+}
 
 int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
                              const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
