@@ -6,10 +6,11 @@ pack kernel (fasta_utils.cpp:78-115) + perfect shift-XOR scan kernel over m=2..1
 (fasta_utils.cpp:117-122 + parse_perfect_shiftxor.cpp:173-223) + event read-back + host pairing
 into runs.  Workload = BASELINE.json configs[1]: 100 Mbp synthetic FASTA, -m 2 -M 100, perfect scan.
 
-N > 1: one process per GPU (torch.distributed, backend nccl == RCCL).  The path shards by record
-(option 1): every rank scans its own 100-Mbp record (weak scaling, no data-path
-collective) and the sparse run records are exchanged with an all-gather-v over RCCL before the
-(host) merge, as BASELINE.json's north_star prescribes.
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL).  ONE record of N x 100 Mbp is
+chunk-sharded (option 2): every rank owns a 100-Mbp chunk (weak scaling), scans it
+together with halos of a few hundred bases taken from its neighbours, keeps the events it owns, and the
+sparse events are exchanged with an all-gather-v over RCCL/xGMI; rank 0 then pairs them into runs
+exactly as for a single GPU -- what BASELINE.json's north_star prescribes.
 
 Prints ONE JSON line on rank 0.
 """
@@ -49,6 +50,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bases", type=int, default=WORKLOAD_BASES, help="bases per GPU (default: BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--verify", action="store_true",
+                    help="N > 1: rank 0 also scans the whole record on its own GPU and checks the sharded runs against it")
     ap.add_argument("--calibrate", action="store_true",
                     help="after the timed region, launch the known-byte-count stream-read kernel (for PMC passes)")
     args = ap.parse_args()
@@ -57,7 +62,7 @@ def main():
     import torch
 
     import ribbit_amd
-    from ribbit_amd.distributed import allgather_records
+    from ribbit_amd.distributed import allgather_array
     from ribbit_amd.simulate import simulate_sequence
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -65,27 +70,46 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: ribbit_amd has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend=args.backend)
 
-    # synthetic records: every rank owns one record, generator seed 2 + rank
+    # synthetic record: rank r owns chunk r (generator seed 2 + r) of one record of world x bases
     seq, _ = simulate_sequence(args.bases, 2 + rank, M_LO, M_HI)
     dev = torch.device("cuda", local_rank)
-    d_ascii = torch.frombuffer(bytearray(seq), dtype=torch.uint8).to(dev)
+    xdev = dev if args.backend == "nccl" else None          # where the exchange buffers live
+    halo_l = halo_r = b""
+    if world > 1:
+        # halos from the neighbours (a few hundred bases; exchanged once, outside the timed region)
+        reach = 4 * (M_HI + 2) + 64
+        edges = allgather_array(np.frombuffer(seq[:reach] + seq[-reach:], dtype=np.uint8).copy(), xdev)
+        if rank > 0:
+            halo_l = edges[rank - 1][reach:].tobytes()[-(2 * (M_HI + 2) + 64) // 32 * 32:]
+        if rank < world - 1:
+            halo_r = edges[rank + 1][:reach].tobytes()
+    loaded = halo_l + seq + halo_r
+    own_lo = len(halo_l)
+    own_hi = own_lo + args.bases + (1 if rank == world - 1 else 0)     # the last chunk owns the end-of-record position
+    d_ascii = torch.frombuffer(bytearray(loaded), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
 
     sc = ribbit_amd.Scanner(M_LO, M_HI, device=local_rank)
 
     def step():
         sc.load_record_device(d_ascii.data_ptr(), d_ascii.numel())
-        runs = sc.scan_perfect_runs()
-        if world > 1:
-            # all-gather-v of the sparse run records over RCCL/xGMI (count exchange + padded gather)
-            allgather_records(runs, dev)
-        return runs
+        if world == 1:
+            return sc.scan_perfect_runs()
+        # own events in record coordinates, then all-gather-v over RCCL/xGMI and pairing on rank 0
+        ev, cnt = sc.stage_events(0, own_lo, own_hi, rank * args.bases - own_lo)
+        evs = allgather_array(ev, xdev)
+        cnts = allgather_array(cnt, xdev)
+        if rank == 0:
+            return ribbit_amd.host_perfect_runs_from_events(M_LO, M_HI, evs, cnts)
+        return ev
 
     for _ in range(args.warmup):
         step()
@@ -113,6 +137,14 @@ def main():
     if args.calibrate:
         sc.debug_stream_read(256 << 20)
 
+    if args.verify and world > 1:
+        whole = allgather_array(np.frombuffer(seq, dtype=np.uint8).copy(), xdev)
+        if rank == 0:
+            sc.load_record(b"".join(w.tobytes() for w in whole))
+            want = sc.scan_perfect_runs()
+            assert np.array_equal(runs.view("<i4"), want.view("<i4")), "chunk-sharded runs differ from the single-GPU scan"
+            print(f"verify: {len(want)} runs identical to the single-GPU scan of the whole record", file=sys.stderr)
+
     if rank == 0:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -131,7 +163,7 @@ def main():
             "config": {"workload": f"{args.bases} bp synthetic record per GPU, -m {M_LO} -M {M_HI}, "
                                    "pack + perfect shift-XOR scan (BASELINE.json configs[1])",
                        "bases_per_gpu": args.bases, "min_motif": M_LO, "max_motif": M_HI,
-                       "parallelism": f"record-sharded x{world} + all-gather-v of runs" if world > 1 else "single GPU"},
+                       "parallelism": f"one record chunk-sharded x{world} (halos) + all-gather-v of events" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "scan_perfect_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": args.bases * ALGO_BYTES_PER_BASE,

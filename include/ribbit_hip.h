@@ -324,6 +324,12 @@ int ribbit_host_scan_from_events(const RibbitScanParams *params, int64_t length,
                                  const uint64_t *ev_anchored, const uint64_t *cnt_anchored,
                                  RibbitSeedLists *out);
 
+/* Host-only: pair gathered perfect-stage events into runs (sorted by motif, start); *runs is malloc'ed
+ * (release with ribbit_runs_free). */
+int ribbit_host_perfect_runs_from_events(const RibbitScanParams *params, size_t nparts, const uint64_t *events,
+                                         const uint64_t *counts, RibbitRun **runs, size_t *n);
+void ribbit_runs_free(RibbitRun *runs);
+
 /* Timing of the last call, milliseconds.  what: 0 pack kernel, 1 last scan kernel, 2 GPU side of
  * the last scan (kernel + compaction + read-back), all by HIP events on the launch stream;
  * 3 host post-processing of the last scan (wall clock). */

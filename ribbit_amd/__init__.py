@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 __all__ = ["RibbitHipError", "ScanParams", "Scanner", "library_path", "load_library", "host_replay_calls", "pack_planes", "pack_bit_planes",
-           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "host_refine_bed", "host_scan_from_events", "ssw_align"]
+           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "host_refine_bed", "host_scan_from_events", "host_perfect_runs_from_events", "ssw_align"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -43,6 +43,7 @@ ABI_SYMBOLS = [
     "ribbit_host_refine_jobs", "ribbit_refine_jobs_free", "ribbit_ssw_align",
     "ribbit_hip_refine_bed", "ribbit_host_refine_bed", "ribbit_text_free",
     "ribbit_hip_stage_events", "ribbit_hip_xa_words", "ribbit_host_scan_from_events",
+    "ribbit_host_perfect_runs_from_events", "ribbit_runs_free",
 ]
 
 
@@ -139,6 +140,9 @@ def load_library():
     L.ribbit_hip_xa_words.argtypes = [vp, i64, i64, vp]
     L.ribbit_host_scan_from_events.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t,
                                                vp, vp, vp, vp, vp, vp, C.POINTER(SeedLists)]
+    L.ribbit_host_perfect_runs_from_events.argtypes = [C.POINTER(ScanParams), C.c_size_t, vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ribbit_runs_free.restype = None
+    L.ribbit_runs_free.argtypes = [vp]
     L.ribbit_ssw_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, C.POINTER(Alignment), C.c_char_p, C.c_size_t]
     L.ribbit_hip_debug_stream_read.argtypes = [vp, i64, C.POINTER(i64)]
     L.ribbit_hip_last_event_count.restype = i64
@@ -302,6 +306,23 @@ def host_scan_from_events(min_motif: int, max_motif: int, length: int, hi, lo, b
                 "guard_hits": int(out.guard_hits)}
     finally:
         L.ribbit_seed_lists_free(C.byref(out))
+
+
+def host_perfect_runs_from_events(min_motif: int, max_motif: int, event_parts, count_parts):
+    """ribbit_host_perfect_runs_from_events: per-rank (events, per-motif counts) -> paired runs. No GPU needed."""
+    L = load_library()
+    params = ScanParams()
+    L.ribbit_scan_params_default(C.byref(params), min_motif, max_motif)
+    ev = np.ascontiguousarray(np.concatenate(event_parts) if len(event_parts) else np.zeros(0, "<u8"), dtype="<u8")
+    cnt = np.ascontiguousarray(np.concatenate(count_parts), dtype="<u8")
+    runs, n = C.c_void_p(), C.c_size_t()
+    rc = L.ribbit_host_perfect_runs_from_events(C.byref(params), len(event_parts), ev.ctypes.data, cnt.ctypes.data, C.byref(runs), C.byref(n))
+    if rc != 0:
+        raise RibbitHipError(f"ribbit_host_perfect_runs_from_events error {rc}: {L.ribbit_hip_last_error().decode()}")
+    try:
+        return _copy(runs.value, n.value, RUN_DT)
+    finally:
+        L.ribbit_runs_free(runs)
 
 
 class Scanner:

@@ -971,6 +971,28 @@ int ribbit_host_scan_from_events(const RibbitScanParams *params, int64_t length,
     return RIBBIT_OK;
 }
 
+int ribbit_host_perfect_runs_from_events(const RibbitScanParams *params, size_t nparts, const uint64_t *events,
+                                         const uint64_t *counts, RibbitRun **runs, size_t *n) {
+    if (!params || !counts || !runs || !n) return fail(RIBBIT_E_ARG, "null argument");
+    const size_t nm = (size_t)(params->max_motif - params->min_motif + 1);
+    std::vector<rb::Seg> segs(nm * nparts, rb::Seg{0, 0});
+    uint64_t off = 0;
+    for (size_t p = 0; p < nparts; ++p)
+        for (size_t mi = 0; mi < nm; ++mi) { segs[mi * nparts + p] = rb::Seg{(uint32_t)off, (uint32_t)counts[p * nm + mi]}; off += counts[p * nm + mi]; }
+    rb::EventSource src;
+    src.ev = events; src.segs = segs.data(); src.segs_per_motif = nparts; src.nm = nm; src.m_lo = params->min_motif;
+    std::vector<RibbitRun> out;
+    std::string why;
+    if (!rb::pair_perfect_runs(src, out, &why)) return fail(RIBBIT_E_INTERNAL, "perfect events: %s", why.c_str());
+    *n = out.size();
+    *runs = (RibbitRun *)std::malloc(std::max<size_t>(out.size(), 1) * sizeof(RibbitRun));
+    if (!*runs) return fail(RIBBIT_E_NOMEM, "out of host memory");
+    if (!out.empty()) std::memcpy(*runs, out.data(), out.size() * sizeof(RibbitRun));
+    return RIBBIT_OK;
+}
+
+void ribbit_runs_free(RibbitRun *runs) { std::free(runs); }
+
 int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
                              const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
                              const uint32_t *xa, size_t xa_stride,

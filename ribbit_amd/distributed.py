@@ -38,6 +38,23 @@ def allgather_records(records: np.ndarray, device: torch.device | None = None) -
     return out
 
 
+def allgather_array(arr: np.ndarray, device: torch.device | None = None) -> list[np.ndarray]:
+    """all-gather-v of a 1-D numpy array of any fixed-size dtype (count exchange + padded gather)."""
+    world = dist.get_world_size()
+    dev = device if device is not None else torch.device("cpu")
+    raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+    n = torch.tensor([raw.size], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    buf = torch.zeros(max(max(counts), 1), dtype=torch.uint8, device=dev)
+    if raw.size:
+        buf[:raw.size] = torch.from_numpy(raw).to(dev)
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf)
+    return [gathered[r][:counts[r]].cpu().numpy().view(arr.dtype).copy() for r in range(world)]
+
+
 def shard_records(n_records: int, lengths: list[int], world: int) -> list[list[int]]:
     """Longest-first bin packing of record indices over ranks (option 1)."""
     order = sorted(range(n_records), key=lambda i: -lengths[i])
