@@ -309,6 +309,13 @@ enum { RIBBIT_STAGE_PERFECT = 0, RIBBIT_STAGE_SUBST = 1, RIBBIT_STAGE_ANCHORED =
 int ribbit_hip_stage_events(RibbitHandle *h, int stage, int64_t own_lo, int64_t own_hi, int64_t pos_offset,
                             const uint64_t **events, size_t *n, const uint64_t **per_motif_counts);
 
+/* Perfect stage of one chunk: scan, keep the events owned ([own_lo, own_hi) local, shifted by pos_offset) and
+ * pair them locally.  runs = complete runs; halves = the unmatched events at the chunk's edges (a motif's
+ * leading END / trailing START: that run continues in a neighbouring chunk).  After gathering, the halves of
+ * all ranks sorted by (motif, position) alternate START, END and pair up into the remaining runs. */
+int ribbit_hip_perfect_runs_partial(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset,
+                                    const RibbitRun **runs, size_t *n_runs, const uint64_t **halves, size_t *n_halves);
+
 /* Words [word_lo, word_hi) of every composed plane XA_m (after the anchored stage's kernel ran),
  * motif-major, into out[(max_motif-min_motif+1) * (word_hi-word_lo)]. */
 int ribbit_hip_xa_words(RibbitHandle *h, int64_t word_lo, int64_t word_hi, uint32_t *out);

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 __all__ = ["RibbitHipError", "ScanParams", "Scanner", "library_path", "load_library", "host_replay_calls", "pack_planes", "pack_bit_planes",
-           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "host_refine_bed", "host_scan_from_events", "host_perfect_runs_from_events", "ssw_align"]
+           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "host_refine_bed", "host_scan_from_events", "host_perfect_runs_from_events", "pair_halves", "ssw_align"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "ribbit_host_refine_jobs", "ribbit_refine_jobs_free", "ribbit_ssw_align",
     "ribbit_hip_refine_bed", "ribbit_host_refine_bed", "ribbit_text_free",
     "ribbit_hip_stage_events", "ribbit_hip_xa_words", "ribbit_host_scan_from_events",
-    "ribbit_host_perfect_runs_from_events", "ribbit_runs_free",
+    "ribbit_host_perfect_runs_from_events", "ribbit_runs_free", "ribbit_hip_perfect_runs_partial",
 ]
 
 
@@ -138,6 +138,7 @@ def load_library():
     L.ribbit_text_free.argtypes = [vp]
     L.ribbit_hip_stage_events.argtypes = [vp, C.c_int, i64, i64, i64, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
     L.ribbit_hip_xa_words.argtypes = [vp, i64, i64, vp]
+    L.ribbit_hip_perfect_runs_partial.argtypes = [vp, i64, i64, i64, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.ribbit_host_scan_from_events.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t,
                                                vp, vp, vp, vp, vp, vp, C.POINTER(SeedLists)]
     L.ribbit_host_perfect_runs_from_events.argtypes = [C.POINTER(ScanParams), C.c_size_t, vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -325,6 +326,25 @@ def host_perfect_runs_from_events(min_motif: int, max_motif: int, event_parts, c
         L.ribbit_runs_free(runs)
 
 
+def pair_halves(halves) -> np.ndarray:
+    """Cross-rank pairing of the edge events of chunk-local pairing (Scanner.perfect_runs_partial): sorted by
+    (motif, position) they alternate START, END."""
+    hv = np.sort(np.asarray(halves, dtype="<u8").view("<u8"), kind="stable") if len(halves) else np.zeros(0, "<u8")
+    if len(hv) == 0:
+        return np.zeros(0, RUN_DT)
+    pos = (hv & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    mlen = ((hv >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64)
+    kind = ((hv >> np.uint64(48)) & np.uint64(0xF)).astype(np.int64)
+    order = np.lexsort((pos, mlen))
+    pos, mlen, kind = pos[order], mlen[order], kind[order]
+    if len(hv) % 2 or np.any(kind[0::2] != 0) or np.any(kind[1::2] == 0) or np.any(mlen[0::2] != mlen[1::2]):
+        raise RibbitHipError("edge events of the chunks do not pair up")
+    out = np.zeros(len(hv) // 2, RUN_DT)
+    out["start"], out["end"], out["mlen"] = pos[0::2], pos[1::2], mlen[0::2]
+    out["term"] = kind[1::2] - 1
+    return out
+
+
 class Scanner:
     """One GPU-resident FASTA record and the scans over it.
 
@@ -457,6 +477,12 @@ class Scanner:
         self._check(self._L.ribbit_hip_stage_events(self._h, stage, own_lo, own_hi, pos_offset, C.byref(ev), C.byref(n), C.byref(cnt)))
         nm = self.params.max_motif - self.params.min_motif + 1
         return _copy(ev.value, n.value, np.dtype("<u8")), _copy(cnt.value, nm, np.dtype("<u8"))
+
+    def perfect_runs_partial(self, own_lo: int, own_hi: int, pos_offset: int = 0):
+        """-> (complete runs of this chunk, unmatched edge events as uint64)"""
+        r, nr, hv, nh = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        self._check(self._L.ribbit_hip_perfect_runs_partial(self._h, own_lo, own_hi, pos_offset, C.byref(r), C.byref(nr), C.byref(hv), C.byref(nh)))
+        return _copy(r.value, nr.value, RUN_DT), _copy(hv.value, nh.value, np.dtype("<u8"))
 
     def xa_words(self, word_lo: int, word_hi: int):
         nm = self.params.max_motif - self.params.min_motif + 1

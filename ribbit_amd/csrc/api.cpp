@@ -881,6 +881,25 @@ int ribbit_hip_stage_events(RibbitHandle *h, int stage, int64_t own_lo, int64_t 
     return RIBBIT_OK;
 }
 
+int ribbit_hip_perfect_runs_partial(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset,
+                                    const RibbitRun **runs, size_t *n_runs, const uint64_t **halves, size_t *n_halves) {
+    if (!h || !runs || !n_runs || !halves || !n_halves) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    int rc = collect_events(h, 0);
+    if (rc) return rc;
+    h->runs_valid = h->calls_valid = false;
+    const double t0 = now_ms();
+    std::string why;
+    if (!rb::pair_perfect_runs_partial(event_source(h), own_lo, own_hi, pos_offset, h->runs, h->export_events, &why))
+        return fail(RIBBIT_E_INTERNAL, "%s", why.c_str());
+    h->host_ms = now_ms() - t0;
+    *runs = h->runs.data();
+    *n_runs = h->runs.size();
+    *halves = h->export_events.data();
+    *n_halves = h->export_events.size();
+    return RIBBIT_OK;
+}
+
 int ribbit_hip_xa_words(RibbitHandle *h, int64_t word_lo, int64_t word_hi, uint32_t *out) {
     if (!h || !out) return fail(RIBBIT_E_ARG, "null argument");
     if (!h->loaded || !h->d_xa.p || h->xa_stride == 0) return fail(RIBBIT_E_STATE, "the anchored kernel has not run on this record");

@@ -37,6 +37,38 @@ bool pair_perfect_runs(const EventSource &src, std::vector<RibbitRun> &runs, std
     return true;
 }
 
+bool pair_perfect_runs_partial(const EventSource &src, int64_t own_lo, int64_t own_hi, int64_t pos_offset,
+                               std::vector<RibbitRun> &runs, std::vector<uint64_t> &halves, std::string *why) {
+    runs.clear();
+    halves.clear();
+    for (size_t mi = 0; mi < src.nm; ++mi) {
+        const int32_t mlen = src.m_lo + (int32_t)mi;
+        int64_t open = -1;
+        bool first = true;
+        for (MotifCursor c(src, mi); !c.done(); c.next()) {
+            const uint64_t e = c.peek();
+            const int64_t local = ev_pos(e);
+            if (local < own_lo || local >= own_hi) continue;
+            const int64_t pos = local + pos_offset;
+            const uint32_t kind = ev_kind(e);
+            if (kind == EV_START) {
+                if (open != -1) { if (why) *why = "two run starts in a row for motif " + std::to_string(mlen); return false; }
+                open = pos;
+            } else if (open == -1) {
+                if (!first) { if (why) *why = "run end without start for motif " + std::to_string(mlen); return false; }
+                halves.push_back(ev_pack((uint32_t)pos, (uint32_t)mlen, kind));      // run began in an earlier chunk
+            } else {
+                const int term = kind == EV_END_ZERO ? RIBBIT_TERM_ZERO : kind == EV_END_N ? RIBBIT_TERM_N : RIBBIT_TERM_EOS;
+                runs.push_back(RibbitRun{(int32_t)open, (int32_t)pos, mlen, term});
+                open = -1;
+            }
+            first = false;
+        }
+        if (open != -1) halves.push_back(ev_pack((uint32_t)open, (uint32_t)mlen, EV_START));   // run ends in a later chunk
+    }
+    return true;
+}
+
 void perfect_calls_from_runs(const std::vector<RibbitRun> &runs, int64_t length, int min_shift, std::vector<RibbitCall> &calls) {
     calls.clear();
     const int32_t L = (int32_t)length;

@@ -46,6 +46,13 @@ class MotifCursor {
 // Returns false and sets *why on a malformed stream.
 bool pair_perfect_runs(const EventSource &src, std::vector<RibbitRun> &runs, std::string *why);
 
+// Same for ONE rank's own events of a chunk-sharded record (positions in [own_lo, own_hi), shifted by
+// pos_offset): a motif's first event may be an END and its last a START -- the run continues in a
+// neighbouring chunk.  Those unmatched events are returned in `halves` (packed events) for the cross-rank
+// pairing; everything else becomes runs locally, so the pairing work scales with the chunk, not the record.
+bool pair_perfect_runs_partial(const EventSource &src, int64_t own_lo, int64_t own_hi, int64_t pos_offset,
+                               std::vector<RibbitRun> &runs, std::vector<uint64_t> &halves, std::string *why);
+
 // parse_perfect_shiftxor.cpp:175-223: runs -> the addSeed calls the perfect scanner makes, in its order
 void perfect_calls_from_runs(const std::vector<RibbitRun> &runs, int64_t length, int min_shift, std::vector<RibbitCall> &calls);
 

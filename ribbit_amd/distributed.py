@@ -55,6 +55,26 @@ def allgather_array(arr: np.ndarray, device: torch.device | None = None) -> list
     return [gathered[r][:counts[r]].cpu().numpy().view(arr.dtype).copy() for r in range(world)]
 
 
+def gather_array(arr: np.ndarray, device: torch.device | None = None, dst: int = 0):
+    """gather-v of a 1-D numpy array to rank `dst` (count exchange + padded gather).  Returns the list of
+    per-rank arrays on `dst`, None elsewhere.  Only `dst` pays for receiving world x payload."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if device is not None else torch.device("cpu")
+    raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+    n = torch.tensor([raw.size], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    buf = torch.zeros(max(max(counts), 1), dtype=torch.uint8, device=dev)
+    if raw.size:
+        buf[:raw.size] = torch.from_numpy(raw).to(dev)
+    gathered = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, gathered, dst=dst)
+    if rank != dst:
+        return None
+    return [gathered[r][:counts[r]].cpu().numpy().view(arr.dtype).copy() for r in range(world)]
+
+
 def shard_records(n_records: int, lengths: list[int], world: int) -> list[list[int]]:
     """Longest-first bin packing of record indices over ranks (option 1)."""
     order = sorted(range(n_records), key=lambda i: -lengths[i])
