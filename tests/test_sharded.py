@@ -79,3 +79,13 @@ def _worker(rank, world, port, out_dir):
 def test_chunk_sharded_exchange_world2(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert np.array_equal(np.load(tmp_path / "dispatch0.npy"), np.load(tmp_path / "dispatch1.npy"))
+
+
+def test_pair_halves_pairs_by_motif_and_position_and_rejects_garbage():
+    ev = lambda pos, m, kind: np.uint64(pos | (m << 32) | (kind << 48))
+    halves = np.array([ev(500, 3, 1), ev(100, 3, 0), ev(90, 2, 0), ev(7000, 2, 3)], dtype=np.uint64)
+    runs = ribbit_amd.pair_halves(halves)
+    assert [tuple(int(x) for x in r) for r in runs] == [(90, 7000, 2, 2), (100, 500, 3, 0)]
+    assert len(ribbit_amd.pair_halves(np.zeros(0, np.uint64))) == 0
+    with pytest.raises(ribbit_amd.RibbitHipError):
+        ribbit_amd.pair_halves(np.array([ev(1, 2, 0), ev(5, 2, 0)], dtype=np.uint64))

@@ -34,3 +34,21 @@ def test_parts_own_disjoint_ranges_and_every_event_once():
         parts = [sharded.scan_part(sc, seq, plan, anchored=False) for plan in sharded.plan_chunks(len(seq), 4, m_hi)]
     union = np.sort(np.concatenate([p["ev1"] for p in parts]))
     assert np.array_equal(union, np.sort(whole))
+
+
+@pytest.mark.parametrize("nparts", [2, 7])
+def test_chunk_local_pairing_plus_edge_halves_gives_the_whole_records_runs(nparts):
+    name, seq, m_lo, m_hi = [c for c in edge_cases() if c[0] == "long_run_cross_tiles"][0]
+    seq = seq + simulated_cases()[1][1][:80_000]
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc:
+        sc.load_record(seq)
+        want = sc.scan_perfect_runs()
+        runs, halves = [], []
+        for own_lo, own_hi, load_lo, load_hi in sharded.plan_chunks(len(seq), nparts, m_hi):
+            sc.load_record(seq[load_lo:load_hi])
+            r, h = sc.perfect_runs_partial(own_lo - load_lo, own_hi - load_lo, load_lo)
+            runs.append(r); halves.append(h)
+    # the 40-kb perfect repeat crosses chunk edges: its run must come out of the edge pairing
+    assert sum(len(h) for h in halves) > 0
+    got = np.sort(np.concatenate(runs + [ribbit_amd.pair_halves(np.concatenate(halves))]), order=["mlen", "start"])
+    assert np.array_equal(got.view("<i4"), want.view("<i4"))
