@@ -103,7 +103,7 @@ def main():
     def step():
         sc.load_record_device(d_ascii.data_ptr(), d_ascii.numel())
         if world == 1:
-            return sc.scan_perfect_runs()
+            return sc.scan_perfect_runs(copy=False)       # the C ABI's own result buffer (pinned), as a C caller sees it
         # pair the chunk's own events locally (work scales with the chunk), then gather-v the sparse run records
         # and the few edge events over RCCL/xGMI; rank 0 pairs the edges and holds the record's runs
         runs, halves = sc.perfect_runs_partial(own_lo, own_hi, rank * args.bases - own_lo)
@@ -121,13 +121,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kernel_ms, pack_ms, nruns, nevents = [], [], 0, 0
+    kernel_ms, pack_ms, gpu_ms, nruns, nevents = [], [], [], 0, 0
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runs = step()
         kernel_ms.append(sc.timing_ms(1))
         pack_ms.append(sc.timing_ms(0))
+        gpu_ms.append(sc.timing_ms(2))
         nruns, nevents = len(runs), sc.last_event_count()
     fence()
     dt = time.perf_counter() - t0
@@ -174,6 +175,7 @@ def main():
                          "kernel_gbases_per_s": args.bases / (kavg * 1e-3) / 1e9,
                          "note": "integer-VALU bound by design (SURVEY.md 8d); HBM fraction reported as required"},
             "runs_per_step": nruns, "device_events_per_step": nevents,
+            "gpu_side_ms_per_step": float(np.mean(gpu_ms)),   # scan + pairing kernels + D2H of the runs (HIP events)
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seq)

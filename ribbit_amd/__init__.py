@@ -398,14 +398,20 @@ class Scanner:
         self.length = int(length)
         self._check(self._L.ribbit_hip_load_record_device(self._h, C.c_void_p(dev_ptr), self.length))
 
-    def _list(self, fn, dt):
+    def _list(self, fn, dt, copy=True):
         p, n = C.c_void_p(), C.c_size_t()
         self._check(fn(self._h, C.byref(p), C.byref(n)))
-        return _copy(p.value, n.value, dt)
+        if copy or n.value == 0:
+            return _copy(p.value, n.value, dt)
+        view = np.frombuffer((C.c_char * (n.value * dt.itemsize)).from_address(p.value), dtype=dt)
+        view.flags.writeable = False
+        return view
 
     # parse_perfect_shiftxor.cpp:146-226 ---------------------------------------------------
-    def scan_perfect_runs(self):
-        return self._list(self._L.ribbit_hip_scan_perfect_runs, RUN_DT)
+    def scan_perfect_runs(self, copy=True):
+        """Runs of the perfect scan ordered by (mlen, start).  copy=False returns a read-only view of the
+        library's pinned result buffer, valid until the next call on this Scanner (what a C caller gets)."""
+        return self._list(self._L.ribbit_hip_scan_perfect_runs, RUN_DT, copy)
 
     def perfect_calls(self):
         return self._list(self._L.ribbit_hip_perfect_calls, CALL_DT)

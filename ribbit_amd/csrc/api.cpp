@@ -120,7 +120,13 @@ struct RibbitHandle {
     size_t table_ntile = 0;
 
     bool runs_valid = false, calls_valid = false;
-    std::vector<RibbitRun> runs;
+    std::vector<RibbitRun> runs;          // chunk-local pairing (multi-GPU path)
+    // device-side pairing of the perfect scan: scratch + the pinned run list it lands in
+    DevBuf<uint64_t> d_pair_table;
+    DevBuf<uint32_t> d_run_base, d_pair_partial, d_pair_status;
+    PinnedBuf<uint32_t> h_pair_status;
+    PinnedBuf<RibbitRun> h_runs;
+    size_t n_runs = 0;
     std::vector<RibbitCall> perfect_calls;
     bool subst_calls_valid = false;
     std::vector<RibbitCall> subst_calls;
@@ -304,16 +310,82 @@ rb::EventSource event_source(const RibbitHandle *h) {
     return src;
 }
 
+// Perfect stage on the device end to end: scan kernel -> START/END events (left in their regions, never
+// copied to the host) -> pairing kernels -> RibbitRun records ordered by (motif, start) -> one D2H copy
+// into pinned memory.  The host only checks the counters and the pairing status.
 int run_perfect_scan(RibbitHandle *h) {
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
     if (h->runs_valid) return RIBBIT_OK;
-    int rc = collect_events(h, 0);
-    if (rc) return rc;
-    const double t0 = now_ms();
-    std::string why;
-    h->runs.reserve(h->produced / 2);
-    if (!rb::pair_perfect_runs(event_source(h), h->runs, &why)) return fail(RIBBIT_E_INTERNAL, "%s", why.c_str());
-    h->host_ms = now_ms() - t0;
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    if ((rc = h->d_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
+    if ((rc = h->h_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
+    if ((rc = h->d_pair_status.ensure(rb::PAIR_STATUS_WORDS))) return rc;
+    if ((rc = h->h_pair_status.ensure(rb::PAIR_STATUS_WORDS))) return rc;
+    rb::PairLaunch pr;
+    pr.m_lo = (uint32_t)h->params.min_motif;
+    pr.nm = (uint32_t)(h->params.max_motif - h->params.min_motif + 1);
+    pr.ntile = (uint32_t)(h->length / rb::TILE_BASES + 1);
+    const size_t entries = (size_t)pr.nm * pr.ntile;
+    if (entries > 0xfffffff0u) return fail(RIBBIT_E_ARG, "record too long for %u motif sizes", pr.nm);
+    if ((rc = h->d_pair_table.ensure(entries))) return rc;
+    if ((rc = h->d_run_base.ensure(entries))) return rc;
+    if ((rc = h->d_pair_partial.ensure(entries / 1024 + 2))) return rc;
+    size_t cap = std::max<size_t>((size_t)1 << 20, (size_t)(h->length / 4));
+    cap = std::max(cap, h->d_events.cap);
+    const rb::DevicePlanes pl = h->planes();
+    uint64_t produced = 0;
+    for (int attempt = 0;; ++attempt) {
+        cap = std::min<size_t>((cap + rb::EV_SHARDS - 1) / rb::EV_SHARDS * rb::EV_SHARDS, 0xffffff00u);
+        if ((rc = h->d_events.ensure(cap))) return rc;
+        if ((rc = h->d_dense.ensure(cap))) return rc;        // cap/2 runs of 16 bytes
+        HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, rb::EV_COUNTER_WORDS * sizeof(uint32_t), h->stream));
+        rb::PerfectLaunch pp;
+        pp.m_lo = h->params.min_motif;
+        pp.m_hi = h->params.max_motif;
+        pp.ev_cap = (uint32_t)cap;
+        pr.region_cap = pp.ev_cap / (uint32_t)rb::EV_SHARDS;
+        HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+        rb::launch_scan_perfect(pl, pp, h->d_events.p, h->d_counters.p, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+        rb::launch_pair_runs(h->d_events.p, h->d_counters.p, pr, h->d_pair_table.p, h->d_run_base.p, h->d_pair_partial.p,
+                             h->d_dense.p, (uint32_t)(cap / 2), h->d_pair_status.p, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->h_counters.p, h->d_counters.p, rb::EV_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->h_pair_status.p, h->d_pair_status.p, rb::PAIR_STATUS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        uint32_t worst = 0;
+        produced = 0;
+        for (int t = 0; t < rb::EV_SHARDS; ++t) {
+            const uint32_t c = h->h_counters.p[t * rb::EV_COUNTER_STRIDE];
+            worst = std::max(worst, c);
+            produced += c;
+        }
+        if (worst <= pr.region_cap) break;
+        // some region overflowed: size every region for the fullest one and retry
+        if (attempt == 2 || (size_t)worst * rb::EV_SHARDS > 0xffffff00u)
+            return fail(RIBBIT_E_OVERFLOW, "event buffer overflow: fullest region needs %u events", worst);
+        cap = ((size_t)worst + 1024) * rb::EV_SHARDS;
+    }
+    h->last_event_count = (int64_t)produced;
+    const uint32_t flags = h->h_pair_status.p[rb::PAIR_FLAGS];
+    if (flags) {
+        return fail(RIBBIT_E_INTERNAL, "run pairing failed (flags 0x%x):%s%s%s%s%s", flags,
+                    flags & rb::PAIR_BAD_EVENT ? " malformed event;" : "", flags & rb::PAIR_DUP_CHUNK ? " duplicate event chunk;" : "",
+                    flags & rb::PAIR_NOT_ALTERNATING ? " run starts and ends do not alternate;" : "",
+                    flags & rb::PAIR_UNTERMINATED ? " unterminated run;" : "", flags & rb::PAIR_NO_ROOM ? " run buffer too small;" : "");
+    }
+    h->n_runs = h->h_pair_status.p[rb::PAIR_TOTAL];
+    if (h->n_runs * 2 != produced) return fail(RIBBIT_E_INTERNAL, "%llu events but %zu runs", (unsigned long long)produced, h->n_runs);
+    if ((rc = h->h_runs.ensure(std::max<size_t>(h->n_runs, 1)))) return rc;
+    if (h->n_runs)
+        HIP_TRY(hipMemcpyAsync(h->h_runs.p, h->d_dense.p, h->n_runs * sizeof(RibbitRun), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(h->ev[5], h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->have_timing[1] = h->have_timing[2] = true;
+    h->host_ms = 0.0;
     h->runs_valid = true;
     return RIBBIT_OK;
 }
@@ -322,7 +394,7 @@ int build_perfect_calls(RibbitHandle *h) {
     if (h->calls_valid) return RIBBIT_OK;
     int rc = run_perfect_scan(h);
     if (rc) return rc;
-    rb::perfect_calls_from_runs(h->runs, h->length, h->min_shift, h->perfect_calls);
+    rb::perfect_calls_from_runs(h->h_runs.p, h->n_runs, h->length, h->min_shift, h->perfect_calls);
     h->calls_valid = true;
     return RIBBIT_OK;
 }
@@ -585,6 +657,8 @@ int ribbit_hip_close(RibbitHandle *h) {
     h->d_ascii.release(); h->d_hi.release(); h->d_lo.release(); h->d_brk.release();
     h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release();
     h->h_events.release(); h->h_counters.release(); h->h_query.release();
+    h->d_pair_table.release(); h->d_run_base.release(); h->d_pair_partial.release(); h->d_pair_status.release();
+    h->h_pair_status.release(); h->h_runs.release();
     for (int i = 0; i < 6; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -624,8 +698,8 @@ int ribbit_hip_scan_perfect_runs(RibbitHandle *h, const RibbitRun **out, size_t 
     h->calls_valid = false;
     int rc = run_perfect_scan(h);
     if (rc) return rc;
-    *out = h->runs.data();
-    *n = h->runs.size();
+    *out = h->h_runs.p;
+    *n = h->n_runs;
     return RIBBIT_OK;
 }
 
@@ -958,7 +1032,7 @@ int ribbit_host_scan_from_events(const RibbitScanParams *params, int64_t length,
     std::vector<RibbitRun> runs;
     std::vector<RibbitCall> calls;
     if (!rb::pair_perfect_runs(source(ev_perfect, cnt_perfect, segs), runs, &why)) return fail(RIBBIT_E_INTERNAL, "perfect events: %s", why.c_str());
-    rb::perfect_calls_from_runs(runs, length, sl.min_shift, calls);
+    rb::perfect_calls_from_runs(runs.data(), runs.size(), length, sl.min_shift, calls);
     for (const RibbitCall &c : calls) rb::perfect_add(sl, c.start, c.end, c.mlen);
     if (!rb::replay_window_events(source(ev_subst, cnt_subst, segs), hp, calls, &why)) return fail(RIBBIT_E_INTERNAL, "substitution events: %s", why.c_str());
     replay_subst_calls(sl, calls.data(), calls.size());

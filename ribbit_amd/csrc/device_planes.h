@@ -53,8 +53,19 @@ enum : uint32_t { EV_START = 0, EV_END_ZERO = 1, EV_END_N = 2, EV_END_EOS = 3 };
 __host__ __device__ inline uint64_t ev_pack(uint32_t pos, uint32_t mlen, uint32_t kind) {
     return (uint64_t)pos | ((uint64_t)mlen << 32) | ((uint64_t)kind << 48);
 }
-inline uint32_t ev_pos(uint64_t e) { return (uint32_t)e; }
-inline uint32_t ev_mlen(uint64_t e) { return (uint32_t)(e >> 32) & 0xffffu; }
-inline uint32_t ev_kind(uint64_t e) { return (uint32_t)(e >> 48) & 0xfu; }
+__host__ __device__ inline uint32_t ev_pos(uint64_t e) { return (uint32_t)e; }
+__host__ __device__ inline uint32_t ev_mlen(uint64_t e) { return (uint32_t)(e >> 32) & 0xffffu; }
+__host__ __device__ inline uint32_t ev_kind(uint64_t e) { return (uint32_t)(e >> 48) & 0xfu; }
+
+// Device-side pairing of the perfect scan's events into runs (pair_runs_* kernels): status words
+//   [PAIR_FLAGS] error bits (0 = clean), [PAIR_TOTAL] number of runs written
+enum : uint32_t { PAIR_FLAGS = 0, PAIR_TOTAL = 1, PAIR_STATUS_WORDS = 4 };
+enum : uint32_t {
+    PAIR_BAD_EVENT = 1,        // motif or tile outside the launch
+    PAIR_DUP_CHUNK = 2,        // two chunks for one (motif, tile)
+    PAIR_NOT_ALTERNATING = 4,  // START/END do not alternate inside a chunk or across tiles
+    PAIR_UNTERMINATED = 8,     // START without a later END
+    PAIR_NO_ROOM = 16,         // more runs than the output buffer holds
+};
 
 }  // namespace rb

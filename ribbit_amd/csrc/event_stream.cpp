@@ -1,6 +1,9 @@
 #include "event_stream.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <thread>
 
 #include "window_fsm.h"
 
@@ -69,10 +72,11 @@ bool pair_perfect_runs_partial(const EventSource &src, int64_t own_lo, int64_t o
     return true;
 }
 
-void perfect_calls_from_runs(const std::vector<RibbitRun> &runs, int64_t length, int min_shift, std::vector<RibbitCall> &calls) {
+void perfect_calls_from_runs(const RibbitRun *runs, size_t n_runs, int64_t length, int min_shift, std::vector<RibbitCall> &calls) {
     calls.clear();
     const int32_t L = (int32_t)length;
-    for (const RibbitRun &r : runs) {
+    for (size_t i = 0; i < n_runs; ++i) {
+        const RibbitRun &r = runs[i];
         const int len = r.end - r.start;
         if (r.term == RIBBIT_TERM_ZERO) {                       // parse_perfect_shiftxor.cpp:199-205
             if (len >= cutoff_zero(r.mlen)) calls.push_back(RibbitCall{r.end, r.mlen, r.start, r.end});
@@ -90,67 +94,117 @@ bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vec
     calls.clear();
     const size_t nm = src.nm;
     const int32_t m_lo = src.m_lo;
-    constexpr int64_t TILE = 16384;          // batching granule of the replay (any value works)
-    std::vector<WindowFsm> fsm;
-    std::vector<MotifCursor> cur;
-    fsm.reserve(nm); cur.reserve(nm);
-    for (size_t mi = 0; mi < nm; ++mi) { fsm.emplace_back(hp, m_lo + (int32_t)mi); cur.emplace_back(src, mi); }
-    std::vector<RibbitCall> batch, by_motif, carry;
-    std::vector<uint32_t> count;
-    int64_t flushed_below = 0;               // every call with pos < flushed_below has been written to `calls`
+    constexpr int64_t TILE = 16384;          // ordering granule (any value works)
     const int64_t ntile = hp.length / TILE + 1;
-    for (int64_t t = 0; t < ntile; ++t) {
-        const int64_t next_tile = (t + 1) * TILE;
-        batch.swap(carry);
-        carry.clear();
-        for (size_t mi = 0; mi < nm; ++mi) {
-            WindowFsm &f = fsm[mi];
-            MotifCursor &c = cur[mi];
-            f.set_output(&batch);
-            for (; !c.done(); c.next()) {
-                const uint64_t e = c.peek();
-                if ((int64_t)ev_pos(e) >= next_tile) break;
-                if (!f.event((int64_t)ev_pos(e), ev_kind(e))) {
-                    if (why) *why = "window START/END events of motif " + std::to_string(m_lo + (int)mi) + " do not alternate";
-                    return false;
+
+    unsigned threads = std::min(std::thread::hardware_concurrency(), 16u);
+    if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
+    threads = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)threads, nm, (size_t)256}));
+
+    // Phase 1 (parallel over motifs): every worker replays the state machines of its motifs over the whole
+    // record, tile by tile, settling pending groups as soon as their reporting window is known to precede the
+    // next tile, so that a call is generated while its tile (or the one before) is current.  Calls go to a
+    // per-worker vector; cut[t] marks where tile t's calls start.  A worker's calls inside a tile are motif-major.
+    struct Worker { std::vector<RibbitCall> calls; std::vector<size_t> cut; std::vector<RibbitCall> flush; std::string err; };
+    std::vector<Worker> work(threads);
+    auto phase1 = [&](unsigned w) {
+        Worker &me = work[w];
+        std::vector<size_t> mine;
+        for (size_t mi = w; mi < nm; mi += threads) mine.push_back(mi);
+        std::vector<WindowFsm> fsm;
+        std::vector<MotifCursor> cur;
+        for (size_t mi : mine) { fsm.emplace_back(hp, m_lo + (int32_t)mi); cur.emplace_back(src, mi); }
+        me.cut.assign((size_t)ntile + 1, 0);
+        for (int64_t t = 0; t < ntile; ++t) {
+            me.cut[(size_t)t] = me.calls.size();
+            const int64_t next_tile = (t + 1) * TILE;
+            for (size_t k = 0; k < mine.size(); ++k) {
+                WindowFsm &f = fsm[k];
+                MotifCursor &c = cur[k];
+                f.set_output(&me.calls);
+                for (; !c.done(); c.next()) {
+                    const uint64_t e = c.peek();
+                    if ((int64_t)ev_pos(e) >= next_tile) break;
+                    if (!f.event((int64_t)ev_pos(e), ev_kind(e))) {
+                        me.err = "window START/END events of motif " + std::to_string(m_lo + (int)mine[k]) + " do not alternate";
+                        return;
+                    }
                 }
+                f.settle_up_to(next_tile);
             }
-            f.settle_up_to(next_tile);
         }
-        // calls generated from here on have pos >= next_tile + 7, so everything below next_tile is final
-        if (batch.empty()) { flushed_below = next_tile; continue; }
-        by_motif.resize(batch.size());
-        count.assign(nm + 1, 0);
-        for (const RibbitCall &c : batch) ++count[(size_t)(c.mlen - m_lo) + 1];
-        for (size_t k = 0; k < nm; ++k) count[k + 1] += count[k];
-        for (const RibbitCall &c : batch) by_motif[count[(size_t)(c.mlen - m_lo)]++] = c;
-        const int64_t span = next_tile - flushed_below;
-        count.assign((size_t)span + 2, 0);
-        for (const RibbitCall &c : by_motif) {
-            if (c.pos < flushed_below) { if (why) *why = "call generated out of order"; return false; }
-            if (c.pos < next_tile) ++count[(size_t)(c.pos - flushed_below) + 1];
+        me.cut[(size_t)ntile] = me.calls.size();
+        for (size_t k = 0; k < mine.size(); ++k) {
+            if (!cur[k].done()) { me.err = "event beyond the end of the record"; return; }
+            fsm[k].set_output(&me.flush);
+            if (!fsm[k].finish()) { me.err = "window event stream ends inside a streak"; return; }
         }
-        for (int64_t k = 0; k < span; ++k) count[(size_t)k + 1] += count[(size_t)k];
-        const size_t base = calls.size();
-        calls.resize(base + count[(size_t)span]);
-        for (const RibbitCall &c : by_motif) {
-            if (c.pos < next_tile) calls[base + count[(size_t)(c.pos - flushed_below)]++] = c;
-            else carry.push_back(c);
-        }
-        flushed_below = next_tile;
+    };
+    {
+        std::vector<std::thread> pool;
+        for (unsigned w = 1; w < threads; ++w) pool.emplace_back(phase1, w);
+        phase1(0);
+        for (std::thread &t : pool) t.join();
     }
-    for (size_t mi = 0; mi < nm; ++mi)
-        if (!cur[mi].done()) { if (why) *why = "event beyond the end of the record"; return false; }
-    // leftovers beyond the last tile boundary, then the end-of-sequence flush in motif order
-    std::stable_sort(carry.begin(), carry.end(), call_order);
-    calls.insert(calls.end(), carry.begin(), carry.end());
-    batch.clear();
-    for (size_t mi = 0; mi < nm; ++mi) {
-        fsm[mi].set_output(&batch);
-        if (!fsm[mi].finish()) { if (why) *why = "window event stream ends inside a streak"; return false; }
+    for (const Worker &w : work)
+        if (!w.err.empty()) { if (why) *why = w.err; return false; }
+
+    // Phase 2: a call generated while tile t was current has pos in [t*TILE, (t+1)*TILE + 7), i.e. it belongs to
+    // ordering bucket t or t+1.  Count per bucket, prefix-sum, then fill and order every bucket independently
+    // (parallel over buckets): (pos, motif) order by two stable counting sorts.
+    const size_t nb = (size_t)ntile + 1;
+    std::vector<size_t> bucket_n(nb + 1, 0);
+    auto bucket_of = [&](const RibbitCall &c) { return (size_t)(c.pos / TILE); };
+    for (const Worker &w : work)
+        for (const RibbitCall &c : w.calls) {
+            const size_t bk = bucket_of(c);
+            if (bk >= nb) { if (why) *why = "call beyond the end of the record"; return false; }
+            ++bucket_n[bk + 1];
+        }
+    for (size_t k = 0; k < nb; ++k) bucket_n[k + 1] += bucket_n[k];
+    calls.resize(bucket_n[nb]);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> bad{false};
+    auto phase2 = [&]() {
+        std::vector<RibbitCall> batch, by_motif;
+        std::vector<uint32_t> count;
+        for (size_t bk; (bk = next.fetch_add(1)) < nb;) {
+            batch.clear();
+            // bucket bk receives calls generated during tiles bk-1 and bk
+            for (const Worker &w : work)
+                for (int64_t t = (int64_t)bk - 1; t <= (int64_t)bk; ++t) {
+                    if (t < 0 || t >= ntile) continue;
+                    for (size_t i = w.cut[(size_t)t]; i < w.cut[(size_t)t + 1]; ++i)
+                        if (bucket_of(w.calls[i]) == bk) batch.push_back(w.calls[i]);
+                }
+            if (batch.size() != bucket_n[bk + 1] - bucket_n[bk]) { bad = true; return; }
+            if (batch.empty()) continue;
+            by_motif.resize(batch.size());
+            count.assign(nm + 1, 0);
+            for (const RibbitCall &c : batch) ++count[(size_t)(c.mlen - m_lo) + 1];
+            for (size_t k = 0; k < nm; ++k) count[k + 1] += count[k];
+            for (const RibbitCall &c : batch) by_motif[count[(size_t)(c.mlen - m_lo)]++] = c;
+            const int64_t base_pos = (int64_t)bk * TILE;
+            count.assign((size_t)TILE + 1, 0);
+            for (const RibbitCall &c : by_motif) ++count[(size_t)(c.pos - base_pos) + 1];
+            for (int64_t k = 0; k < TILE; ++k) count[(size_t)k + 1] += count[(size_t)k];
+            RibbitCall *dst = calls.data() + bucket_n[bk];
+            for (const RibbitCall &c : by_motif) dst[count[(size_t)(c.pos - base_pos)]++] = c;
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (unsigned w = 1; w < threads; ++w) pool.emplace_back(phase2);
+        phase2();
+        for (std::thread &t : pool) t.join();
     }
-    std::stable_sort(batch.begin(), batch.end(), call_order);
-    calls.insert(calls.end(), batch.begin(), batch.end());
+    if (bad) { if (why) *why = "call generated outside its ordering buckets"; return false; }
+
+    // the end-of-sequence flush comes last, in motif order
+    std::vector<RibbitCall> flush;
+    for (const Worker &w : work) flush.insert(flush.end(), w.flush.begin(), w.flush.end());
+    std::stable_sort(flush.begin(), flush.end(), call_order);
+    calls.insert(calls.end(), flush.begin(), flush.end());
     return true;
 }
 

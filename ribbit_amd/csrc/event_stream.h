@@ -54,7 +54,7 @@ bool pair_perfect_runs_partial(const EventSource &src, int64_t own_lo, int64_t o
                                std::vector<RibbitRun> &runs, std::vector<uint64_t> &halves, std::string *why);
 
 // parse_perfect_shiftxor.cpp:175-223: runs -> the addSeed calls the perfect scanner makes, in its order
-void perfect_calls_from_runs(const std::vector<RibbitRun> &runs, int64_t length, int min_shift, std::vector<RibbitCall> &calls);
+void perfect_calls_from_runs(const RibbitRun *runs, size_t n_runs, int64_t length, int min_shift, std::vector<RibbitCall> &calls);
 
 // Replay of the per-motif window state machines (window_fsm.h), tile by tile, producing the call list in the
 // reference's call order (scan position major, motif minor, end-of-sequence flush last) without a global

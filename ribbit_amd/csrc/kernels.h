@@ -40,6 +40,19 @@ void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint3
 void launch_compact_events(const uint64_t *events, uint32_t ev_cap, uint32_t *counters, uint64_t *dense,
                            hipStream_t stream);
 
+// Device-side pairing of the perfect scan's events (still in their EV_SHARDS regions, counters[] as the scan
+// left them) into RibbitRun records ordered by (motif, start): parse_perfect_shiftxor.cpp:173-223's run
+// bookkeeping.  table: nm*ntile 8-byte entries, run_base: nm*ntile words, partial: nm*ntile/1024+1 words,
+// status: PAIR_STATUS_WORDS words (all device scratch, initialised here).  runs holds run_cap records.
+struct PairLaunch {
+    uint32_t m_lo, nm;        // first motif, number of motifs
+    uint32_t ntile;           // tiles of TILE_BASES positions covering 0..L
+    uint32_t region_cap;      // events per region
+};
+void launch_pair_runs(const uint64_t *events, const uint32_t *counters, const PairLaunch &pl, void *table,
+                      uint32_t *run_base, uint32_t *partial, void *runs, uint32_t run_cap, uint32_t *status,
+                      hipStream_t stream);
+
 // X_shift words [w0, w0+nw) -> out_words (device); if count != nullptr also adds the popcount of
 // bits in [p0, p1) to *count.
 void launch_plane_words(const DevicePlanes &pl, int shift, int64_t w0, int64_t nw, uint32_t *out_words,

@@ -13,6 +13,7 @@
 //     written out, compacted in position order with a wave prefix sum.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
 
 #include "kernels.h"
@@ -762,6 +763,206 @@ void launch_compact_events(const uint64_t *events, uint32_t ev_cap, uint32_t *co
                            hipStream_t stream) {
     hipLaunchKernelGGL(compact_events_kernel, dim3(EV_SHARDS, 16), dim3(256), 0, stream, events,
                        ev_cap / (uint32_t)EV_SHARDS, counters, dense);
+}
+
+// ------------------------------------------------------------- device-side run pairing (a5)
+// The perfect scan leaves its events as position-ordered chunks, exactly one per (motif, tile) that has
+// any event, scattered over EV_SHARDS regions in arrival order.  These kernels turn them into the run
+// records of the perfect stage, ordered by (motif, start), without a sort and without the host:
+//   1. chunk_bounds: every event looks at its neighbours; the first/last event of a chunk records the
+//      chunk's [begin, end) in a direct-address table keyed (motif, tile);
+//   2. chunk_starts + scan: START events per chunk, exclusive prefix sum in (motif, tile) order;
+//   3. pair_runs: every START event finds its END (the next event of the chunk, or the first event of
+//      the next non-empty tile of the same motif) and writes its run at prefix + index-in-chunk.
+// Malformed streams (which would mean a kernel bug) raise PAIR_* flags instead of producing garbage.
+struct ChunkEntry { uint32_t begin1, end1; };    // global event index + 1; 0 = no chunk
+
+__device__ __forceinline__ bool chunk_key_of(uint64_t e, const PairLaunch &pl, uint32_t &key) {
+    const uint32_t mi = ev_mlen(e) - pl.m_lo;
+    const uint32_t tile = ev_pos(e) / (uint32_t)TILE_BASES;
+    key = mi * pl.ntile + tile;
+    return mi < pl.nm && tile < pl.ntile;
+}
+
+__device__ __forceinline__ uint32_t region_count(const uint32_t *counters, uint32_t shard, uint32_t region_cap) {
+    const uint32_t raw = counters[shard * EV_COUNTER_STRIDE];
+    return raw < region_cap ? raw : region_cap;
+}
+
+__global__ __launch_bounds__(256) void pair_chunk_bounds_kernel(const uint64_t *__restrict__ events,
+                                                                const uint32_t *__restrict__ counters, PairLaunch pl,
+                                                                ChunkEntry *__restrict__ table,
+                                                                uint32_t *__restrict__ status) {
+    const uint32_t shard = blockIdx.y;
+    const uint32_t n = region_count(counters, shard, pl.region_cap);
+    const uint64_t *ev = events + (size_t)shard * pl.region_cap;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint64_t e = ev[i];
+        uint32_t key, other;
+        if (!chunk_key_of(e, pl, key)) { atomicOr(&status[PAIR_FLAGS], (uint32_t)PAIR_BAD_EVENT); continue; }
+        const uint32_t g = shard * pl.region_cap + i;
+        const bool first = i == 0 || !chunk_key_of(ev[i - 1], pl, other) || other != key;
+        const bool last = i + 1 == n || !chunk_key_of(ev[i + 1], pl, other) || other != key;
+        if (first && atomicExch(&table[key].begin1, g + 1u) != 0u) atomicOr(&status[PAIR_FLAGS], (uint32_t)PAIR_DUP_CHUNK);
+        if (last) table[key].end1 = g + 2u;
+        // inside a chunk START and END alternate
+        if (!first && (ev_kind(ev[i - 1]) == EV_START) == (ev_kind(e) == EV_START))
+            atomicOr(&status[PAIR_FLAGS], (uint32_t)PAIR_NOT_ALTERNATING);
+    }
+}
+
+// START events of chunk `key` (0 for an empty entry)
+__device__ __forceinline__ uint32_t chunk_start_count(const ChunkEntry *table, const uint64_t *events, uint32_t key) {
+    const ChunkEntry c = table[key];
+    if (c.begin1 == 0u) return 0u;
+    const uint32_t cnt = c.end1 - c.begin1;
+    return (cnt + (ev_kind(events[c.begin1 - 1u]) == EV_START ? 1u : 0u)) >> 1;
+}
+
+constexpr int SCAN_ITEMS = 4;                        // table entries per thread
+constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t &block_total) {
+    __shared__ uint32_t wave_sum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = (uint32_t)wave_inclusive_scan((int)v);
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { if (w < wave) before += wave_sum[w]; total += wave_sum[w]; }
+    __syncthreads();
+    block_total = total;
+    return before + incl - v;
+}
+
+// pass A: per-entry START counts -> run_base[], per-block sums -> partial[]
+__global__ __launch_bounds__(256) void pair_chunk_starts_kernel(const ChunkEntry *__restrict__ table,
+                                                                const uint64_t *__restrict__ events, uint32_t entries,
+                                                                uint32_t *__restrict__ run_base,
+                                                                uint32_t *__restrict__ partial) {
+    const uint32_t base = blockIdx.x * (uint32_t)SCAN_BLOCK + threadIdx.x * (uint32_t)SCAN_ITEMS;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const uint32_t key = base + (uint32_t)k;
+        const uint32_t c = key < entries ? chunk_start_count(table, events, key) : 0u;
+        if (key < entries) run_base[key] = c;
+        sum += c;
+    }
+    uint32_t total;
+    (void)block_exclusive_scan(sum, total);
+    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+
+// pass B: exclusive scan of partial[] by one block; the grand total goes to status[PAIR_TOTAL]
+__global__ __launch_bounds__(256) void pair_scan_partials_kernel(uint32_t *__restrict__ partial, uint32_t nblocks,
+                                                                 uint32_t *__restrict__ status) {
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nblocks; base += 256u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? partial[i] : 0u;
+        uint32_t total;
+        const uint32_t excl = block_exclusive_scan(v, total);
+        if (i < nblocks) partial[i] = carry + excl;
+        carry += total;
+    }
+    if (threadIdx.x == 0) status[PAIR_TOTAL] = carry;
+}
+
+// pass C: run_base[] counts -> exclusive prefix in (motif, tile) order
+__global__ __launch_bounds__(256) void pair_run_base_kernel(uint32_t entries, const uint32_t *__restrict__ partial,
+                                                            uint32_t *__restrict__ run_base) {
+    const uint32_t base = blockIdx.x * (uint32_t)SCAN_BLOCK + threadIdx.x * (uint32_t)SCAN_ITEMS;
+    uint32_t c[SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        c[k] = base + (uint32_t)k < entries ? run_base[base + (uint32_t)k] : 0u;
+        sum += c[k];
+    }
+    uint32_t total;
+    uint32_t at = partial[blockIdx.x] + block_exclusive_scan(sum, total);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + (uint32_t)k < entries) run_base[base + (uint32_t)k] = at;
+        at += c[k];
+    }
+}
+
+struct RunRecord { int32_t start, end, mlen, term; };    // == RibbitRun (ribbit_hip.h)
+
+__global__ __launch_bounds__(256) void pair_runs_kernel(const uint64_t *__restrict__ events,
+                                                        const uint32_t *__restrict__ counters, PairLaunch pl,
+                                                        const ChunkEntry *__restrict__ table,
+                                                        const uint32_t *__restrict__ run_base,
+                                                        RunRecord *__restrict__ runs, uint32_t run_cap,
+                                                        uint32_t *__restrict__ status) {
+    const uint32_t shard = blockIdx.y;
+    const uint32_t n = region_count(counters, shard, pl.region_cap);
+    const uint64_t *ev = events + (size_t)shard * pl.region_cap;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint64_t e = ev[i];
+        uint32_t key;
+        if (!chunk_key_of(e, pl, key)) continue;                        // flagged by chunk_bounds
+        const ChunkEntry c = table[key];
+        const uint32_t g1 = shard * pl.region_cap + i + 1u;             // this event's index + 1
+        if (c.begin1 == 0u || g1 < c.begin1 || g1 >= c.end1) continue;  // duplicate chunk, flagged by chunk_bounds
+        const uint32_t mi = key / pl.ntile, tile = key - mi * pl.ntile;
+        const bool chunk_opens_with_end = ev_kind(events[c.begin1 - 1u]) != EV_START;
+        if (ev_kind(e) != EV_START) {
+            // the END that opens a chunk closes a run begun in an earlier tile: there must be one
+            if (g1 == c.begin1) {
+                bool ok = false;
+                for (uint32_t t = tile; t-- > 0u;) {
+                    const ChunkEntry p = table[mi * pl.ntile + t];
+                    if (p.begin1 == 0u) continue;
+                    ok = ev_kind(events[p.end1 - 2u]) == EV_START;
+                    break;
+                }
+                if (!ok) atomicOr(&status[PAIR_FLAGS], (uint32_t)PAIR_NOT_ALTERNATING);
+            }
+            continue;
+        }
+        // partner: the next event of this chunk, or the first event of the next non-empty tile of this motif
+        uint64_t closer = 0;
+        bool found = false;
+        if (g1 + 1u < c.end1) { closer = ev[i + 1]; found = true; }
+        else {
+            for (uint32_t t = tile + 1u; t < pl.ntile; ++t) {
+                const ChunkEntry nx = table[key + (t - tile)];
+                if (nx.begin1 == 0u) continue;
+                closer = events[nx.begin1 - 1u];
+                found = true;
+                break;
+            }
+        }
+        if (!found) { atomicOr(&status[PAIR_FLAGS], (uint32_t)PAIR_UNTERMINATED); continue; }
+        const uint32_t kind = ev_kind(closer);
+        if (kind == EV_START || ev_pos(closer) <= ev_pos(e)) { atomicOr(&status[PAIR_FLAGS], (uint32_t)PAIR_NOT_ALTERNATING); continue; }
+        const uint32_t in_chunk = (g1 - c.begin1 - (chunk_opens_with_end ? 1u : 0u)) >> 1;
+        const uint32_t slot = run_base[key] + in_chunk;
+        if (slot >= run_cap) { atomicOr(&status[PAIR_FLAGS], (uint32_t)PAIR_NO_ROOM); continue; }
+        // RIBBIT_TERM_ZERO / _N / _EOS = EV_END_ZERO / _N / _EOS - 1
+        runs[slot] = RunRecord{(int32_t)ev_pos(e), (int32_t)ev_pos(closer), (int32_t)(mi + pl.m_lo), (int32_t)kind - 1};
+    }
+}
+
+void launch_pair_runs(const uint64_t *events, const uint32_t *counters, const PairLaunch &pl, void *table,
+                      uint32_t *run_base, uint32_t *partial, void *runs, uint32_t run_cap, uint32_t *status,
+                      hipStream_t stream) {
+    const uint32_t entries = pl.nm * pl.ntile;
+    const uint32_t nblocks = (entries + (uint32_t)SCAN_BLOCK - 1u) / (uint32_t)SCAN_BLOCK;
+    const uint32_t per_region = std::min<uint32_t>(std::max<uint32_t>((pl.region_cap + 255u) / 256u, 1u), 64u);
+    (void)hipMemsetAsync(table, 0, (size_t)entries * sizeof(ChunkEntry), stream);
+    (void)hipMemsetAsync(status, 0, PAIR_STATUS_WORDS * sizeof(uint32_t), stream);
+    hipLaunchKernelGGL(pair_chunk_bounds_kernel, dim3(per_region, EV_SHARDS), dim3(256), 0, stream, events, counters, pl,
+                       (ChunkEntry *)table, status);
+    hipLaunchKernelGGL(pair_chunk_starts_kernel, dim3(nblocks), dim3(256), 0, stream, (const ChunkEntry *)table, events,
+                       entries, run_base, partial);
+    hipLaunchKernelGGL(pair_scan_partials_kernel, dim3(1), dim3(256), 0, stream, partial, nblocks, status);
+    hipLaunchKernelGGL(pair_run_base_kernel, dim3(nblocks), dim3(256), 0, stream, entries, (const uint32_t *)partial, run_base);
+    hipLaunchKernelGGL(pair_runs_kernel, dim3(per_region, EV_SHARDS), dim3(256), 0, stream, events, counters, pl,
+                       (const ChunkEntry *)table, (const uint32_t *)run_base, (RunRecord *)runs, run_cap, status);
 }
 
 // ------------------------------------------------------------------- plane query (a5, a13)

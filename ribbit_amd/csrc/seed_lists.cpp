@@ -277,7 +277,8 @@ void walk_back(const std::vector<RibbitSeed> &list, long &i, int seed_start, Pus
 // Divergence D1: an empty substitution list is treated as exhausted (the reference reads it: UB).
 void merge_all_lists(SeedLists &sl, Cursor2 from, int seed_start, std::vector<Cand3> &out) {
     const std::vector<RibbitSeed> &P = sl.perfect, &S = sl.subst, &A = sl.anchored;
-    std::vector<Cand3> ps;
+    static thread_local std::vector<Cand3> ps;       // scratch, reused across the millions of calls of a record
+    ps.clear();
     bool p_done = P.empty(), s_done = false;
     if (S.empty()) { s_done = true; ++sl.guard_hits; }
     long pi = from.perfect, si = from.subst;
@@ -329,9 +330,9 @@ void merge_all_lists(SeedLists &sl, Cursor2 from, int seed_start, std::vector<Ca
 Cursor2 anchored_add(SeedLists &sl, int seed_start, int seed_end, int mlen, const Cursor2 from, int seed_type) {
     std::vector<RibbitSeed> &P = sl.perfect, &S = sl.subst, &A = sl.anchored;
     constexpr int RA = RIBBIT_RANK_A, RC = RIBBIT_RANK_C, RP = RIBBIT_RANK_P, RS = RIBBIT_RANK_S, RQ = RIBBIT_RANK_Q;
-    std::vector<Cand3> cands;
     struct Child { int idx, mlen, type; };
-    std::vector<Child> factor_children, nonfactor_children;
+    static thread_local std::vector<Cand3> cands;    // scratch, reused across the millions of calls of a record
+    static thread_local std::vector<Child> factor_children, nonfactor_children;
 
     // state the reference keeps in function-scope variables across loop iterations; the coverage code
     // after the loop reads whatever was left in them (Q8)

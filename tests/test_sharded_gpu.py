@@ -36,7 +36,7 @@ def test_parts_own_disjoint_ranges_and_every_event_once():
     assert np.array_equal(union, np.sort(whole))
 
 
-@pytest.mark.parametrize("nparts", [2, 7])
+@pytest.mark.parametrize("nparts", [4, 7])      # cuts at 30 kb resp. 17/34 kb: inside the 40-kb repeat
 def test_chunk_local_pairing_plus_edge_halves_gives_the_whole_records_runs(nparts):
     name, seq, m_lo, m_hi = [c for c in edge_cases() if c[0] == "long_run_cross_tiles"][0]
     seq = seq + simulated_cases()[1][1][:80_000]
