@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--bases", type=int, default=WORKLOAD_BASES, help="bases per GPU (default: BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "shm", "rccl"],
+                    help="N > 1: how the chunks' run records reach rank 0's host merge (auto: shm on one node, else rccl)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--verify", action="store_true",
                     help="N > 1: rank 0 also scans the whole record on its own GPU and checks the sharded runs against it")
@@ -63,7 +65,7 @@ def main():
     import torch
 
     import ribbit_amd
-    from ribbit_amd.distributed import allgather_array, gather_array
+    from ribbit_amd.distributed import allgather_array, gather_array, open_node_gather, same_node
     from ribbit_amd.simulate import simulate_sequence
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,17 +102,49 @@ def main():
 
     sc = ribbit_amd.Scanner(M_LO, M_HI, device=local_rank)
 
+    # N > 1: every rank scans and pairs its chunk on its GPU; the run records (16 B each) are then gathered for the
+    # host-side merge on rank 0.  On one node every GPU copies its records down its own PCIe link into a page-locked
+    # segment all ranks map ("shm": N links in parallel, no second hop); otherwise gather-v over RCCL ("rccl").
+    exchange = args.exchange
+    if exchange == "auto":
+        exchange = "shm" if world > 1 and same_node() else "rccl"
+    ng = None
+    if world > 1 and exchange == "shm":
+        sc.load_record_device(d_ascii.data_ptr(), d_ascii.numel())
+        probe, _ = sc.scan_perfect_chunk(own_lo, own_hi, rank * args.bases - own_lo)
+        cap = max(int(a[0]) for a in allgather_array(np.array([len(probe)], dtype=np.int64), xdev))
+        ng = open_node_gather(ribbit_amd.RUN_DT, 2 * cap + 4096, 2 * (M_HI - M_LO + 1))
+        for addr, nbytes in ng.my_cells():
+            try:
+                sc.host_register(addr, nbytes)
+            except ribbit_amd.RibbitHipError as e:       # still correct, the copies are just staged by the runtime
+                print(f"rank {rank}: shared segment not page-locked ({e})", file=sys.stderr)
+                break
+    step_no = [0]
+
     def step():
         sc.load_record_device(d_ascii.data_ptr(), d_ascii.numel())
         if world == 1:
             return sc.scan_perfect_runs(copy=False)       # the C ABI's own result buffer (pinned), as a C caller sees it
-        # pair the chunk's own events locally (work scales with the chunk), then gather-v the sparse run records
-        # and the few edge events over RCCL/xGMI; rank 0 pairs the edges and holds the record's runs
-        runs, halves = sc.perfect_runs_partial(own_lo, own_hi, rank * args.bases - own_lo)
+        step_no[0] += 1
+        k = step_no[0]
+        if ng is not None:
+            if rank == 0 and k > 1:
+                ng.release(k - 1)                         # the previous step's views are dead from here on
+            ng.wait_free(k)
+            rec, hv = ng.mine(k)
+            n, nh = sc.scan_perfect_chunk(own_lo, own_hi, rank * args.bases - own_lo, out=rec, halves_out=hv)
+            ng.publish(k, n, nh)
+            if rank != 0:
+                return rec[:n]
+            parts, halves = ng.collect(k)
+            # the record's runs: every chunk's records in place (term < 0 = place holder) + the runs cut by chunk edges
+            return parts + [ribbit_amd.join_run_halves(halves)]
+        runs, halves = sc.scan_perfect_chunk(own_lo, own_hi, rank * args.bases - own_lo)
         all_runs = gather_array(runs, xdev)
         all_halves = gather_array(halves, xdev)
         if rank == 0:
-            return np.concatenate(all_runs + [ribbit_amd.pair_halves(np.concatenate(all_halves))])
+            return all_runs + [ribbit_amd.join_run_halves(all_halves)]
         return runs
 
     for _ in range(args.warmup):
@@ -129,7 +163,8 @@ def main():
         kernel_ms.append(sc.timing_ms(1))
         pack_ms.append(sc.timing_ms(0))
         gpu_ms.append(sc.timing_ms(2))
-        nruns, nevents = len(runs), sc.last_event_count()
+        nruns = len(runs) if world == 1 else (sum(len(r) for r in runs) if rank == 0 else len(runs))
+        nevents = sc.last_event_count()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -143,9 +178,10 @@ def main():
     if args.verify and world > 1:
         whole = allgather_array(np.frombuffer(seq, dtype=np.uint8).copy(), xdev)
         if rank == 0:
+            got = np.concatenate(runs)
+            got = np.sort(got[got["term"] >= 0], order=["mlen", "start"])
             sc.load_record(b"".join(w.tobytes() for w in whole))
             want = sc.scan_perfect_runs()
-            got = np.sort(runs, order=["mlen", "start"])
             assert np.array_equal(got.view("<i4"), want.view("<i4")), "chunk-sharded runs differ from the single-GPU scan"
             print(f"verify: {len(want)} runs identical to the single-GPU scan of the whole record", file=sys.stderr)
 
@@ -167,7 +203,9 @@ def main():
             "config": {"workload": f"{args.bases} bp synthetic record per GPU, -m {M_LO} -M {M_HI}, "
                                    "pack + perfect shift-XOR scan (BASELINE.json configs[1])",
                        "bases_per_gpu": args.bases, "min_motif": M_LO, "max_motif": M_HI,
-                       "parallelism": f"one record chunk-sharded x{world} (halos) + gather-v of runs over RCCL" if world > 1 else "single GPU"},
+                       "parallelism": (f"one record chunk-sharded x{world} (halos), runs paired on each GPU, gathered for rank 0's host merge "
+                                       + ("through page-locked node-shared memory (one PCIe link per GPU)" if ng is not None else "by gather-v over RCCL"))
+                                      if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "scan_perfect_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": args.bases * ALGO_BYTES_PER_BASE,
@@ -181,6 +219,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(seq)
         print(json.dumps(out), flush=True)
 
+    if ng is not None:
+        dist.barrier()
+        for addr, _ in ng.my_cells():
+            try:
+                sc.host_unregister(addr)
+            except ribbit_amd.RibbitHipError:
+                pass
+        runs = None
+        ng.close()
     sc.close()
     if world > 1:
         dist.destroy_process_group()

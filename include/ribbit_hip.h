@@ -316,6 +316,28 @@ int ribbit_hip_stage_events(RibbitHandle *h, int stage, int64_t own_lo, int64_t 
 int ribbit_hip_perfect_runs_partial(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset,
                                     const RibbitRun **runs, size_t *n_runs, const uint64_t **halves, size_t *n_halves);
 
+/* The same on the device end to end (no event ever reaches the host): scan the loaded piece, pair on the GPU, and
+ * deliver one record per run START of the piece, ordered by (motif, start), into dst (caller's buffer of dst_cap
+ * records; ideally pinned, see ribbit_hip_host_register) or, when dst is NULL, into handle-owned pinned memory;
+ * *out is where they are.  A record is either a complete run owned by this chunk (START in [own_lo, own_hi), END
+ * before own_hi; term = RIBBIT_TERM_*) or a place holder to skip (term = RIBBIT_RUN_NOT_OWNED: the run belongs to
+ * a neighbour or is cut by the own range).  The cut runs -- at most two per motif -- go to half_dst / *halves:
+ *   term RIBBIT_RUN_HALF_START     START owned, the END lies in a later chunk (end = -1);
+ *   term RIBBIT_RUN_HALF_END + t   END owned (terminator t), the START lies in an earlier chunk (start = -1).
+ * Over all chunks of a record the halves, ordered by (motif, position), pair up START, END into the remaining runs.
+ * Positions are shifted by pos_offset.  A whole record is own_lo = 0, own_hi = INT64_MAX, pos_offset = 0: only
+ * complete runs, no halves (that is what ribbit_hip_scan_perfect_runs does).
+ * Replaces the run bookkeeping of parse_perfect_shiftxor.cpp:173-223 for one chunk of a chunk-sharded record. */
+enum { RIBBIT_RUN_NOT_OWNED = -1, RIBBIT_RUN_HALF_START = 3, RIBBIT_RUN_HALF_END = 4 };
+int ribbit_hip_scan_perfect_chunk(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset,
+                                  RibbitRun *dst, size_t dst_cap, RibbitRun *half_dst, size_t half_dst_cap,
+                                  const RibbitRun **out, size_t *n, const RibbitRun **halves, size_t *n_halves);
+
+/* Page-lock a host buffer the caller owns (e.g. a shared-memory segment several ranks of one node write their
+ * chunk's records into) so that ribbit_hip_scan_perfect_chunk can DMA straight into it.  hipHostRegister. */
+int ribbit_hip_host_register(void *p, size_t bytes);
+int ribbit_hip_host_unregister(void *p);
+
 /* Words [word_lo, word_hi) of every composed plane XA_m (after the anchored stage's kernel ran),
  * motif-major, into out[(max_motif-min_motif+1) * (word_hi-word_lo)]. */
 int ribbit_hip_xa_words(RibbitHandle *h, int64_t word_lo, int64_t word_hi, uint32_t *out);

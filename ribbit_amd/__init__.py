@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 __all__ = ["RibbitHipError", "ScanParams", "Scanner", "library_path", "load_library", "host_replay_calls", "pack_planes", "pack_bit_planes",
-           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "host_refine_bed", "host_scan_from_events", "host_perfect_runs_from_events", "pair_halves", "ssw_align"]
+           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "host_refine_bed", "host_scan_from_events", "host_perfect_runs_from_events", "pair_halves", "ssw_align", "merge_chunk_runs", "join_run_halves",
+           "RUN_NOT_OWNED", "RUN_HALF_START", "RUN_HALF_END"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -44,6 +45,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_refine_bed", "ribbit_host_refine_bed", "ribbit_text_free",
     "ribbit_hip_stage_events", "ribbit_hip_xa_words", "ribbit_host_scan_from_events",
     "ribbit_host_perfect_runs_from_events", "ribbit_runs_free", "ribbit_hip_perfect_runs_partial",
+    "ribbit_hip_scan_perfect_chunk", "ribbit_hip_host_register", "ribbit_hip_host_unregister",
 ]
 
 
@@ -139,6 +141,10 @@ def load_library():
     L.ribbit_hip_stage_events.argtypes = [vp, C.c_int, i64, i64, i64, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
     L.ribbit_hip_xa_words.argtypes = [vp, i64, i64, vp]
     L.ribbit_hip_perfect_runs_partial.argtypes = [vp, i64, i64, i64, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ribbit_hip_scan_perfect_chunk.argtypes = [vp, i64, i64, i64, vp, C.c_size_t, vp, C.c_size_t,
+                                                C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ribbit_hip_host_register.argtypes = [vp, C.c_size_t]
+    L.ribbit_hip_host_unregister.argtypes = [vp]
     L.ribbit_host_scan_from_events.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t,
                                                vp, vp, vp, vp, vp, vp, C.POINTER(SeedLists)]
     L.ribbit_host_perfect_runs_from_events.argtypes = [C.POINTER(ScanParams), C.c_size_t, vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -345,6 +351,35 @@ def pair_halves(halves) -> np.ndarray:
     return out
 
 
+RUN_NOT_OWNED, RUN_HALF_START, RUN_HALF_END = -1, 3, 4
+
+
+def join_run_halves(halves) -> np.ndarray:
+    """Half records of all chunks of one record (Scanner.scan_perfect_chunk) -> the runs they form: ordered by
+    (motif, position) every open START is closed by the next orphan END of its motif."""
+    hv = np.concatenate([np.asarray(h, dtype=RUN_DT) for h in halves]) if len(halves) else np.zeros(0, RUN_DT)
+    hs = hv[hv["term"] == RUN_HALF_START]
+    he = hv[hv["term"] >= RUN_HALF_END]
+    if len(hs) + len(he) != len(hv) or len(hs) != len(he):
+        raise RibbitHipError(f"{len(hs)} open run starts but {len(he)} orphan run ends across the chunks")
+    hs = hs[np.lexsort((hs["start"], hs["mlen"]))]
+    he = he[np.lexsort((he["end"], he["mlen"]))]
+    if np.any(hs["mlen"] != he["mlen"]) or np.any(he["end"] <= hs["start"]) or \
+            np.any((hs["mlen"][1:] == hs["mlen"][:-1]) & (hs["start"][1:] <= he["end"][:-1])):
+        raise RibbitHipError("run halves of the chunks do not pair up")
+    joined = np.zeros(len(hs), RUN_DT)
+    joined["start"], joined["end"], joined["mlen"], joined["term"] = hs["start"], he["end"], hs["mlen"], he["term"] - RUN_HALF_END
+    return joined
+
+
+def merge_chunk_runs(parts, halves) -> np.ndarray:
+    """All chunks' run records and halves -> the record's runs ordered by (mlen, start) (copies; for tests and
+    small inputs -- a streaming consumer walks the parts in place and skips term == RUN_NOT_OWNED)."""
+    allr = np.concatenate([np.asarray(p) for p in parts] + [join_run_halves(halves)])
+    allr = allr[allr["term"] >= 0]
+    return allr[np.lexsort((allr["start"], allr["mlen"]))]
+
+
 class Scanner:
     """One GPU-resident FASTA record and the scans over it.
 
@@ -489,6 +524,35 @@ class Scanner:
         r, nr, hv, nh = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
         self._check(self._L.ribbit_hip_perfect_runs_partial(self._h, own_lo, own_hi, pos_offset, C.byref(r), C.byref(nr), C.byref(hv), C.byref(nh)))
         return _copy(r.value, nr.value, RUN_DT), _copy(hv.value, nh.value, np.dtype("<u8"))
+
+    def scan_perfect_chunk(self, own_lo: int, own_hi: int, pos_offset: int = 0, out: np.ndarray | None = None,
+                           halves_out: np.ndarray | None = None):
+        """ribbit_hip_scan_perfect_chunk: device-paired run records of one chunk.
+        Without out -> (read-only view of the library's pinned run records, copy of the halves).
+        With out / halves_out (RUN_DT arrays to fill in place, e.g. over registered shared memory) -> (n, n_halves).
+        Records with term == RUN_NOT_OWNED are place holders to skip."""
+        p, n, hp, nh = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        if out is not None:
+            assert out.dtype == RUN_DT and out.flags.c_contiguous and halves_out is not None and halves_out.dtype == RUN_DT
+            self._check(self._L.ribbit_hip_scan_perfect_chunk(self._h, own_lo, own_hi, pos_offset, out.ctypes.data, len(out),
+                                                              halves_out.ctypes.data, len(halves_out),
+                                                              C.byref(p), C.byref(n), C.byref(hp), C.byref(nh)))
+            return n.value, nh.value
+        self._check(self._L.ribbit_hip_scan_perfect_chunk(self._h, own_lo, own_hi, pos_offset, None, 0, None, 0,
+                                                          C.byref(p), C.byref(n), C.byref(hp), C.byref(nh)))
+        halves = _copy(hp.value, nh.value, RUN_DT)
+        if n.value == 0:
+            return np.zeros(0, RUN_DT), halves
+        view = np.frombuffer((C.c_char * (n.value * RUN_DT.itemsize)).from_address(p.value), dtype=RUN_DT)
+        view.flags.writeable = False
+        return view, halves
+
+    def host_register(self, address: int, nbytes: int) -> None:
+        """Page-lock caller-owned host memory so that scan_perfect_chunk(out=...) DMAs straight into it."""
+        self._check(self._L.ribbit_hip_host_register(address, nbytes))
+
+    def host_unregister(self, address: int) -> None:
+        self._check(self._L.ribbit_hip_host_unregister(address))
 
     def xa_words(self, word_lo: int, word_hi: int):
         nm = self.params.max_motif - self.params.min_motif + 1

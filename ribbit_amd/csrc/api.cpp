@@ -125,8 +125,9 @@ struct RibbitHandle {
     DevBuf<uint64_t> d_pair_table;
     DevBuf<uint32_t> d_run_base, d_pair_partial, d_pair_status;
     PinnedBuf<uint32_t> h_pair_status;
-    PinnedBuf<RibbitRun> h_runs;
-    size_t n_runs = 0;
+    PinnedBuf<RibbitRun> h_runs, h_halves;
+    DevBuf<RibbitRun> d_halves;
+    size_t n_runs = 0, n_halves = 0;
     std::vector<RibbitCall> perfect_calls;
     bool subst_calls_valid = false;
     std::vector<RibbitCall> subst_calls;
@@ -313,9 +314,14 @@ rb::EventSource event_source(const RibbitHandle *h) {
 // Perfect stage on the device end to end: scan kernel -> START/END events (left in their regions, never
 // copied to the host) -> pairing kernels -> RibbitRun records ordered by (motif, start) -> one D2H copy
 // into pinned memory.  The host only checks the counters and the pairing status.
-int run_perfect_scan(RibbitHandle *h) {
+// own_lo/own_hi/pos_offset: see rb::PairLaunch (a whole record is 0, INT64_MAX, 0).  dst: where the records go
+// (caller's buffer of dst_cap records, ideally pinned) or nullptr for the handle's own pinned buffer.
+int run_perfect_scan_range(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset, RibbitRun *dst, size_t dst_cap,
+                           RibbitRun *half_dst = nullptr, size_t half_dst_cap = 0) {
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
-    if (h->runs_valid) return RIBBIT_OK;
+    const bool whole = own_lo == 0 && own_hi == INT64_MAX && pos_offset == 0 && !dst;
+    if (whole && h->runs_valid) return RIBBIT_OK;
+    h->runs_valid = h->calls_valid = false;
     int rc;
     if ((rc = bind_device(h))) return rc;
     if ((rc = h->d_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
@@ -326,6 +332,10 @@ int run_perfect_scan(RibbitHandle *h) {
     pr.m_lo = (uint32_t)h->params.min_motif;
     pr.nm = (uint32_t)(h->params.max_motif - h->params.min_motif + 1);
     pr.ntile = (uint32_t)(h->length / rb::TILE_BASES + 1);
+    pr.own_lo = own_lo; pr.own_hi = own_hi; pr.pos_offset = pos_offset;
+    const size_t half_cap = 2 * (size_t)pr.nm;
+    if ((rc = h->d_halves.ensure(half_cap))) return rc;
+    if ((rc = h->h_halves.ensure(half_cap))) return rc;
     const size_t entries = (size_t)pr.nm * pr.ntile;
     if (entries > 0xfffffff0u) return fail(RIBBIT_E_ARG, "record too long for %u motif sizes", pr.nm);
     if ((rc = h->d_pair_table.ensure(entries))) return rc;
@@ -351,7 +361,7 @@ int run_perfect_scan(RibbitHandle *h) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[3], h->stream));
         rb::launch_pair_runs(h->d_events.p, h->d_counters.p, pr, h->d_pair_table.p, h->d_run_base.p, h->d_pair_partial.p,
-                             h->d_dense.p, (uint32_t)(cap / 2), h->d_pair_status.p, h->stream);
+                             h->d_dense.p, (uint32_t)(cap / 2), h->d_halves.p, (uint32_t)half_cap, h->d_pair_status.p, h->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h->h_counters.p, h->d_counters.p, rb::EV_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(h->h_pair_status.p, h->d_pair_status.p, rb::PAIR_STATUS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
@@ -379,16 +389,27 @@ int run_perfect_scan(RibbitHandle *h) {
     }
     h->n_runs = h->h_pair_status.p[rb::PAIR_TOTAL];
     if (h->n_runs * 2 != produced) return fail(RIBBIT_E_INTERNAL, "%llu events but %zu runs", (unsigned long long)produced, h->n_runs);
-    if ((rc = h->h_runs.ensure(std::max<size_t>(h->n_runs, 1)))) return rc;
+    h->n_halves = h->h_pair_status.p[rb::PAIR_HALVES];
+    if (half_dst && h->n_halves > half_dst_cap) return fail(RIBBIT_E_OVERFLOW, "%zu half records do not fit the caller's buffer of %zu", h->n_halves, half_dst_cap);
+    if (!half_dst) half_dst = h->h_halves.p;
+    if (h->n_halves)
+        HIP_TRY(hipMemcpyAsync(half_dst, h->d_halves.p, h->n_halves * sizeof(RibbitRun), hipMemcpyDeviceToHost, h->stream));
+    if (dst && h->n_runs > dst_cap) return fail(RIBBIT_E_OVERFLOW, "%zu run records do not fit the caller's buffer of %zu", h->n_runs, dst_cap);
+    if (!dst) {
+        if ((rc = h->h_runs.ensure(std::max<size_t>(h->n_runs, 1)))) return rc;
+        dst = h->h_runs.p;
+    }
     if (h->n_runs)
-        HIP_TRY(hipMemcpyAsync(h->h_runs.p, h->d_dense.p, h->n_runs * sizeof(RibbitRun), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(dst, h->d_dense.p, h->n_runs * sizeof(RibbitRun), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipEventRecord(h->ev[5], h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->have_timing[1] = h->have_timing[2] = true;
     h->host_ms = 0.0;
-    h->runs_valid = true;
+    h->runs_valid = whole;
     return RIBBIT_OK;
 }
+
+int run_perfect_scan(RibbitHandle *h) { return run_perfect_scan_range(h, 0, INT64_MAX, 0, nullptr, 0); }
 
 int build_perfect_calls(RibbitHandle *h) {
     if (h->calls_valid) return RIBBIT_OK;
@@ -658,7 +679,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release();
     h->h_events.release(); h->h_counters.release(); h->h_query.release();
     h->d_pair_table.release(); h->d_run_base.release(); h->d_pair_partial.release(); h->d_pair_status.release();
-    h->h_pair_status.release(); h->h_runs.release();
+    h->h_pair_status.release(); h->h_runs.release(); h->h_halves.release(); h->d_halves.release();
     for (int i = 0; i < 6; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -971,6 +992,32 @@ int ribbit_hip_perfect_runs_partial(RibbitHandle *h, int64_t own_lo, int64_t own
     *n_runs = h->runs.size();
     *halves = h->export_events.data();
     *n_halves = h->export_events.size();
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_scan_perfect_chunk(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset, RibbitRun *dst, size_t dst_cap,
+                                  RibbitRun *half_dst, size_t half_dst_cap, const RibbitRun **out, size_t *n,
+                                  const RibbitRun **halves, size_t *n_halves) {
+    if (!h || !out || !n || !halves || !n_halves) return fail(RIBBIT_E_ARG, "null argument");
+    if (own_lo < 0 || own_hi < own_lo) return fail(RIBBIT_E_ARG, "bad own range");
+    int rc = run_perfect_scan_range(h, own_lo, own_hi, pos_offset, dst, dst_cap, half_dst, half_dst_cap);
+    if (rc) return rc;
+    *out = dst ? dst : h->h_runs.p;
+    *n = h->n_runs;
+    *halves = half_dst ? half_dst : h->h_halves.p;
+    *n_halves = h->n_halves;
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return fail(RIBBIT_E_ARG, "null argument");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_host_unregister(void *p) {
+    if (!p) return fail(RIBBIT_E_ARG, "null argument");
+    HIP_TRY(hipHostUnregister(p));
     return RIBBIT_OK;
 }
 

@@ -57,9 +57,13 @@ __host__ __device__ inline uint32_t ev_pos(uint64_t e) { return (uint32_t)e; }
 __host__ __device__ inline uint32_t ev_mlen(uint64_t e) { return (uint32_t)(e >> 32) & 0xffffu; }
 __host__ __device__ inline uint32_t ev_kind(uint64_t e) { return (uint32_t)(e >> 48) & 0xfu; }
 
+// `term` values of a run record beyond RIBBIT_TERM_* (ribbit_hip.h), used when the loaded piece is one chunk of a
+// longer record: the run's START or END lies in the chunk's own range but its partner does not.
+enum : int32_t { RUN_NOT_OWNED = -1, RUN_HALF_START = 3, RUN_HALF_END = 4 /* + RIBBIT_TERM_* of the END */ };
+
 // Device-side pairing of the perfect scan's events into runs (pair_runs_* kernels): status words
-//   [PAIR_FLAGS] error bits (0 = clean), [PAIR_TOTAL] number of runs written
-enum : uint32_t { PAIR_FLAGS = 0, PAIR_TOTAL = 1, PAIR_STATUS_WORDS = 4 };
+//   [PAIR_FLAGS] error bits (0 = clean), [PAIR_TOTAL] number of run records, [PAIR_HALVES] number of half records
+enum : uint32_t { PAIR_FLAGS = 0, PAIR_TOTAL = 1, PAIR_HALVES = 2, PAIR_STATUS_WORDS = 4 };
 enum : uint32_t {
     PAIR_BAD_EVENT = 1,        // motif or tile outside the launch
     PAIR_DUP_CHUNK = 2,        // two chunks for one (motif, tile)

@@ -48,10 +48,14 @@ struct PairLaunch {
     uint32_t m_lo, nm;        // first motif, number of motifs
     uint32_t ntile;           // tiles of TILE_BASES positions covering 0..L
     uint32_t region_cap;      // events per region
+    // chunk of a longer record: only runs whose START lies in [own_lo, own_hi) (positions of the loaded piece) are
+    // reported, with pos_offset added; a whole record is own_lo = 0, own_hi = INT64_MAX, pos_offset = 0
+    int64_t own_lo, own_hi, pos_offset;
 };
+// halves (half_cap >= 2*nm records) receives the runs cut by the own range, status[PAIR_HALVES] their number.
 void launch_pair_runs(const uint64_t *events, const uint32_t *counters, const PairLaunch &pl, void *table,
-                      uint32_t *run_base, uint32_t *partial, void *runs, uint32_t run_cap, uint32_t *status,
-                      hipStream_t stream);
+                      uint32_t *run_base, uint32_t *partial, void *runs, uint32_t run_cap, void *halves,
+                      uint32_t half_cap, uint32_t *status, hipStream_t stream);
 
 // X_shift words [w0, w0+nw) -> out_words (device); if count != nullptr also adds the popcount of
 // bits in [p0, p1) to *count.

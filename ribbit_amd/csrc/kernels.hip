@@ -896,6 +896,7 @@ __global__ __launch_bounds__(256) void pair_runs_kernel(const uint64_t *__restri
                                                         const ChunkEntry *__restrict__ table,
                                                         const uint32_t *__restrict__ run_base,
                                                         RunRecord *__restrict__ runs, uint32_t run_cap,
+                                                        RunRecord *__restrict__ halves, uint32_t half_cap,
                                                         uint32_t *__restrict__ status) {
     const uint32_t shard = blockIdx.y;
     const uint32_t n = region_count(counters, shard, pl.region_cap);
@@ -942,14 +943,29 @@ __global__ __launch_bounds__(256) void pair_runs_kernel(const uint64_t *__restri
         const uint32_t in_chunk = (g1 - c.begin1 - (chunk_opens_with_end ? 1u : 0u)) >> 1;
         const uint32_t slot = run_base[key] + in_chunk;
         if (slot >= run_cap) { atomicOr(&status[PAIR_FLAGS], (uint32_t)PAIR_NO_ROOM); continue; }
-        // RIBBIT_TERM_ZERO / _N / _EOS = EV_END_ZERO / _N / _EOS - 1
-        runs[slot] = RunRecord{(int32_t)ev_pos(e), (int32_t)ev_pos(closer), (int32_t)(mi + pl.m_lo), (int32_t)kind - 1};
+        // RIBBIT_TERM_ZERO / _N / _EOS = EV_END_ZERO / _N / _EOS - 1.  When the loaded piece is one chunk of a longer
+        // record (own range narrower than the piece), a run is reported by the chunk that owns its START; if its END
+        // lies beyond the own range the record is an open half, and the chunk that owns the END reports the other half.
+        const int64_t rs = (int64_t)ev_pos(e), re = (int64_t)ev_pos(closer);
+        const int32_t mlen = (int32_t)(mi + pl.m_lo), term = (int32_t)kind - 1;
+        const bool start_owned = rs >= pl.own_lo && rs < pl.own_hi, end_owned = re >= pl.own_lo && re < pl.own_hi;
+        if (start_owned && re < pl.own_hi) {
+            runs[slot] = RunRecord{(int32_t)(rs + pl.pos_offset), (int32_t)(re + pl.pos_offset), mlen, term};
+            continue;
+        }
+        runs[slot] = RunRecord{0, 0, 0, RUN_NOT_OWNED};
+        if (!start_owned && !end_owned) continue;
+        // at most two halves per motif and chunk: a plain atomic append is enough
+        const uint32_t at = atomicAdd(&status[PAIR_HALVES], 1u);
+        if (at >= half_cap) { atomicOr(&status[PAIR_FLAGS], (uint32_t)PAIR_NO_ROOM); continue; }
+        halves[at] = start_owned ? RunRecord{(int32_t)(rs + pl.pos_offset), -1, mlen, RUN_HALF_START}
+                                 : RunRecord{-1, (int32_t)(re + pl.pos_offset), mlen, RUN_HALF_END + term};
     }
 }
 
 void launch_pair_runs(const uint64_t *events, const uint32_t *counters, const PairLaunch &pl, void *table,
-                      uint32_t *run_base, uint32_t *partial, void *runs, uint32_t run_cap, uint32_t *status,
-                      hipStream_t stream) {
+                      uint32_t *run_base, uint32_t *partial, void *runs, uint32_t run_cap, void *halves,
+                      uint32_t half_cap, uint32_t *status, hipStream_t stream) {
     const uint32_t entries = pl.nm * pl.ntile;
     const uint32_t nblocks = (entries + (uint32_t)SCAN_BLOCK - 1u) / (uint32_t)SCAN_BLOCK;
     const uint32_t per_region = std::min<uint32_t>(std::max<uint32_t>((pl.region_cap + 255u) / 256u, 1u), 64u);
@@ -962,7 +978,8 @@ void launch_pair_runs(const uint64_t *events, const uint32_t *counters, const Pa
     hipLaunchKernelGGL(pair_scan_partials_kernel, dim3(1), dim3(256), 0, stream, partial, nblocks, status);
     hipLaunchKernelGGL(pair_run_base_kernel, dim3(nblocks), dim3(256), 0, stream, entries, (const uint32_t *)partial, run_base);
     hipLaunchKernelGGL(pair_runs_kernel, dim3(per_region, EV_SHARDS), dim3(256), 0, stream, events, counters, pl,
-                       (const ChunkEntry *)table, (const uint32_t *)run_base, (RunRecord *)runs, run_cap, status);
+                       (const ChunkEntry *)table, (const uint32_t *)run_base, (RunRecord *)runs, run_cap,
+                       (RunRecord *)halves, half_cap, status);
 }
 
 // ------------------------------------------------------------------- plane query (a5, a13)

@@ -75,6 +75,26 @@ def gather_array(arr: np.ndarray, device: torch.device | None = None, dst: int =
     return [gathered[r][:counts[r]].cpu().numpy().view(arr.dtype).copy() for r in range(world)]
 
 
+def same_node() -> bool:
+    """True when every rank of the job runs on this node (torchrun sets LOCAL_WORLD_SIZE)."""
+    import os
+    return int(os.environ.get("LOCAL_WORLD_SIZE", "0")) == dist.get_world_size()
+
+
+def open_node_gather(dtype, cap: int, half_cap: int):
+    """Collective: rank 0 creates the node-shared segment (ribbit_amd.node_gather), its name is broadcast and
+    the other ranks attach.  cap / half_cap must be the same on all ranks."""
+    from .node_gather import NodeGather
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ng = NodeGather(dtype, cap, half_cap, rank, world) if rank == 0 else None
+    box = [ng.name if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    if rank != 0:
+        ng = NodeGather(dtype, cap, half_cap, rank, world, name=box[0])
+    dist.barrier()
+    return ng
+
+
 def shard_records(n_records: int, lengths: list[int], world: int) -> list[list[int]]:
     """Longest-first bin packing of record indices over ranks (option 1)."""
     order = sorted(range(n_records), key=lambda i: -lengths[i])

@@ -52,3 +52,55 @@ def test_chunk_local_pairing_plus_edge_halves_gives_the_whole_records_runs(npart
     assert sum(len(h) for h in halves) > 0
     got = np.sort(np.concatenate(runs + [ribbit_amd.pair_halves(np.concatenate(halves))]), order=["mlen", "start"])
     assert np.array_equal(got.view("<i4"), want.view("<i4"))
+
+
+@pytest.mark.parametrize("nparts", [1, 4, 7])
+def test_device_paired_chunk_records_plus_halves_give_the_whole_records_runs(nparts):
+    """ribbit_hip_scan_perfect_chunk (pairing on the GPU, own-range classification in the kernel) against the whole
+    record's scan and against the host-side chunk pairing of ribbit_hip_perfect_runs_partial."""
+    name, seq, m_lo, m_hi = [c for c in edge_cases() if c[0] == "long_run_cross_tiles"][0]
+    seq = seq + simulated_cases()[1][1][:80_000]
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc:
+        sc.load_record(seq)
+        want = sc.scan_perfect_runs()
+        parts, halves, n_half_old = [], [], 0
+        for own_lo, own_hi, load_lo, load_hi in sharded.plan_chunks(len(seq), nparts, m_hi):
+            sc.load_record(seq[load_lo:load_hi])
+            rec, hv = sc.scan_perfect_chunk(own_lo - load_lo, own_hi - load_lo, load_lo)
+            rec = rec.copy()
+            old_runs, old_halves = sc.perfect_runs_partial(own_lo - load_lo, own_hi - load_lo, load_lo)
+            assert np.array_equal(rec[rec["term"] >= 0].view("<i4"), old_runs.view("<i4"))
+            assert set(np.unique(rec["term"])) <= {-1, 0, 1, 2} and len(hv) == len(old_halves)
+            parts.append(rec); halves.append(hv); n_half_old += len(old_halves)
+    assert (n_half_old > 0) == (nparts > 1)
+    got = ribbit_amd.merge_chunk_runs(parts, halves)
+    assert np.array_equal(got.view("<i4"), want.view("<i4"))
+
+
+def test_chunk_records_land_in_a_page_locked_node_shared_segment():
+    from ribbit_amd.node_gather import NodeGather
+    name, seq, m_lo, m_hi = simulated_cases()[1]
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc:
+        sc.load_record(seq)
+        want = sc.scan_perfect_runs()
+        ng = NodeGather(ribbit_amd.RUN_DT, len(want) + 8, 2 * (m_hi - m_lo + 1), rank=0, world=1)
+        try:
+            for addr, nbytes in ng.my_cells():
+                sc.host_register(addr, nbytes)
+            for k in (1, 2, 3):
+                if k > 1:
+                    ng.release(k - 1)
+                ng.wait_free(k)
+                rec, hv = ng.mine(k)
+                n, nh = sc.scan_perfect_chunk(0, len(seq) + 1, 0, out=rec, halves_out=hv)
+                ng.publish(k, n, nh)
+                parts, halves = ng.collect(k)
+                assert nh == 0 and np.array_equal(parts[0].view("<i4"), want.view("<i4"))
+            small = np.zeros(3, ribbit_amd.RUN_DT)
+            with pytest.raises(ribbit_amd.RibbitHipError, match="do not fit"):
+                sc.scan_perfect_chunk(0, len(seq) + 1, 0, out=small, halves_out=hv)
+            for addr, _ in ng.my_cells():
+                sc.host_unregister(addr)
+        finally:
+            parts = halves = rec = hv = None
+            ng.close()
