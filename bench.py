@@ -28,6 +28,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 WORKLOAD_BASES = 100_000_000
 M_LO, M_HI = 2, 100
 ALGO_BYTES_PER_BASE = 0.375      # 2 code bits + 1 N bit per base read by the scan kernel
+ALIGNBIT_SHARE = 81 / 190        # v_alignbit_b32 among the VALU instructions of scan_perfect_kernel's hot loop
+ALIGNBIT_RATE = 550e9            # wave-instr/s chip-wide at 4 waves/SIMD (profiles/r01b_valu_peak_probe.txt)
+PLAIN_VALU_RATE = 930e9          # v_or / v_xor / v_bitop3, same probe
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 CPU_SAMPLE_BASES = 20_000_000
 
@@ -186,12 +189,14 @@ def main():
             print(f"verify: {len(want)} runs identical to the single-GPU scan of the whole record", file=sys.stderr)
 
     if rank == 0:
-        traffic = None
+        traffic = n_valu = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and args.bases == WORKLOAD_BASES:
             # HBM bytes per scan_perfect_kernel launch from the committed rocprofv3 PMC passes
             # (FETCH_SIZE / WRITE_SIZE collected separately, corrected as profiles/README.md explains)
-            traffic = json.load(open(tpath)).get("scan_perfect_kernel_hbm_bytes_per_launch")
+            prof = json.load(open(tpath))
+            traffic = prof.get("scan_perfect_kernel_hbm_bytes_per_launch")
+            n_valu = prof.get("scan_perfect_kernel_SQ_INSTS_VALU")
         total_bases = args.bases * world * args.steps
         kavg = float(np.mean(kernel_ms))
         achieved = args.bases * ALGO_BYTES_PER_BASE / (kavg * 1e-3) / 1e9
@@ -215,6 +220,14 @@ def main():
             "runs_per_step": nruns, "device_events_per_step": nevents,
             "gpu_side_ms_per_step": float(np.mean(gpu_ms)),   # scan + pairing kernels + D2H of the runs (HIP events)
         }
+        if n_valu:
+            # the honest limiter: wave-instructions per launch from the committed SQ_INSTS_VALU pass,
+            # ALIGNBIT_SHARE of them v_alignbit (ISA of the hot loop), against the issue rates measured on this part by
+            # tools/probes/valu_peak.hip at the kernel's occupancy
+            roof_ms = (n_valu * ALIGNBIT_SHARE / ALIGNBIT_RATE + n_valu * (1 - ALIGNBIT_SHARE) / PLAIN_VALU_RATE) * 1e3
+            out["roofline"]["valu"] = {"wave_instr_per_launch": n_valu, "alignbit_share": ALIGNBIT_SHARE,
+                                       "issue_rate_wave_instr_per_s": {"v_alignbit_b32": ALIGNBIT_RATE, "other": PLAIN_VALU_RATE},
+                                       "issue_bound_ms": roof_ms, "frac": roof_ms / kavg}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seq)
         print(json.dumps(out), flush=True)

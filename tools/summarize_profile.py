@@ -22,13 +22,14 @@ shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_trace.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
 
 pmc = {}
-for name in ("pmc_fetch", "pmc_write"):
-    f = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))[0]
+for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in agg.items():
-        pmc.setdefault(k, {})[c] = {"launches": len(v), "mean_kb": sum(v) / len(v)}
+        # FETCH_SIZE / WRITE_SIZE are in KB; everything else is a plain count (or a percentage for VALUBusy)
+        key = "mean_kb" if c in ("FETCH_SIZE", "WRITE_SIZE") else "mean"
+        pmc.setdefault(k, {})[c] = {"launches": len(v), key: sum(v) / len(v)}
 with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as fh:
     json.dump(pmc, fh, indent=1, sort_keys=True)
 
@@ -52,6 +53,9 @@ out = {
     "algorithmic_read_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
     "events_per_launch": bench["device_events_per_step"],
 }
+for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "VALUBusy", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
+    if c in scan:
+        out["scan_perfect_kernel_" + c] = scan[c]["mean"]
 with open(os.path.join(dst, "traffic.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out, indent=1))
