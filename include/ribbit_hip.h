@@ -134,7 +134,7 @@ int ribbit_hip_seeds_substitutions(RibbitHandle *h, const RibbitSeed **perfect, 
  * generateAnchoredShiftXORs (parse_anchored_shiftxor.h:10, called at fasta_utils.cpp:144), the plane
  * composition of fasta_utils.cpp:146-160 and the 6-of-8 window scan.  After this call "plane m"
  * means the composed plane for every motif length m (as in the reference, fasta_utils.cpp:159).
- * This build handles max_motif <= 110 in the anchored stage.
+ * Motif sizes up to 990 (the anchored kernel widens its per-wave halo with max_motif).
  */
 int ribbit_hip_anchored_calls(RibbitHandle *h, const RibbitCall **out, size_t *n);
 

@@ -280,7 +280,8 @@ int collect_events(RibbitHandle *h, int which) {
     const uint64_t *ev = h->h_events.p;
     const uint32_t m_lo = (uint32_t)h->params.min_motif;
     const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
-    const uint32_t tile_bases = which == 2 ? (uint32_t)rb::ATILE_BASES : (uint32_t)rb::TILE_BASES;
+    const uint32_t tile_bases = which == 2 ? (uint32_t)rb::anchored_tile_words(rb::anchored_halo_lanes(h->params.max_motif)) * 32u
+                                           : (uint32_t)rb::TILE_BASES;
     const size_t ntile = (size_t)(h->length / tile_bases + 1);
     struct Chunk { uint32_t off, n; };
     static_assert(sizeof(Chunk) == sizeof(uint64_t), "chunk table entry is one 64-bit word");

@@ -19,7 +19,7 @@ namespace rb {
 constexpr int WORDS_PER_LANE = 8;
 constexpr int TILE_WORDS = 64 * WORDS_PER_LANE;   // 512 words = 16384 bases per wave tile
 constexpr int TILE_BASES = TILE_WORDS * 32;
-constexpr int LEAD_WORDS = 16;          // >= WORDS_PER_LANE + 1 (the anchored kernel has a halo lane on each side)
+constexpr int LEAD_WORDS = 72;          // >= 8 halo lanes x WORDS_PER_LANE + 1 (the anchored kernel's left halo at the largest motif)
 constexpr int TAIL_SLACK_WORDS = 544;    // >= TILE_WORDS + halo lane + shifted-operand words
 
 struct DevicePlanes {
@@ -31,14 +31,13 @@ struct DevicePlanes {
     int64_t tail_words;   // words readable past ntiles*TILE_WORDS
 };
 
-// The anchored kernel gives up lanes 0 and 63 of every wave as halo lanes (run lengths that decide
-// whether a run is an anchor extend up to 2*shift bases beyond a lane), so its tiles are narrower.
-constexpr int ATILE_LANES = 62;
-constexpr int ATILE_WORDS = ATILE_LANES * WORDS_PER_LANE;   // 496 words = 15872 bases
-constexpr int ATILE_BASES = ATILE_WORDS * 32;
-// largest motif the anchored kernel handles exactly: 2*(max_motif+2) must fit in the 7 words a halo
-// lane can vouch for beyond its boundary word
-constexpr int ANCHORED_MAX_MOTIF = (7 * 32) / 2 - 2;        // 110
+// The anchored kernel gives up `hl` lanes at either end of every wave as halo lanes: whether a run of X_s ones is
+// an anchor depends on its true length up to 2s, i.e. on up to 2*(max_motif+2) bases beyond a lane.  The last
+// word of the last halo lane must still be classified exactly, so the halo has to span 2s + 32 bases:
+//   hl = ceil((2*(max_motif+2) + 32) / 256)      1 up to max_motif 110, 5 at 500, 8 at 990
+constexpr int ANCHORED_MAX_MOTIF = 990;
+__host__ __device__ inline int anchored_halo_lanes(int max_motif) { return (2 * (max_motif + 2) + 32 + 255) / 256; }
+__host__ __device__ inline int anchored_tile_words(int hl) { return (64 - 2 * hl) * WORDS_PER_LANE; }
 
 // Event buffer sharding: EV_SHARDS regions, one counter each (own 128-byte line).
 constexpr int EV_SHARDS = 64;

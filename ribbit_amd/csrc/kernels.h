@@ -31,7 +31,7 @@ void launch_scan_window(const DevicePlanes &pl, const PerfectLaunch &pp, int all
 // generateAnchoredShiftXORs (parse_anchored_shiftxor.cpp:20-56) + the composition of
 // fasta_utils.cpp:143-161 + the window scan of processShiftXORsAnchored (:580-679), fused.
 // xa (may be null) receives the composed planes XA_m, motif-major, xa_stride words per motif.
-// Tiles are ATILE_WORDS wide.  Requires pp.m_hi <= ANCHORED_MAX_MOTIF.
+// Tiles are anchored_tile_words(anchored_halo_lanes(pp.m_hi)) wide.  Requires pp.m_hi <= ANCHORED_MAX_MOTIF.
 void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint32_t *xa, int64_t xa_stride,
                           uint64_t *events, uint32_t *counters, hipStream_t stream);
 

@@ -486,17 +486,19 @@ void launch_scan_window(const DevicePlanes &pl, const PerfectLaunch &pp, int all
 // p = L-s on: such a run becomes unbounded and fails "< 2s".  Run lengths are classified per lane:
 //   * a lane owns 8 consecutive words (256 bases); per word it knows its leading / trailing ones;
 //   * a sequential carry over the 8 words gives, for every word, the length of the run entering
-//     from the left (CL) and from the right (CR) -- seeded with the neighbour lanes' trailing /
-//     leading ones, or SATURATED when the neighbour lane is all ones (a full lane is >= 256 >= 2s);
+//     from the left (CL) and from the right (CR) -- seeded with the trailing / leading ones of the
+//     lanes to the left / right, combined over `hl` lanes by a segmented Kogge-Stone scan across the
+//     wave (256 per all-ones lane; hl*256 >= 2s + 32, so longer runs need not be told apart);
 //   * runs interior to a word are handled bit-parallel (>= 3 by AND of shifts; >= 2s, only
 //     possible when 2s <= 30, by AND-/OR-doubling).
-// Lanes 0 and 63 are halo lanes (their own neighbours are unknown): they compute but emit nothing.
+// The first and last hl lanes are halo lanes (what lies beyond them is unknown): they compute but emit
+// nothing (device_planes.h: anchored_halo_lanes).
 // The composed plane XA_m = X_m | anchor_{m-2} | anchor_{m-1} | anchor_{m+1} | anchor_{m+2}
 // needs five consecutive shifts, so every wave walks s = m_lo-2 .. m_hi+2 of its motif group with a
 // register ring of the last five anchor words and the last three mismatch words.
 constexpr int RUN_SAT = 1 << 20;
 
-__global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, PerfectLaunch pp, int motifs_per_block,
+__global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, PerfectLaunch pp, int motifs_per_block, int hl,
                                                             uint32_t *__restrict__ xa, int64_t xa_stride,
                                                             uint64_t *__restrict__ events,
                                                             uint32_t *__restrict__ counters) {
@@ -507,8 +509,8 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t tile_base = (int64_t)blockIdx.x * ATILE_WORDS;   // first OWN word (lane 1, k = 0)
-    const int64_t first = tile_base - K - 1;                       // word held at LDS index 0
+    const int64_t tile_base = (int64_t)blockIdx.x * anchored_tile_words(hl);   // first OWN word (lane hl, k = 0)
+    const int64_t first = tile_base - (int64_t)hl * K - 1;                     // word held at LDS index 0
 
     const int bm_lo = pp.m_lo + (int)blockIdx.y * motifs_per_block;
     const int bm_hi = min(pp.m_hi, bm_lo + motifs_per_block - 1);
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
     if (wm_lo > wm_hi) return;
 
     const int lb = lane * K;
-    const bool own_lane = lane >= 1 && lane <= ATILE_LANES;
+    const bool own_lane = lane >= hl && lane < 64 - hl;
     uint32_t H[K + 2], Lo[K + 2];
     uint32_t EVAL[K + 1];
     {
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
         for (int j = 0; j < K + 1; j++) EVAL[j] = ~(B[j] | funnel(B[j + 1], B[j], 4));
     }
 
-    const int64_t w_own0 = tile_base + (int64_t)(lane - 1) * K;     // global index of this lane's word k = 0
+    const int64_t w_own0 = tile_base + (int64_t)(lane - hl) * K;    // global index of this lane's word k = 0
     const uint32_t word0 = (uint32_t)w_own0;
     const int64_t length = pl.length;
     // masks are only needed where the lane touches p < 0 or p >= L - (largest shift)
@@ -628,8 +630,21 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
             span_trail += alive ? trail1[k] : 0;
             alive = alive && (X[k] == 0xffffffffu);
         }
-        int left_in = __shfl_up(span_full ? RUN_SAT : span_trail, 1);
-        int right_in = __shfl_down(span_full ? RUN_SAT : span_lead, 1);
+        // ones ending at this lane's right edge (accL) / starting at its left edge (accR), over a growing window
+        // of lanes: after the loop the windows span >= hl lanes, which is as far as a length below 2s can reach
+        int accL = span_trail, accR = span_lead, fullL = span_full ? 1 : 0, fullR = fullL;
+        for (int d = 1; d < hl; d <<= 1) {          // wave-uniform; no iteration up to max_motif 110
+            int a = __shfl_up(accL, d), f = __shfl_up(fullL, d);
+            if (lane < d) { a = 0; f = 0; }
+            accL = min(accL + (fullL ? a : 0), RUN_SAT);
+            fullL &= f;
+            a = __shfl_down(accR, d); f = __shfl_down(fullR, d);
+            if (lane + d > 63) { a = 0; f = 0; }
+            accR = min(accR + (fullR ? a : 0), RUN_SAT);
+            fullR &= f;
+        }
+        int left_in = __shfl_up(accL, 1);
+        int right_in = __shfl_down(accR, 1);
         if (lane == 0) left_in = 0;
         if (lane == 63) right_in = 0;
         int CL[K], CR[K];
@@ -723,8 +738,9 @@ void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint3
                           uint64_t *events, uint32_t *counters, hipStream_t stream) {
     const int nm = pp.m_hi - pp.m_lo + 1;
     const int64_t nwords = pl.length / 32 + 1;
-    const int64_t ntiles = (nwords + ATILE_WORDS - 1) / ATILE_WORDS;
-    if (nm <= 0 || ntiles <= 0) return;
+    const int hl = anchored_halo_lanes(pp.m_hi);
+    const int64_t ntiles = (nwords + anchored_tile_words(hl) - 1) / anchored_tile_words(hl);
+    if (nm <= 0 || ntiles <= 0 || pp.m_hi > ANCHORED_MAX_MOTIF) return;
     // each wave recomputes 4 extra shifts around its motif group, so keep the groups large
     int64_t want_y = (1024 + ntiles - 1) / ntiles;
     int max_y = (nm + 31) / 32;
@@ -732,7 +748,7 @@ void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint3
     int motifs_per_block = (nm + gy - 1) / gy;
     gy = (nm + motifs_per_block - 1) / motifs_per_block;
     dim3 grid((unsigned)ntiles, (unsigned)gy);
-    hipLaunchKernelGGL(scan_anchored_kernel, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, xa, xa_stride, events,
+    hipLaunchKernelGGL(scan_anchored_kernel, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, hl, xa, xa_stride, events,
                        counters);
 }
 

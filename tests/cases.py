@@ -48,3 +48,38 @@ def simulated_cases():
     out.append(("sim_m4_50_60k", seq, 4, 50))
     out.append(("random_n_100k", random_sequence(100_000, 3, n_fraction=0.02, n_run_lo=10, n_run_hi=500), 2, 100))
     return out
+
+
+def _mutate(unit: bytes, copies: int, rate: float, seed: int) -> bytes:
+    """copies x unit with substitutions / 1-base indels at `rate` per base (a degenerate tandem repeat)."""
+    rs = np.random.RandomState(seed)
+    out = bytearray()
+    for c in bytearray(unit * copies):
+        u = rs.rand()
+        if u < rate * 0.6:
+            out.append(b"ACGT"[rs.randint(4)])
+        elif u < rate * 0.8:
+            continue
+        elif u < rate:
+            out.append(c); out.append(b"ACGT"[rs.randint(4)])
+        else:
+            out.append(c)
+    return bytes(out)
+
+
+def large_motif_cases():
+    """-M above 110: the anchored kernel needs more than one halo lane per side (BASELINE.json configs[4] runs
+    -M 500).  Long units with few copies, degenerate copies (anchors of length up to 2s), all-ones stretches
+    longer than a lane (homopolymers), N blocks, and tile edges (> 1 tile at 5 halo lanes = 13824 bases)."""
+    big = (_rand(700, 41) + _rand(180, 42) * 4 + _rand(300, 43) + _mutate(_rand(140, 44), 6, 0.04, 45) + _rand(500, 46)
+           + b"A" * 1300 + _rand(200, 47) + _mutate(_rand(37, 48), 40, 0.06, 49) + b"N" * 300 + _rand(64, 50) * 30
+           + _rand(900, 51) + _mutate(_rand(411, 52), 4, 0.02, 53) + _rand(400, 54))
+    long = _rand(9000, 55) + _mutate(_rand(260, 56), 9, 0.05, 57) + _rand(3000, 58) + b"CA" * 900 + _rand(12000, 59) \
+        + _mutate(_rand(95, 60), 30, 0.08, 61) + _rand(2500, 62)
+    return [
+        ("M200_mixed", big, 2, 200),
+        ("M500_mixed", big, 100, 500),
+        ("M500_two_tiles", long, 60, 500),
+        ("M990_long_units", _rand(1500, 63) + _rand(800, 64) * 3 + _rand(600, 65) + _mutate(_rand(600, 66), 4, 0.03, 67) + _rand(900, 68), 500, 990),
+        ("M111_first_above_one_halo_lane", big[:6000], 90, 111),
+    ]

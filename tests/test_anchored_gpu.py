@@ -7,12 +7,12 @@ import numpy as np
 import pytest
 
 import ribbit_amd
-from cases import edge_cases, simulated_cases
+from cases import edge_cases, large_motif_cases, simulated_cases
 from oracle_lib import LIST_ANCHORED, LIST_PERFECT, LIST_SUBST, Oracle
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-ALL = edge_cases() + simulated_cases()
+ALL = edge_cases() + simulated_cases() + large_motif_cases()
 
 
 @pytest.mark.parametrize("name,seq,m_lo,m_hi", ALL, ids=[c[0] for c in ALL])
@@ -56,9 +56,16 @@ def test_all_composed_planes_on_a_dense_case():
             assert np.array_equal(sc.plane_bits(m), o.plane(m)), f"composed plane {m}"
 
 
-def test_anchored_stage_rejects_large_motifs():
-    with ribbit_amd.Scanner(2, 200) as sc:
-        sc.load_record(b"ACGT" * 100)
-        sc.processShiftXORswithSubstitutions()          # earlier stages have no such limit
-        with pytest.raises(ribbit_amd.RibbitHipError, match="max_motif"):
-            sc.anchored_calls()
+def test_anchored_stage_rejects_motifs_beyond_the_kernels_reach():
+    with pytest.raises(ribbit_amd.RibbitHipError):
+        ribbit_amd.Scanner(2, 1200)
+
+
+@pytest.mark.parametrize("name,seq,m_lo,m_hi", large_motif_cases(), ids=[c[0] for c in large_motif_cases()])
+def test_all_composed_planes_at_large_motifs(name, seq, m_lo, m_hi):
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc, Oracle(seq, m_lo, m_hi) as o:
+        sc.load_record(seq)
+        o.run_perfect(); o.run_subst(); o.run_anchor_planes()
+        sc.anchored_calls()
+        for m in range(m_lo, m_hi + 1, 7):
+            assert np.array_equal(sc.plane_bits(m), o.plane(m)), f"composed plane {m}"

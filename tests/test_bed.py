@@ -6,13 +6,13 @@ import os
 import pytest
 
 import ribbit_amd
-from cases import edge_cases, simulated_cases
+from cases import edge_cases, large_motif_cases, simulated_cases
 from oracle_lib import Oracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libssw_ref.so")),
                                 reason="oracle/_ref/libssw_ref.so not built")
-ALL = edge_cases() + simulated_cases()
+ALL = edge_cases() + simulated_cases() + large_motif_cases()
 
 
 @pytest.mark.parametrize("name,seq,m_lo,m_hi", ALL, ids=[c[0] for c in ALL])

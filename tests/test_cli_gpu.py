@@ -7,14 +7,14 @@ import subprocess
 import pytest
 
 import ribbit_amd
-from cases import edge_cases, simulated_cases
+from cases import edge_cases, large_motif_cases, simulated_cases
 from oracle_lib import Oracle
 from ribbit_amd.simulate import write_fasta
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "ribbit_amd", "ribbit-hip")
-ALL = edge_cases() + simulated_cases()
+ALL = edge_cases() + simulated_cases() + large_motif_cases()
 
 
 @pytest.mark.parametrize("name,seq,m_lo,m_hi", ALL, ids=[c[0] for c in ALL])
@@ -43,6 +43,18 @@ def test_cli_multi_record_fasta(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Processing sequence chrA" in r.stderr and "Total number of perfect seeds:" in r.stderr
     assert bed.read_text() == _oracle_bed(records, 2, 30)
+
+
+def test_cli_long_reads_at_M_500(tmp_path):
+    """BASELINE.json configs[4]: many short records (simulated long reads), -m 2 -M 500."""
+    big = large_motif_cases()[0][1]
+    sim = simulated_cases()[1][1]
+    records = [(f"read{i}", (big[i * 900:i * 900 + 5000] + sim[i * 3000:i * 3000 + 4000])) for i in range(4)]
+    fa, bed = tmp_path / "in.fa", tmp_path / "out.bed"
+    write_fasta(str(fa), records)
+    r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "500"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert bed.read_text() == _oracle_bed(records, 2, 500)
 
 
 def test_cli_bed_goes_to_stderr_without_o_and_purity_flag_is_ignored(tmp_path):

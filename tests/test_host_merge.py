@@ -9,11 +9,11 @@ import numpy as np
 import pytest
 
 import ribbit_amd
-from cases import edge_cases, simulated_cases
+from cases import edge_cases, large_motif_cases, simulated_cases
 from oracle_lib import LIST_ANCHORED, LIST_PERFECT, LIST_SUBST, Oracle
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-ALL = edge_cases() + simulated_cases()
+ALL = edge_cases() + simulated_cases() + large_motif_cases()
 
 
 def test_pack_planes_matches_oracle_encoding():
