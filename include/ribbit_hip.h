@@ -333,6 +333,12 @@ int ribbit_hip_scan_perfect_chunk(RibbitHandle *h, int64_t own_lo, int64_t own_h
                                   RibbitRun *dst, size_t dst_cap, RibbitRun *half_dst, size_t half_dst_cap,
                                   const RibbitRun **out, size_t *n, const RibbitRun **halves, size_t *n_halves);
 
+/* Worker threads the host-side stages of this handle may use (window state machines, refinement);
+ * 0 = default (environment RIBBIT_THREADS, else min(cores, 16)).  A caller that keeps several handles busy at
+ * once -- ribbit-hip does, one per in-flight FASTA record (ribbit.cpp:269-280 processes them one by one) --
+ * divides the cores among them with this. */
+int ribbit_hip_set_host_threads(RibbitHandle *h, int32_t threads);
+
 /* Page-lock a host buffer the caller owns (e.g. a shared-memory segment several ranks of one node write their
  * chunk's records into) so that ribbit_hip_scan_perfect_chunk can DMA straight into it.  hipHostRegister. */
 int ribbit_hip_host_register(void *p, size_t bytes);

@@ -46,6 +46,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_stage_events", "ribbit_hip_xa_words", "ribbit_host_scan_from_events",
     "ribbit_host_perfect_runs_from_events", "ribbit_runs_free", "ribbit_hip_perfect_runs_partial",
     "ribbit_hip_scan_perfect_chunk", "ribbit_hip_host_register", "ribbit_hip_host_unregister",
+    "ribbit_hip_set_host_threads",
 ]
 
 
@@ -145,6 +146,7 @@ def load_library():
                                                 C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.ribbit_hip_host_register.argtypes = [vp, C.c_size_t]
     L.ribbit_hip_host_unregister.argtypes = [vp]
+    L.ribbit_hip_set_host_threads.argtypes = [vp, i32]
     L.ribbit_host_scan_from_events.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t,
                                                vp, vp, vp, vp, vp, vp, C.POINTER(SeedLists)]
     L.ribbit_host_perfect_runs_from_events.argtypes = [C.POINTER(ScanParams), C.c_size_t, vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]

@@ -93,6 +93,7 @@ struct RibbitHandle {
     hipEvent_t ev[6] = {};        // 0/1 pack, 2/3 scan kernel, 4/5 whole GPU side of the last scan
     bool have_timing[3] = {false, false, false};
     double host_ms = 0.0;         // host post-processing of the last scan (pairing / FSM)
+    unsigned host_threads = 0;    // worker threads of the host stages (0 = RIBBIT_THREADS or min(cores, 16))
 
     bool loaded = false;
     int64_t length = 0;
@@ -140,6 +141,7 @@ struct RibbitHandle {
     DevBuf<int32_t> d_longest;
     DevBuf<uint8_t> d_sym;
     DevBuf<unsigned long long> d_best;
+    DevBuf<int32_t> d_slices;          // {job, first row} per 64-row slice of the long-motif seeds
     bool best_rows_valid = false;
     std::vector<int32_t> best_rows;       // per dispatch seed: mostFrequentLongerMotif's window start, or -1
     std::vector<RibbitAlignJob> jobs;
@@ -441,7 +443,7 @@ int build_subst_calls(RibbitHandle *h) {
     if ((rc = collect_events(h, 1))) return rc;
     const double t0 = now_ms();
     std::string why;
-    if (!rb::replay_window_events(event_source(h), h->host, h->subst_calls, &why)) return fail(RIBBIT_E_INTERNAL, "%s", why.c_str());
+    if (!rb::replay_window_events(event_source(h), h->host, h->subst_calls, &why, h->host_threads)) return fail(RIBBIT_E_INTERNAL, "%s", why.c_str());
     h->host_ms = now_ms() - t0;
     h->subst_calls_valid = true;
     return RIBBIT_OK;
@@ -496,7 +498,7 @@ int build_anchored_calls(RibbitHandle *h) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     const double t0 = now_ms();
     std::string why;
-    if (!rb::replay_window_events(event_source(h), h->host, h->anchored_calls, &why)) return fail(RIBBIT_E_INTERNAL, "%s", why.c_str());
+    if (!rb::replay_window_events(event_source(h), h->host, h->anchored_calls, &why, h->host_threads)) return fail(RIBBIT_E_INTERNAL, "%s", why.c_str());
     h->host_ms = now_ms() - t0;
     h->anchored_calls_valid = true;
     return RIBBIT_OK;
@@ -591,7 +593,18 @@ int build_best_rows(RibbitHandle *h, const RibbitRefineParams &prm) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h->d_seeds.p, jobs.data(), jobs.size() * sizeof(RibbitSeed), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemsetAsync(h->d_best.p, 0, jobs.size() * sizeof(unsigned long long), h->stream));
-        rb::launch_long_motif_rows(h->d_sym.p, h->length, h->d_seeds.p, (int64_t)jobs.size(), h->d_best.p, h->stream);
+        // 64-row slices of every seed: {job, first row}
+        std::vector<int32_t> slices;
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            const int64_t seed_end = std::min<int64_t>((int64_t)jobs[j].start + jobs[j].end, h->length);   // .end holds the length here
+            const int64_t rows = seed_end - jobs[j].mlen + 1 - jobs[j].start;
+            for (int64_t r = 0; r < rows; r += 64) { slices.push_back((int32_t)j); slices.push_back((int32_t)r); }
+        }
+        if ((rc = h->d_slices.ensure(std::max<size_t>(slices.size(), 2)))) return rc;
+        if (!slices.empty())
+            HIP_TRY(hipMemcpyAsync(h->d_slices.p, slices.data(), slices.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        rb::launch_long_motif_rows(h->d_sym.p, h->length, h->d_seeds.p, (int64_t)jobs.size(), h->d_slices.p,
+                                   (int64_t)(slices.size() / 2), h->d_best.p, h->stream);
         HIP_TRY(hipGetLastError());
         std::vector<unsigned long long> best(jobs.size());
         HIP_TRY(hipMemcpyAsync(best.data(), h->d_best.p, jobs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
@@ -677,7 +690,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ascii.release(); h->d_hi.release(); h->d_lo.release(); h->d_brk.release();
-    h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release();
+    h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release(); h->d_slices.release();
     h->h_events.release(); h->h_counters.release(); h->h_query.release();
     h->d_pair_table.release(); h->d_run_base.release(); h->d_pair_partial.release(); h->d_pair_status.release();
     h->h_pair_status.release(); h->h_runs.release(); h->h_halves.release(); h->d_halves.release();
@@ -869,8 +882,13 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
     if (!h || !prm || !sequence_id || !text || !len) return fail(RIBBIT_E_ARG, "null argument");
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
     h->best_rows_valid = false;
+    static double t_rows = 0, t_text = 0;
+    static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
+    double t0 = now_ms();
     int rc = build_best_rows(h, *prm);
     if (rc) return rc;
+    t_rows += now_ms() - t0;
+    t0 = now_ms();
     if (!h->host_ascii_valid) {      // record was loaded from device memory: fetch the bases once
         h->host_ascii.resize((size_t)h->length);
         if (h->length) {
@@ -880,7 +898,9 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
         h->host_ascii_valid = true;
     }
     h->bed.clear();
-    rb::refine_to_bed(h->host, h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sequence_id, h->bed);
+    rb::refine_to_bed(h->host, h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sequence_id, h->bed, h->host_threads);
+    t_text += now_ms() - t0;
+    if (profile) std::fprintf(stderr, "[refine_bed] cumulative: GPU scans of the seeds %.1f ms, host refinement + BED %.1f ms\n", t_rows, t_text);
     *text = h->bed.c_str();
     *len = h->bed.size();
     return RIBBIT_OK;
@@ -1007,6 +1027,12 @@ int ribbit_hip_scan_perfect_chunk(RibbitHandle *h, int64_t own_lo, int64_t own_h
     *n = h->n_runs;
     *halves = half_dst ? half_dst : h->h_halves.p;
     *n_halves = h->n_halves;
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_set_host_threads(RibbitHandle *h, int32_t threads) {
+    if (!h || threads < 0) return fail(RIBBIT_E_ARG, "bad argument");
+    h->host_threads = (unsigned)threads;
     return RIBBIT_OK;
 }
 

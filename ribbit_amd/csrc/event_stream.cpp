@@ -90,15 +90,16 @@ void perfect_calls_from_runs(const RibbitRun *runs, size_t n_runs, int64_t lengt
     std::stable_sort(calls.begin(), calls.end(), call_order);
 }
 
-bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vector<RibbitCall> &calls, std::string *why) {
+bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vector<RibbitCall> &calls, std::string *why, unsigned host_threads) {
     calls.clear();
     const size_t nm = src.nm;
     const int32_t m_lo = src.m_lo;
     constexpr int64_t TILE = 16384;          // ordering granule (any value works)
     const int64_t ntile = hp.length / TILE + 1;
 
-    unsigned threads = std::min(std::thread::hardware_concurrency(), 16u);
-    if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
+    unsigned threads = host_threads ? host_threads : std::min(std::thread::hardware_concurrency(), 16u);
+    if (!host_threads)
+        if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
     threads = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)threads, nm, (size_t)256}));
 
     // Phase 1 (parallel over motifs): every worker replays the state machines of its motifs over the whole

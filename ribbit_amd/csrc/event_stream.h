@@ -59,6 +59,6 @@ void perfect_calls_from_runs(const RibbitRun *runs, size_t n_runs, int64_t lengt
 // Replay of the per-motif window state machines (window_fsm.h), tile by tile, producing the call list in the
 // reference's call order (scan position major, motif minor, end-of-sequence flush last) without a global
 // sort.  O(events + calls).
-bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vector<RibbitCall> &calls, std::string *why);
+bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vector<RibbitCall> &calls, std::string *why, unsigned host_threads = 0);
 
 }  // namespace rb

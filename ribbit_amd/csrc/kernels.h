@@ -70,9 +70,10 @@ void launch_seed_longest_runs(const uint32_t *xa, int64_t xa_stride, int m_lo, c
 void launch_sym(const uint8_t *ascii, int64_t length, uint8_t *sym, hipStream_t stream);
 // mostFrequentLongerMotif's row scores (parse_seed.cpp:165-243) for njobs seeds {seed_start, seed_sequence_length, m, -}:
 // best[job] = (best score << 32) | (0xffffffff - first row with that score), 0 when every row scores 0.
-// best[] must be zeroed by the caller.
-void launch_long_motif_rows(const uint8_t *sym, int64_t length, const void *jobs, int64_t njobs, unsigned long long *best,
-                            hipStream_t stream);
+// best[] must be zeroed by the caller.  blocks[nblocks] = {job, first row of a 64-row slice of that seed}: every
+// seed is covered by ceil(rows / 64) slices, rows = seed_sequence_length - m + 1 (clipped at the record end).
+void launch_long_motif_rows(const uint8_t *sym, int64_t length, const void *jobs, int64_t njobs, const void *blocks,
+                            int64_t nblocks, unsigned long long *best, hipStream_t stream);
 
 // profiling aid: reads nwords dwords of src with one coalesced dword per lane (known byte count)
 void launch_calib_stream_read(const uint32_t *src, int64_t nwords, uint32_t *sink, hipStream_t stream);

@@ -1079,8 +1079,11 @@ void launch_seed_longest_runs(const uint32_t *xa, int64_t xa_stride, int m_lo, c
 // parse_seed.cpp:153-256 for every dispatched seed with m > 10 at once.  Every window
 // row_start .. row_start+m-1 of a seed is scored independently (walk down- and upstream in steps of
 // m with a +-2 jitter, count identical bases on the best diagonal), so the rows are the parallel
-// axis: one workgroup per seed, threads stride over its rows; the seed's best (score, smallest row)
-// is kept with a 64-bit atomicMax.  sym = one byte per base: 0..3 = A C G T, 4 = N.
+// axis: one thread per row, 64 rows per wavefront-sized workgroup, a long seed spread over as many
+// workgroups as it has 64-row slices (blocks[] maps a workgroup to its seed and first row; a row costs
+// ~5 x seed length byte compares, so one workgroup per whole seed made the longest seed of a record the
+// critical path of the launch).  The seed's best (score, smallest row) is kept with a 64-bit atomicMax.
+// sym = one byte per base: 0..3 = A C G T, 4 = N.
 __global__ __launch_bounds__(256) void sym_kernel(const uint8_t *__restrict__ ascii, int64_t length, uint8_t *__restrict__ sym) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= length) return;
@@ -1102,15 +1105,18 @@ __device__ __forceinline__ int diag_matches(const uint8_t *__restrict__ sym, int
 
 __global__ __launch_bounds__(64) void long_motif_rows_kernel(const uint8_t *__restrict__ sym, int64_t length,
                                                              const int4 *__restrict__ jobs, int64_t njobs,
+                                                             const int2 *__restrict__ blocks,
                                                              unsigned long long *__restrict__ best) {
-    const int64_t job = blockIdx.x;
-    if (job >= njobs) return;
+    const int2 blk = blocks[blockIdx.x];       // job, first row of this slice (relative to seed_start)
+    const int64_t job = blk.x;
+    if (job < 0 || job >= njobs) return;
     const int4 jb = jobs[job];                 // seed_start, seed_sequence_length, m, unused
     const int seed_start = jb.x, m = jb.z;
     int seed_end = jb.x + jb.y;
     if (seed_end > (int)length) seed_end = (int)length;
     unsigned long long mine = 0;
-    for (int row = seed_start + (int)threadIdx.x; row < seed_end - m + 1; row += 64) {
+    const int row = seed_start + blk.y + (int)threadIdx.x;
+    if (row < seed_end - m + 1) {
         int score = 0;
         for (int col = row + m; col < seed_end;) {
             int pick = -2, top = 0;
@@ -1142,7 +1148,13 @@ __global__ __launch_bounds__(64) void long_motif_rows_kernel(const uint8_t *__re
         const unsigned long long key = ((unsigned long long)(unsigned)score << 32) | (0xffffffffu - (unsigned)row);
         if (score > 0 && key > mine) mine = key;
     }
-    if (mine) atomicMax(&best[job], mine);
+    // one atomic per workgroup: reduce over the wave first
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long other = __shfl_down(mine, d);
+        if (other > mine) mine = other;
+    }
+    if (threadIdx.x == 0 && mine) atomicMax(&best[job], mine);
 }
 
 void launch_sym(const uint8_t *ascii, int64_t length, uint8_t *sym, hipStream_t stream) {
@@ -1150,10 +1162,11 @@ void launch_sym(const uint8_t *ascii, int64_t length, uint8_t *sym, hipStream_t 
     hipLaunchKernelGGL(sym_kernel, dim3((unsigned)((length + 255) / 256)), dim3(256), 0, stream, ascii, length, sym);
 }
 
-void launch_long_motif_rows(const uint8_t *sym, int64_t length, const void *jobs, int64_t njobs, unsigned long long *best,
-                            hipStream_t stream) {
-    if (njobs <= 0) return;
-    hipLaunchKernelGGL(long_motif_rows_kernel, dim3((unsigned)njobs), dim3(64), 0, stream, sym, length, (const int4 *)jobs, njobs, best);
+void launch_long_motif_rows(const uint8_t *sym, int64_t length, const void *jobs, int64_t njobs, const void *blocks,
+                            int64_t nblocks, unsigned long long *best, hipStream_t stream) {
+    if (njobs <= 0 || nblocks <= 0) return;
+    hipLaunchKernelGGL(long_motif_rows_kernel, dim3((unsigned)nblocks), dim3(64), 0, stream, sym, length, (const int4 *)jobs, njobs,
+                       (const int2 *)blocks, best);
 }
 
 // ------------------------------------------------------------------- PMC calibration

@@ -454,7 +454,7 @@ struct Writer {
 
 void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
                    const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
-                   const std::string &sequence_id, std::string &bed) {
+                   const std::string &sequence_id, std::string &bed, unsigned host_threads) {
     const Bases b(hp);
     auto run_range = [&](size_t lo, size_t hi, Writer &w) {
         for (size_t i = lo; i < hi; ++i) {
@@ -467,13 +467,16 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
     // reference's shared Alignment object untouched and so sees the previous seed's CIGAR.  Chunks of seeds
     // therefore run on host threads with their own writers, concatenated in seed order; if any chunk met an
     // empty query the record is redone sequentially.
-    unsigned threads = std::min(std::thread::hardware_concurrency(), 16u);      // one GPU's share of the host by default
-    if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
+    unsigned threads = host_threads ? host_threads : std::min(std::thread::hardware_concurrency(), 16u);   // one GPU's share of the host by default
+    if (!host_threads)
+        if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
     threads = std::max(1u, std::min(threads, 256u));
-    if (dispatch.size() < 4096) threads = 1;
+    if (dispatch.size() < 512) threads = 1;
     bool sequential = threads == 1;
     if (!sequential) {
-        const size_t chunk = 2048;
+        // ~8 chunks per thread (seed costs vary by orders of magnitude), 64..2048 seeds each
+        const size_t chunk = std::min<size_t>(2048, std::max<size_t>(64, dispatch.size() / (threads * 8)));
+        threads = (unsigned)std::min<size_t>(threads, (dispatch.size() + chunk - 1) / chunk);
         const size_t nchunks = (dispatch.size() + chunk - 1) / chunk;
         std::vector<std::string> parts(nchunks);
         std::atomic<size_t> next{0};

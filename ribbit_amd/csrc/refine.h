@@ -36,6 +36,6 @@ int longest_run_host(const HostPlanes &hp, int mlen, int start, int end);
 // and the BED rows (11 tab-separated columns) appended to `bed`.  sequence = the record's bases.
 void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
                    const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
-                   const std::string &sequence_id, std::string &bed);
+                   const std::string &sequence_id, std::string &bed, unsigned host_threads = 0);
 
 }  // namespace rb

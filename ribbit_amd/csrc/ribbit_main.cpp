@@ -4,11 +4,22 @@
 //
 //   ribbit-hip -i in.fa [-o out.bed] [-m 2] [-M 100] [-p 0.85] [-l N|file] [--min-units N|file] [--perfect-units N|file]
 //
+// Records are independent (ribbit.cpp:269-280 handles them one after the other); here up to --jobs of them are in
+// flight at once, each on its own handle / HIP stream, so that the GPU scans of one record overlap the sequential
+// host merges of the others (long-read inputs: thousands of 10-100 kb records).  Output order is the input order.
+//
 // Reproduced quirks: -p is accepted and ignored (Q1); without -o the BED rows go to
 // stderr (Q2); --help exits with status 1 (Q3); the record name ends at the first space and the last
 // record is processed even when the file is empty (Q4).
 #include <algorithm>
 #include <cctype>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,6 +40,7 @@ struct Options {
     bool has_min_length = false, has_min_units = false, has_perfect_units = false;
     std::string min_length, min_units, perfect_units;
     int device = 0;
+    int jobs = 0;                                 // records in flight; 0 = automatic
 };
 
 const char *kHelp =
@@ -43,7 +55,9 @@ const char *kHelp =
     "  --min-units arg               The minimum number of units of the repeat. Integer, or a tab separated file\n"
     "                                with the motif size and the unit cutoff. Default: 2\n"
     "  --perfect-units arg           The minimum number of complete units of the repeat. Integer, or a tab\n"
-    "                                separated file with the motif size and the unit cutoff. Default: 2\n";
+    "                                separated file with the motif size and the unit cutoff. Default: 2\n"
+    "  --jobs arg                    (ribbit-hip) FASTA records processed side by side. Default: automatic\n"
+    "  --device arg                  (ribbit-hip) GPU ordinal. Default: 0\n";
 
 [[noreturn]] void die(const std::string &msg) {
     std::cerr << "ribbit-hip: " << msg << "\n";
@@ -54,7 +68,7 @@ const char *kHelp =
 int parse_arguments(int argc, char **argv, Options &o) {
     static const std::map<std::string, std::string> longs = {
         {"help", "h"}, {"input-file", "i"}, {"output-file", "o"}, {"min-motif-length", "m"}, {"max-motif-length", "M"},
-        {"purity", "p"}, {"min-length", "l"}, {"min-units", "U"}, {"perfect-units", "P"}, {"device", "D"}};
+        {"purity", "p"}, {"min-length", "l"}, {"min-units", "U"}, {"perfect-units", "P"}, {"device", "D"}, {"jobs", "J"}};
     bool help = false;
     for (int a = 1; a < argc; ++a) {
         std::string arg = argv[a], key, value;
@@ -87,6 +101,7 @@ int parse_arguments(int argc, char **argv, Options &o) {
         else if (key == "U") { o.has_min_units = true; o.min_units = value; }
         else if (key == "P") { o.has_perfect_units = true; o.perfect_units = value; }
         else if (key == "D") o.device = std::atoi(value.c_str());
+        else if (key == "J") o.jobs = std::atoi(value.c_str());
     }
     if (help) { std::cerr << kHelp << "\n"; return 0; }                       // ribbit.cpp:114-117
     if (o.fasta.empty()) { std::cerr << "ERROR: Please specify an input fasta file!\n"; return 0; }   // :122-126
@@ -146,32 +161,41 @@ size_t count_failed(const RibbitSeed *s, size_t n) {
     return c;
 }
 
+// RIBBIT_PROFILE=1: wall time per stage, summed over the records, printed at exit
+double g_stage_ms[6] = {0, 0, 0, 0, 0, 0};
+struct StageClock {
+    int slot;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit StageClock(int s) : slot(s) {}
+    ~StageClock() { g_stage_ms[slot] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 // processSequence (fasta_utils.cpp:59-250) through the C ABI, with the reference's progress lines
 void process_sequence(RibbitHandle *h, const RibbitRefineParams &prm, const std::string &name, const std::string &sequence,
-                      std::ostream &out) {
+                      std::ostream &out, std::ostream &log) {
     const time_t t0 = time(0);
     auto secs = [&]() { return difftime(time(0), t0); };
-    check(ribbit_hip_load_record(h, sequence.data(), (int64_t)sequence.size()));
-    std::cerr << "Generated shift XORs!\t Time elapsed:" << secs() << "secs\n";
+    { StageClock c(0); check(ribbit_hip_load_record(h, sequence.data(), (int64_t)sequence.size())); }
+    log << "Generated shift XORs!\t Time elapsed:" << secs() << "secs\n";
     const RibbitSeed *p, *s, *a;
     size_t np, ns, na;
-    check(ribbit_hip_seeds_perfect(h, &p, &np));
-    std::cerr << "Total number of perfect seeds: " << np << "\t Time elapsed: " << secs() << "secs\n";
-    check(ribbit_hip_seeds_substitutions(h, &p, &np, &s, &ns));
-    std::cerr << "Total number of seeds considering substitutions: " << np + ns - count_failed(p, np) - count_failed(s, ns)
+    { StageClock c(1); check(ribbit_hip_seeds_perfect(h, &p, &np)); }
+    log << "Total number of perfect seeds: " << np << "\t Time elapsed: " << secs() << "secs\n";
+    { StageClock c(2); check(ribbit_hip_seeds_substitutions(h, &p, &np, &s, &ns)); }
+    log << "Total number of seeds considering substitutions: " << np + ns - count_failed(p, np) - count_failed(s, ns)
               << "\t Time elapsed: " << secs() << "secs\n";
-    check(ribbit_hip_seeds_anchored(h, &p, &np, &s, &ns, &a, &na));
-    std::cerr << "Generated anchored shift XORs!\t Time elapsed: " << secs() << "secs\n";
-    std::cerr << "Total number of seeds considering indels: "
+    { StageClock c(3); check(ribbit_hip_seeds_anchored(h, &p, &np, &s, &ns, &a, &na)); }
+    log << "Generated anchored shift XORs!\t Time elapsed: " << secs() << "secs\n";
+    log << "Total number of seeds considering indels: "
               << np + ns + na - count_failed(p, np) - count_failed(s, ns) - count_failed(a, na) << "\t Time elapsed: " << secs() << "secs\n";
     const RibbitSeed *d;
     size_t nd;
-    check(ribbit_hip_dispatch_seeds(h, &d, &nd));
+    { StageClock c(4); check(ribbit_hip_dispatch_seeds(h, &d, &nd)); }
     const char *text;
     size_t len;
-    check(ribbit_hip_refine_bed(h, &prm, name.c_str(), &text, &len));
+    { StageClock c(5); check(ribbit_hip_refine_bed(h, &prm, name.c_str(), &text, &len)); }
     out.write(text, (std::streamsize)len);
-    std::cerr << "Total number of seeds that are processed for alignment: " << nd << "\t Time elapsed: " << secs() << "secs\n";
+    log << "Total number of seeds that are processed for alignment: " << nd << "\t Time elapsed: " << secs() << "secs\n";
 }
 
 }  // namespace
@@ -195,14 +219,87 @@ int main(int argc, char **argv) {
     RibbitHandle *h = nullptr;
     check(ribbit_hip_open(&scan, opt.device, &h));
 
+    // ---- record pipeline: the reader (this thread) parses records; `jobs` workers process them on their own
+    // handles; results are written in input order.  A record weighs ceil(length / 4 Mbp) of the `jobs` tokens (at
+    // most all of them), so many reads run side by side while a chromosome has the machine to itself.
+    unsigned cores = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+    if (const char *env = std::getenv("RIBBIT_THREADS")) cores = (unsigned)std::max(1, std::atoi(env));
+    int jobs = (int)std::max(1u, std::min(8u, cores / 2));
+    if (const char *env = std::getenv("RIBBIT_JOBS")) jobs = std::max(1, std::atoi(env));
+    if (opt.jobs > 0) jobs = opt.jobs;
+    jobs = std::min(jobs, 64);
+    struct Record { size_t index; std::string name, sequence; };
+    struct Result { std::string bed, log; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Record> queue;
+    std::map<size_t, Result> done;
+    size_t next_out = 0;
+    bool reader_done = false;
+    int tokens = jobs;
+
+    auto flush_ready = [&]() {                      // call with mu held
+        for (auto it = done.find(next_out); it != done.end(); it = done.find(next_out)) {
+            std::cerr << it->second.log;
+            out.write(it->second.bed.data(), (std::streamsize)it->second.bed.size());
+            done.erase(it);
+            ++next_out;
+        }
+    };
+    auto worker = [&](RibbitHandle *wh) {
+        for (;;) {
+            Record rec;
+            int weight;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    if (!queue.empty()) {
+                        weight = (int)std::min<size_t>((size_t)jobs, queue.front().sequence.size() / 4000000 + 1);
+                        if (tokens >= weight) break;
+                    } else if (reader_done) {
+                        return;
+                    }
+                    cv.wait(lk);
+                }
+                rec = std::move(queue.front());
+                queue.pop_front();
+                tokens -= weight;
+            }
+            cv.notify_all();
+            check(ribbit_hip_set_host_threads(wh, (int)std::max(1u, cores * (unsigned)weight / (unsigned)jobs)));
+            std::ostringstream bed, log;
+            log << "Processing sequence " << rec.name << "\n";
+            process_sequence(wh, prm, rec.name, rec.sequence, bed, log);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                done[rec.index] = Result{bed.str(), log.str()};
+                tokens += weight;
+                flush_ready();
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<RibbitHandle *> handles{h};
+    for (int j = 1; j < jobs; ++j) {
+        RibbitHandle *extra = nullptr;
+        check(ribbit_hip_open(&scan, opt.device, &extra));
+        handles.push_back(extra);
+    }
+    std::vector<std::thread> pool;
+    for (RibbitHandle *wh : handles) pool.emplace_back(worker, wh);
+
+    size_t n_records = 0;
+    auto submit = [&](std::string &name, std::string &sequence) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return queue.size() < (size_t)(2 * jobs); });       // bounded look-ahead
+        queue.push_back(Record{n_records++, name, std::move(sequence)});
+        cv.notify_all();
+    };
     std::ifstream in(opt.fasta);
     std::string line, name, sequence;
     while (std::getline(in, line)) {                                          // ribbit.cpp:269-279
         if (!line.empty() && line[0] == '>') {
-            if (!sequence.empty()) {
-                std::cerr << "Processing sequence " << name << "\n";
-                process_sequence(h, prm, name, sequence, out);
-            }
+            if (!sequence.empty()) submit(name, sequence);
             const size_t sp = line.find(' ');
             name = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
             sequence.clear();
@@ -210,7 +307,24 @@ int main(int argc, char **argv) {
             sequence += line;
         }
     }
-    process_sequence(h, prm, name, sequence, out);                            // :280, also for an empty file (Q4)
+    // :280 -- the last record is processed unconditionally and WITHOUT the "Processing sequence" line, also for an
+    // empty file (Q4): it bypasses the pipeline once the pipeline has drained
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        reader_done = true;
+        cv.notify_all();
+    }
+    for (std::thread &t : pool) t.join();
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        flush_ready();
+    }
+    check(ribbit_hip_set_host_threads(h, 0));
+    process_sequence(h, prm, name, sequence, out, std::cerr);
+    for (size_t j = 1; j < handles.size(); ++j) ribbit_hip_close(handles[j]);
     ribbit_hip_close(h);
+    if (std::getenv("RIBBIT_PROFILE"))
+        std::cerr << "[stages, ms over all records] load " << g_stage_ms[0] << "  perfect " << g_stage_ms[1] << "  substitutions "
+                  << g_stage_ms[2] << "  anchored " << g_stage_ms[3] << "  dispatch " << g_stage_ms[4] << "  refine+BED " << g_stage_ms[5] << "\n";
     return 0;
 }
