@@ -1,0 +1,35 @@
+"""CPU fuzz: the oracle's call logs replayed through the product's independently written merges, refinement and
+BED writer on seeded adversarial records (tests/fuzz.py).  Any disagreement prints the seed."""
+import os
+
+import numpy as np
+import pytest
+
+import ribbit_amd
+from fuzz import fuzz_case
+from oracle_lib import LIST_ANCHORED, LIST_PERFECT, LIST_SUBST, Oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAVE_REF_SSW = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libssw_ref.so"))
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_merges_and_bed_rows_agree_with_the_oracle_on_fuzzed_records(block):
+    for seed in range(9000 + 40 * block, 9000 + 40 * (block + 1)):
+        seq, m_lo, m_hi = fuzz_case(seed)
+        tag = f"seed {seed}: {len(seq)} bases, -m {m_lo} -M {m_hi}"
+        with Oracle(seq, m_lo, m_hi) as o:
+            o.run_perfect(); pc = o.calls(LIST_PERFECT)
+            o.run_subst(); sc = o.calls(LIST_SUBST)
+            o.run_anchor_planes()
+            xa, stride = ribbit_amd.pack_bit_planes([o.plane(m) for m in range(m_lo, m_hi + 1)], len(seq))
+            o.run_anchored(); o.run_dispatch()
+            r = ribbit_amd.host_replay_calls(m_lo, m_hi, seq, pc, sc, o.calls(LIST_ANCHORED), xa, stride)
+            assert np.array_equal(r["perfect"].view("<i4"), o.seeds(LIST_PERFECT).view("<i4")), tag
+            assert np.array_equal(r["subst"].view("<i4"), o.seeds(LIST_SUBST).view("<i4")), tag
+            assert np.array_equal(r["anchored"].view("<i4"), o.seeds(LIST_ANCHORED).view("<i4")), tag
+            assert np.array_equal(r["dispatch"].view("<i4"), o.dispatch().view("<i4")), tag
+            assert r["guard_hits"] == o.guard_hits(), tag
+            if HAVE_REF_SSW and len(seq):
+                got = ribbit_amd.host_refine_bed(m_lo, m_hi, seq, xa, stride, o.dispatch(), "fz")
+                assert got.split("\n") == o.refine_bed("fz").split("\n"), tag

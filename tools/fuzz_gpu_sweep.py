@@ -1,0 +1,35 @@
+"""One-off wide fuzz on the GPU box: whole path against the oracle for seeds [lo, hi) of tests/fuzz.py.
+Usage: python tools/fuzz_gpu_sweep.py <lo> <hi>  (prints mismatching seeds; progress every 200 cases)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ribbit_amd
+from fuzz import fuzz_case
+from oracle_lib import LIST_ANCHORED, LIST_PERFECT, LIST_SUBST, Oracle
+
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+bad, t0 = 0, time.time()
+for seed in range(lo, hi):
+    seq, m_lo, m_hi = fuzz_case(seed)
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc, Oracle(seq, m_lo, m_hi) as o:
+        sc.load_record(seq)
+        o.run_all()
+        ok = np.array_equal(sc.perfect_calls().view("<i4"), o.calls(LIST_PERFECT).view("<i4"))
+        ok &= np.array_equal(sc.subst_calls().view("<i4"), o.calls(LIST_SUBST).view("<i4"))
+        ok &= np.array_equal(sc.anchored_calls().view("<i4"), o.calls(LIST_ANCHORED).view("<i4"))
+        p, s, a = sc.processShiftXORsAnchored()
+        ok &= np.array_equal(p.view("<i4"), o.seeds(LIST_PERFECT).view("<i4")) and np.array_equal(s.view("<i4"), o.seeds(LIST_SUBST).view("<i4"))
+        ok &= np.array_equal(a.view("<i4"), o.seeds(LIST_ANCHORED).view("<i4")) and np.array_equal(sc.dispatch_seeds().view("<i4"), o.dispatch().view("<i4"))
+        ok &= sc.guard_hits() == o.guard_hits() and sc.refine_bed("fz") == o.refine_bed("fz")
+    if not ok:
+        bad += 1
+        print(f"MISMATCH seed {seed}: {len(seq)} bases -m {m_lo} -M {m_hi}", flush=True)
+    if (seed - lo) % 200 == 199:
+        print(f"... {seed - lo + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+print(f"seeds [{lo}, {hi}): {bad} mismatches")
