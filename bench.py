@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "shm", "rccl"],
                     help="N > 1: how the chunks' run records reach rank 0's host merge (auto: shm on one node, else rccl)")
+    ap.add_argument("--depth", type=int, default=3,
+                    help="batches in flight per GPU (handles/streams alternating); 1 = strictly one after the other")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--verify", action="store_true",
                     help="N > 1: rank 0 also scans the whole record on its own GPU and checks the sharded runs against it")
@@ -103,7 +105,13 @@ def main():
     d_ascii = torch.frombuffer(bytearray(loaded), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
 
-    sc = ribbit_amd.Scanner(M_LO, M_HI, device=local_rank)
+    # Two handles (each with its own HIP stream) alternate: while one batch's run records cross PCIe, the next
+    # batch is already being packed and scanned -- the double-buffered streaming of a multi-record FASTA.
+    depth = max(1, args.depth)
+    scs = [ribbit_amd.Scanner(M_LO, M_HI, device=local_rank) for _ in range(depth)]
+    sc = scs[0]
+    pos_offset = rank * args.bases - own_lo
+    lo_hi = (own_lo, own_hi) if world > 1 else (0, (1 << 63) - 1)
 
     # N > 1: every rank scans and pairs its chunk on its GPU; the run records (16 B each) are then gathered for the
     # host-side merge on rank 0.  On one node every GPU copies its records down its own PCIe link into a page-locked
@@ -114,62 +122,83 @@ def main():
     ng = None
     if world > 1 and exchange == "shm":
         sc.load_record_device(d_ascii.data_ptr(), d_ascii.numel())
-        probe, _ = sc.scan_perfect_chunk(own_lo, own_hi, rank * args.bases - own_lo)
+        probe, _ = sc.scan_perfect_chunk(own_lo, own_hi, pos_offset)
         cap = max(int(a[0]) for a in allgather_array(np.array([len(probe)], dtype=np.int64), xdev))
-        ng = open_node_gather(ribbit_amd.RUN_DT, 2 * cap + 4096, 2 * (M_HI - M_LO + 1))
+        ng = open_node_gather(ribbit_amd.RUN_DT, 2 * cap + 4096, 2 * (M_HI - M_LO + 1), nslots=depth + 1)
         for addr, nbytes in ng.my_cells():
             try:
                 sc.host_register(addr, nbytes)
             except ribbit_amd.RibbitHipError as e:       # still correct, the copies are just staged by the runtime
                 print(f"rank {rank}: shared segment not page-locked ({e})", file=sys.stderr)
                 break
-    step_no = [0]
 
-    def step():
-        sc.load_record_device(d_ascii.data_ptr(), d_ascii.numel())
+    def issue(k):
+        """enqueue batch k: pack + scan + pairing kernels on handle k % depth, no waiting"""
+        h = scs[k % depth]
+        h.load_record_device(d_ascii.data_ptr(), d_ascii.numel())
+        h.scan_perfect_begin(lo_hi[0], lo_hi[1], pos_offset if world > 1 else 0)
+
+    def complete(k):
+        """batch k's run records on the host (rank 0: of every rank)"""
+        h = scs[k % depth]
         if world == 1:
-            return sc.scan_perfect_runs(copy=False)       # the C ABI's own result buffer (pinned), as a C caller sees it
-        step_no[0] += 1
-        k = step_no[0]
+            return h.scan_perfect_end()[0]               # view of the C ABI's own pinned result buffer
         if ng is not None:
             if rank == 0 and k > 1:
-                ng.release(k - 1)                         # the previous step's views are dead from here on
+                ng.release(k - 1)                         # the previous batch's views are dead from here on
             ng.wait_free(k)
             rec, hv = ng.mine(k)
-            n, nh = sc.scan_perfect_chunk(own_lo, own_hi, rank * args.bases - own_lo, out=rec, halves_out=hv)
+            n, nh = h.scan_perfect_end(out=rec, halves_out=hv)
             ng.publish(k, n, nh)
             if rank != 0:
-                return rec[:n]
+                return [rec[:n]]
             parts, halves = ng.collect(k)
             # the record's runs: every chunk's records in place (term < 0 = place holder) + the runs cut by chunk edges
             return parts + [ribbit_amd.join_run_halves(halves)]
-        runs, halves = sc.scan_perfect_chunk(own_lo, own_hi, rank * args.bases - own_lo)
+        runs, halves = h.scan_perfect_end()
         all_runs = gather_array(runs, xdev)
         all_halves = gather_array(halves, xdev)
         if rank == 0:
             return all_runs + [ribbit_amd.join_run_halves(all_halves)]
-        return runs
+        return [runs]
 
-    for _ in range(args.warmup):
-        step()
+    batch = [0]          # batches are numbered 1, 2, ... across warm-up and timed region
+
+    def run_steps(n, on_step=None):
+        first, last = batch[0] + 1, batch[0] + n
+        issued, out = first - 1, None
+        for k in range(first, last + 1):
+            while issued < min(k + depth - 1, last):      # keep `depth` batches in flight
+                issued += 1
+                issue(issued)
+            out = complete(k)
+            if on_step:
+                on_step(scs[k % depth], out)
+        batch[0] = last
+        return out
+
+    run_steps(args.warmup)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    kernel_ms, pack_ms, gpu_ms, nruns, nevents = [], [], [], 0, 0
+    kernel_ms, pack_ms, gpu_ms, counts = [], [], [], [0, 0]
+
+    def on_step(h, out):
+        kernel_ms.append(h.timing_ms(1))
+        pack_ms.append(h.timing_ms(0))
+        gpu_ms.append(h.timing_ms(2))
+        counts[0] = len(out) if world == 1 else sum(len(r) for r in out)
+        counts[1] = h.last_event_count()
+
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runs = step()
-        kernel_ms.append(sc.timing_ms(1))
-        pack_ms.append(sc.timing_ms(0))
-        gpu_ms.append(sc.timing_ms(2))
-        nruns = len(runs) if world == 1 else (sum(len(r) for r in runs) if rank == 0 else len(runs))
-        nevents = sc.last_event_count()
+    runs = run_steps(args.steps, on_step)
     fence()
     dt = time.perf_counter() - t0
+    nruns, nevents = counts
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -207,6 +236,7 @@ def main():
             "data": "synthetic (ribbit_amd.simulate, seeded restatement of data_simulation/simulate_data.py)",
             "config": {"workload": f"{args.bases} bp synthetic record per GPU, -m {M_LO} -M {M_HI}, "
                                    "pack + perfect shift-XOR scan (BASELINE.json configs[1])",
+                       "batches_in_flight": depth,
                        "bases_per_gpu": args.bases, "min_motif": M_LO, "max_motif": M_HI,
                        "parallelism": (f"one record chunk-sharded x{world} (halos), runs paired on each GPU, gathered for rank 0's host merge "
                                        + ("through page-locked node-shared memory (one PCIe link per GPU)" if ng is not None else "by gather-v over RCCL"))
@@ -241,7 +271,8 @@ def main():
                 pass
         runs = None
         ng.close()
-    sc.close()
+    for h in scs:
+        h.close()
     if world > 1:
         dist.destroy_process_group()
 

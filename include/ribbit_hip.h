@@ -333,6 +333,15 @@ int ribbit_hip_scan_perfect_chunk(RibbitHandle *h, int64_t own_lo, int64_t own_h
                                   RibbitRun *dst, size_t dst_cap, RibbitRun *half_dst, size_t half_dst_cap,
                                   const RibbitRun **out, size_t *n, const RibbitRun **halves, size_t *n_halves);
 
+/* The same scan split in two, for callers that keep several handles (each has its own HIP stream) busy: _begin
+ * enqueues the load's pack, the scan and the pairing kernels and returns at once; _end waits for them and
+ * copies the records down (arguments as for ribbit_hip_scan_perfect_chunk).  With two handles, one record's
+ * kernels run while the previous record's runs cross PCIe -- the double-buffered streaming of a multi-record
+ * FASTA (ribbit.cpp:269-280 is the loop being pipelined).  A whole record: own_lo 0, own_hi INT64_MAX, offset 0. */
+int ribbit_hip_scan_perfect_begin(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset);
+int ribbit_hip_scan_perfect_end(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *half_dst, size_t half_dst_cap,
+                                const RibbitRun **out, size_t *n, const RibbitRun **halves, size_t *n_halves);
+
 /* Worker threads the host-side stages of this handle may use (window state machines, refinement);
  * 0 = default (environment RIBBIT_THREADS, else min(cores, 16)).  A caller that keeps several handles busy at
  * once -- ribbit-hip does, one per in-flight FASTA record (ribbit.cpp:269-280 processes them one by one) --

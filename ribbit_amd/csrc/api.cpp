@@ -127,6 +127,9 @@ struct RibbitHandle {
     DevBuf<uint32_t> d_run_base, d_pair_partial, d_pair_status;
     PinnedBuf<uint32_t> h_pair_status;
     PinnedBuf<RibbitRun> h_runs, h_halves;
+    rb::PairLaunch pair{};                // the perfect scan in flight (perfect_begin .. perfect_finish)
+    size_t pair_cap = 0;
+    bool pair_pending = false;
     DevBuf<RibbitRun> d_halves;
     size_t n_runs = 0, n_halves = 0;
     std::vector<RibbitCall> perfect_calls;
@@ -317,21 +320,48 @@ rb::EventSource event_source(const RibbitHandle *h) {
 // Perfect stage on the device end to end: scan kernel -> START/END events (left in their regions, never
 // copied to the host) -> pairing kernels -> RibbitRun records ordered by (motif, start) -> one D2H copy
 // into pinned memory.  The host only checks the counters and the pairing status.
-// own_lo/own_hi/pos_offset: see rb::PairLaunch (a whole record is 0, INT64_MAX, 0).  dst: where the records go
-// (caller's buffer of dst_cap records, ideally pinned) or nullptr for the handle's own pinned buffer.
-int run_perfect_scan_range(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset, RibbitRun *dst, size_t dst_cap,
-                           RibbitRun *half_dst = nullptr, size_t half_dst_cap = 0) {
-    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
-    const bool whole = own_lo == 0 && own_hi == INT64_MAX && pos_offset == 0 && !dst;
-    if (whole && h->runs_valid) return RIBBIT_OK;
-    h->runs_valid = h->calls_valid = false;
+// The perfect stage in two halves, so that a caller with several handles can keep one record's kernels running
+// while another record's results travel to the host (each handle has its own stream):
+//   perfect_enqueue: memset + scan + pairing kernels + D2H of counters and status, no synchronisation;
+//   perfect_finish:  waits for those, grows the event buffer and repeats on overflow, then copies the run records.
+// own_lo/own_hi/pos_offset: see rb::PairLaunch (a whole record is 0, INT64_MAX, 0).
+int perfect_enqueue(RibbitHandle *h, size_t cap) {
     int rc;
     if ((rc = bind_device(h))) return rc;
+    rb::PairLaunch &pr = h->pair;
+    cap = std::min<size_t>((cap + rb::EV_SHARDS - 1) / rb::EV_SHARDS * rb::EV_SHARDS, 0xffffff00u);
+    if ((rc = h->d_events.ensure(cap))) return rc;
+    if ((rc = h->d_dense.ensure(cap))) return rc;        // cap/2 runs of 16 bytes
+    h->pair_cap = cap;
+    HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, rb::EV_COUNTER_WORDS * sizeof(uint32_t), h->stream));
+    rb::PerfectLaunch pp;
+    pp.m_lo = h->params.min_motif;
+    pp.m_hi = h->params.max_motif;
+    pp.ev_cap = (uint32_t)cap;
+    pr.region_cap = pp.ev_cap / (uint32_t)rb::EV_SHARDS;
+    HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+    rb::launch_scan_perfect(h->planes(), pp, h->d_events.p, h->d_counters.p, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    rb::launch_pair_runs(h->d_events.p, h->d_counters.p, pr, h->d_pair_table.p, h->d_run_base.p, h->d_pair_partial.p,
+                         h->d_dense.p, (uint32_t)(cap / 2), h->d_halves.p, (uint32_t)(2 * (size_t)pr.nm), h->d_pair_status.p, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->h_counters.p, h->d_counters.p, rb::EV_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_pair_status.p, h->d_pair_status.p, rb::PAIR_STATUS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    return RIBBIT_OK;
+}
+
+int perfect_begin(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset) {
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    h->runs_valid = h->calls_valid = false;
+    h->pair_pending = false;
+    int rc;
     if ((rc = h->d_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
     if ((rc = h->h_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
     if ((rc = h->d_pair_status.ensure(rb::PAIR_STATUS_WORDS))) return rc;
     if ((rc = h->h_pair_status.ensure(rb::PAIR_STATUS_WORDS))) return rc;
-    rb::PairLaunch pr;
+    rb::PairLaunch &pr = h->pair;
     pr.m_lo = (uint32_t)h->params.min_motif;
     pr.nm = (uint32_t)(h->params.max_motif - h->params.min_motif + 1);
     pr.ntile = (uint32_t)(h->length / rb::TILE_BASES + 1);
@@ -344,30 +374,20 @@ int run_perfect_scan_range(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int6
     if ((rc = h->d_pair_table.ensure(entries))) return rc;
     if ((rc = h->d_run_base.ensure(entries))) return rc;
     if ((rc = h->d_pair_partial.ensure(entries / 1024 + 2))) return rc;
-    size_t cap = std::max<size_t>((size_t)1 << 20, (size_t)(h->length / 4));
-    cap = std::max(cap, h->d_events.cap);
-    const rb::DevicePlanes pl = h->planes();
+    const size_t cap = std::max(std::max<size_t>((size_t)1 << 20, (size_t)(h->length / 4)), h->d_events.cap);
+    if ((rc = perfect_enqueue(h, cap))) return rc;
+    h->pair_pending = true;
+    return RIBBIT_OK;
+}
+
+int perfect_finish(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *half_dst, size_t half_dst_cap) {
+    if (!h->pair_pending) return fail(RIBBIT_E_STATE, "no perfect scan in flight on this handle");
+    h->pair_pending = false;
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    const rb::PairLaunch &pr = h->pair;
     uint64_t produced = 0;
     for (int attempt = 0;; ++attempt) {
-        cap = std::min<size_t>((cap + rb::EV_SHARDS - 1) / rb::EV_SHARDS * rb::EV_SHARDS, 0xffffff00u);
-        if ((rc = h->d_events.ensure(cap))) return rc;
-        if ((rc = h->d_dense.ensure(cap))) return rc;        // cap/2 runs of 16 bytes
-        HIP_TRY(hipEventRecord(h->ev[4], h->stream));
-        HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, rb::EV_COUNTER_WORDS * sizeof(uint32_t), h->stream));
-        rb::PerfectLaunch pp;
-        pp.m_lo = h->params.min_motif;
-        pp.m_hi = h->params.max_motif;
-        pp.ev_cap = (uint32_t)cap;
-        pr.region_cap = pp.ev_cap / (uint32_t)rb::EV_SHARDS;
-        HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-        rb::launch_scan_perfect(pl, pp, h->d_events.p, h->d_counters.p, h->stream);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(h->ev[3], h->stream));
-        rb::launch_pair_runs(h->d_events.p, h->d_counters.p, pr, h->d_pair_table.p, h->d_run_base.p, h->d_pair_partial.p,
-                             h->d_dense.p, (uint32_t)(cap / 2), h->d_halves.p, (uint32_t)half_cap, h->d_pair_status.p, h->stream);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h->h_counters.p, h->d_counters.p, rb::EV_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->h_pair_status.p, h->d_pair_status.p, rb::PAIR_STATUS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         uint32_t worst = 0;
         produced = 0;
@@ -377,10 +397,10 @@ int run_perfect_scan_range(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int6
             produced += c;
         }
         if (worst <= pr.region_cap) break;
-        // some region overflowed: size every region for the fullest one and retry
+        // some region overflowed: size every region for the fullest one and run again
         if (attempt == 2 || (size_t)worst * rb::EV_SHARDS > 0xffffff00u)
             return fail(RIBBIT_E_OVERFLOW, "event buffer overflow: fullest region needs %u events", worst);
-        cap = ((size_t)worst + 1024) * rb::EV_SHARDS;
+        if ((rc = perfect_enqueue(h, ((size_t)worst + 1024) * rb::EV_SHARDS))) return rc;
     }
     h->last_event_count = (int64_t)produced;
     const uint32_t flags = h->h_pair_status.p[rb::PAIR_FLAGS];
@@ -398,6 +418,7 @@ int run_perfect_scan_range(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int6
     if (h->n_halves)
         HIP_TRY(hipMemcpyAsync(half_dst, h->d_halves.p, h->n_halves * sizeof(RibbitRun), hipMemcpyDeviceToHost, h->stream));
     if (dst && h->n_runs > dst_cap) return fail(RIBBIT_E_OVERFLOW, "%zu run records do not fit the caller's buffer of %zu", h->n_runs, dst_cap);
+    const bool whole = pr.own_lo == 0 && pr.own_hi == INT64_MAX && pr.pos_offset == 0 && !dst;
     if (!dst) {
         if ((rc = h->h_runs.ensure(std::max<size_t>(h->n_runs, 1)))) return rc;
         dst = h->h_runs.p;
@@ -410,6 +431,16 @@ int run_perfect_scan_range(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int6
     h->host_ms = 0.0;
     h->runs_valid = whole;
     return RIBBIT_OK;
+}
+
+int run_perfect_scan_range(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset, RibbitRun *dst, size_t dst_cap,
+                           RibbitRun *half_dst = nullptr, size_t half_dst_cap = 0) {
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    const bool whole = own_lo == 0 && own_hi == INT64_MAX && pos_offset == 0 && !dst;
+    if (whole && h->runs_valid) return RIBBIT_OK;
+    int rc = perfect_begin(h, own_lo, own_hi, pos_offset);
+    if (rc) return rc;
+    return perfect_finish(h, dst, dst_cap, half_dst, half_dst_cap);
 }
 
 int run_perfect_scan(RibbitHandle *h) { return run_perfect_scan_range(h, 0, INT64_MAX, 0, nullptr, 0); }
@@ -1027,6 +1058,24 @@ int ribbit_hip_scan_perfect_chunk(RibbitHandle *h, int64_t own_lo, int64_t own_h
     *n = h->n_runs;
     *halves = half_dst ? half_dst : h->h_halves.p;
     *n_halves = h->n_halves;
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_scan_perfect_begin(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset) {
+    if (!h) return fail(RIBBIT_E_ARG, "null argument");
+    if (own_lo < 0 || own_hi < own_lo) return fail(RIBBIT_E_ARG, "bad own range");
+    return perfect_begin(h, own_lo, own_hi, pos_offset);
+}
+
+int ribbit_hip_scan_perfect_end(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *half_dst, size_t half_dst_cap,
+                                const RibbitRun **out, size_t *n, const RibbitRun **halves, size_t *n_halves) {
+    if (!h || !out || !n) return fail(RIBBIT_E_ARG, "null argument");
+    int rc = perfect_finish(h, dst, dst_cap, half_dst, half_dst_cap);
+    if (rc) return rc;
+    *out = dst ? dst : h->h_runs.p;
+    *n = h->n_runs;
+    if (halves) *halves = half_dst ? half_dst : h->h_halves.p;
+    if (n_halves) *n_halves = h->n_halves;
     return RIBBIT_OK;
 }
 

@@ -2,6 +2,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <thread>
 
@@ -106,6 +108,9 @@ bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vec
     // record, tile by tile, settling pending groups as soon as their reporting window is known to precede the
     // next tile, so that a call is generated while its tile (or the one before) is current.  Calls go to a
     // per-worker vector; cut[t] marks where tile t's calls start.  A worker's calls inside a tile are motif-major.
+    static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
     struct Worker { std::vector<RibbitCall> calls; std::vector<size_t> cut; std::vector<RibbitCall> flush; std::string err; };
     std::vector<Worker> work(threads);
     auto phase1 = [&](unsigned w) {
@@ -150,6 +155,7 @@ bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vec
     for (const Worker &w : work)
         if (!w.err.empty()) { if (why) *why = w.err; return false; }
 
+    const double t_phase1 = now();
     // Phase 2: a call generated while tile t was current has pos in [t*TILE, (t+1)*TILE + 7), i.e. it belongs to
     // ordering bucket t or t+1.  Count per bucket, prefix-sum, then fill and order every bucket independently
     // (parallel over buckets): (pos, motif) order by two stable counting sorts.
@@ -164,6 +170,7 @@ bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vec
         }
     for (size_t k = 0; k < nb; ++k) bucket_n[k + 1] += bucket_n[k];
     calls.resize(bucket_n[nb]);
+    const double t_count = now();
     std::atomic<size_t> next{0};
     std::atomic<bool> bad{false};
     auto phase2 = [&]() {
@@ -200,6 +207,9 @@ bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vec
         for (std::thread &t : pool) t.join();
     }
     if (bad) { if (why) *why = "call generated outside its ordering buckets"; return false; }
+    if (profile)
+        std::fprintf(stderr, "[window replay] %u threads: state machines %.1f ms, bucket count %.1f ms, ordering %.1f ms, %zu calls\n",
+                     threads, t_phase1 - t_begin, t_count - t_phase1, now() - t_count, calls.size());
 
     // the end-of-sequence flush comes last, in motif order
     std::vector<RibbitCall> flush;

@@ -81,16 +81,16 @@ def same_node() -> bool:
     return int(os.environ.get("LOCAL_WORLD_SIZE", "0")) == dist.get_world_size()
 
 
-def open_node_gather(dtype, cap: int, half_cap: int):
+def open_node_gather(dtype, cap: int, half_cap: int, nslots: int = 2):
     """Collective: rank 0 creates the node-shared segment (ribbit_amd.node_gather), its name is broadcast and
     the other ranks attach.  cap / half_cap must be the same on all ranks."""
     from .node_gather import NodeGather
     rank, world = dist.get_rank(), dist.get_world_size()
-    ng = NodeGather(dtype, cap, half_cap, rank, world) if rank == 0 else None
+    ng = NodeGather(dtype, cap, half_cap, rank, world, nslots=nslots) if rank == 0 else None
     box = [ng.name if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     if rank != 0:
-        ng = NodeGather(dtype, cap, half_cap, rank, world, name=box[0])
+        ng = NodeGather(dtype, cap, half_cap, rank, world, name=box[0], nslots=nslots)
     dist.barrier()
     return ng
 
