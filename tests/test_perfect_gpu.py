@@ -117,3 +117,27 @@ def test_full_size_properties_100mbp():
         sel = runs[(runs["start"] >= copy * m + 200) & (runs["end"] < (copy + 1) * m - 200) & (runs["start"] > copy * m + 200)]
         sel = sel.copy(); sel["start"] -= copy * m; sel["end"] -= copy * m
         assert np.array_equal(np.sort(sel, order=["mlen", "start"]), np.sort(inner, order=["mlen", "start"]))
+
+
+def test_begin_end_on_two_handles_interleaved_gives_the_same_runs():
+    """ribbit_hip_scan_perfect_begin/_end: two records in flight on two handles (own streams), finished out of
+    phase, must give what the one-call scan gives; _end without _begin is an error."""
+    (_, seq_a, m_lo, m_hi), (_, seq_b, _, _) = simulated_cases()[1], simulated_cases()[3]
+    with ribbit_amd.Scanner(m_lo, m_hi) as a, ribbit_amd.Scanner(m_lo, m_hi) as b:
+        a.load_record(seq_a); want_a = a.scan_perfect_runs()
+        b.load_record(seq_b); want_b = b.scan_perfect_runs()
+        for _ in range(3):
+            a.load_record(seq_a); a.scan_perfect_begin()
+            b.load_record(seq_b); b.scan_perfect_begin()
+            got_a, halves = a.scan_perfect_end()
+            assert len(halves) == 0 and np.array_equal(got_a.view("<i4"), want_a.view("<i4"))
+            a.load_record(seq_b); a.scan_perfect_begin()          # next batch enqueued before b is collected
+            got_b, _ = b.scan_perfect_end()
+            assert np.array_equal(got_b.view("<i4"), want_b.view("<i4"))
+            got_a2, _ = a.scan_perfect_end()
+            assert np.array_equal(got_a2.view("<i4"), want_b.view("<i4"))
+        with pytest.raises(ribbit_amd.RibbitHipError, match="no perfect scan in flight"):
+            a.scan_perfect_end()
+        # the later stages still work on a handle that used the split calls
+        a.load_record(seq_a)
+        assert len(a.processShiftXORsPerfect()) > 0
