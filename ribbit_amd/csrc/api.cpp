@@ -108,6 +108,7 @@ struct RibbitHandle {
     PinnedBuf<uint64_t> h_events;
     PinnedBuf<uint32_t> h_counters;
     PinnedBuf<uint32_t> h_query;
+    PinnedBuf<uint32_t> h_xa;          // host copy of the composed planes (rb::HostPlanes::xa_view points here)
 
     // host copy of the packed planes: answers the sparse, latency-bound range reads of the
     // sequential merges (retainNestedSeed & co) without a GPU round trip per query
@@ -132,11 +133,11 @@ struct RibbitHandle {
     bool pair_pending = false;
     DevBuf<RibbitRun> d_halves;
     size_t n_runs = 0, n_halves = 0;
-    std::vector<RibbitCall> perfect_calls;
+    rb::CallVec perfect_calls;
     bool subst_calls_valid = false;
-    std::vector<RibbitCall> subst_calls;
+    rb::CallVec subst_calls;
     bool anchored_calls_valid = false;
-    std::vector<RibbitCall> anchored_calls;
+    rb::CallVec anchored_calls;
     std::vector<RibbitSeed> dispatch;
     bool longest_valid = false;
     std::vector<int32_t> longest_runs;
@@ -237,7 +238,10 @@ int collect_events(RibbitHandle *h, int which) {
     if ((rc = h->d_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
     if ((rc = h->h_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
     // capacity in events, split evenly over EV_SHARDS regions; grows on overflow
-    size_t cap = std::max<size_t>((size_t)1 << 20, (size_t)(h->length / 4));
+    // typical event densities on repeat-rich sequence: 0.07 per base (perfect), 0.25 (1-mismatch windows), 3.7 (anchored
+    // windows at 99 motif sizes); a too small first guess costs a second launch and a second round of allocations
+    const size_t per_base_x4 = which == 0 ? 1 : which == 1 ? 2 : (size_t)std::max(16, (h->params.max_motif - h->params.min_motif + 1) / 6);
+    size_t cap = std::max<size_t>((size_t)1 << 20, (size_t)h->length * per_base_x4 / 4);
     cap = std::max(cap, h->d_events.cap);
     const rb::DevicePlanes pl = h->planes();
     uint32_t produced = 0;
@@ -521,11 +525,13 @@ int build_anchored_calls(RibbitHandle *h) {
     if ((rc = h->d_xa.ensure(nm * (size_t)h->xa_stride))) return rc;
     if ((rc = collect_events(h, 2))) return rc;
     // composed planes -> host (the sequential merges read a few bits at a time, far too often for a GPU round trip each)
-    h->host.xa.resize(nm * (size_t)h->xa_stride);
+    if ((rc = h->h_xa.ensure(nm * (size_t)h->xa_stride))) return rc;      // page-locked: the copy runs at link speed
+    h->host.xa.clear();
+    h->host.xa_view = h->h_xa.p;
     h->host.xa_stride = h->xa_stride;
     h->host.xa_m_lo = h->params.min_motif;
     h->host.xa_m_hi = h->params.max_motif;
-    HIP_TRY(hipMemcpyAsync(h->host.xa.data(), h->d_xa.p, nm * (size_t)h->xa_stride * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_xa.p, h->d_xa.p, nm * (size_t)h->xa_stride * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const double t0 = now_ms();
     std::string why;
@@ -539,7 +545,7 @@ int build_anchored_calls(RibbitHandle *h) {
 // but the end-of-sequence flush keeps the returned cursors only for the first of the two calls it
 // makes when a motif has both a pending group and an unmerged open streak
 // (parse_anchored_shiftxor.cpp:713 vs :688,:697,:706,:717).
-void replay_anchored_calls(rb::SeedLists &lists, const std::vector<RibbitCall> &calls, int64_t length) {
+void replay_anchored_calls(rb::SeedLists &lists, const rb::CallVec &calls, int64_t length) {
     rb::Cursor2 cur;
     int pending_end = -1;   // largest seed_end among in-loop calls that only moved the cursors (:133-153)
     auto catch_up = [&]() {
@@ -722,7 +728,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ascii.release(); h->d_hi.release(); h->d_lo.release(); h->d_brk.release();
     h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release(); h->d_slices.release();
-    h->h_events.release(); h->h_counters.release(); h->h_query.release();
+    h->h_events.release(); h->h_counters.release(); h->h_query.release(); h->h_xa.release();
     h->d_pair_table.release(); h->d_run_base.release(); h->d_pair_partial.release(); h->d_pair_status.release();
     h->h_pair_status.release(); h->h_runs.release(); h->h_halves.release(); h->d_halves.release();
     for (int i = 0; i < 6; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -1153,7 +1159,7 @@ int ribbit_host_scan_from_events(const RibbitScanParams *params, int64_t length,
     std::vector<rb::Seg> segs;
     std::string why;
     std::vector<RibbitRun> runs;
-    std::vector<RibbitCall> calls;
+    rb::CallVec calls;
     if (!rb::pair_perfect_runs(source(ev_perfect, cnt_perfect, segs), runs, &why)) return fail(RIBBIT_E_INTERNAL, "perfect events: %s", why.c_str());
     rb::perfect_calls_from_runs(runs.data(), runs.size(), length, sl.min_shift, calls);
     for (const RibbitCall &c : calls) rb::perfect_add(sl, c.start, c.end, c.mlen);
@@ -1248,7 +1254,7 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
     }
     std::vector<RibbitSeed> dispatch;
     if (n_anchored_calls || xa) {
-        std::vector<RibbitCall> ac(anchored_calls, anchored_calls + n_anchored_calls);
+        rb::CallVec ac(anchored_calls, anchored_calls + n_anchored_calls);
         replay_anchored_calls(sl, ac, length);
         rb::dispatch_order(sl, dispatch);
     }
@@ -1300,7 +1306,7 @@ int ribbit_hip_plane_bits(RibbitHandle *h, int32_t shift, int64_t start, int64_t
     if (h->loaded && h->anchored_calls_valid && h->host.has_xa(shift)) {
         // composed plane (fasta_utils.cpp:159): written by the anchored kernel, already on the host
         if (start < 0 || end > h->length || start > end) return fail(RIBBIT_E_ARG, "range [%lld,%lld) outside the record", (long long)start, (long long)end);
-        const uint32_t *w = h->host.xa.data() + (int64_t)(shift - h->host.xa_m_lo) * h->host.xa_stride;
+        const uint32_t *w = h->host.xa_words() + (int64_t)(shift - h->host.xa_m_lo) * h->host.xa_stride;
         for (int64_t p = start; p < end; ++p) out[p - start] = (w[p >> 5] >> (p & 31)) & 1u;
         return RIBBIT_OK;
     }

@@ -74,7 +74,7 @@ bool pair_perfect_runs_partial(const EventSource &src, int64_t own_lo, int64_t o
     return true;
 }
 
-void perfect_calls_from_runs(const RibbitRun *runs, size_t n_runs, int64_t length, int min_shift, std::vector<RibbitCall> &calls) {
+void perfect_calls_from_runs(const RibbitRun *runs, size_t n_runs, int64_t length, int min_shift, CallVec &calls) {
     calls.clear();
     const int32_t L = (int32_t)length;
     for (size_t i = 0; i < n_runs; ++i) {
@@ -92,7 +92,7 @@ void perfect_calls_from_runs(const RibbitRun *runs, size_t n_runs, int64_t lengt
     std::stable_sort(calls.begin(), calls.end(), call_order);
 }
 
-bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vector<RibbitCall> &calls, std::string *why, unsigned host_threads) {
+bool replay_window_events(const EventSource &src, const HostPlanes &hp, CallVec &calls, std::string *why, unsigned host_threads) {
     calls.clear();
     const size_t nm = src.nm;
     const int32_t m_lo = src.m_lo;
@@ -111,8 +111,13 @@ bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vec
     static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
-    struct Worker { std::vector<RibbitCall> calls; std::vector<size_t> cut; std::vector<RibbitCall> flush; std::string err; };
-    std::vector<Worker> work(threads);
+    // worker buffers live as long as the calling thread: a 250-Mbp chromosome's half gigabyte of calls is
+    // page-faulted in once, not once per record
+    struct Worker { CallVec calls; std::vector<size_t> cut; CallVec flush; std::string err; };
+    static thread_local std::vector<Worker> tl_work;
+    std::vector<Worker> &work = tl_work;      // the worker threads must see THIS thread's buffers, not their own
+    if (work.size() < threads) work.resize(threads);
+    for (unsigned w = 0; w < threads; ++w) { work[w].calls.clear(); work[w].flush.clear(); work[w].err.clear(); }
     auto phase1 = [&](unsigned w) {
         Worker &me = work[w];
         std::vector<size_t> mine;
@@ -152,8 +157,8 @@ bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vec
         phase1(0);
         for (std::thread &t : pool) t.join();
     }
-    for (const Worker &w : work)
-        if (!w.err.empty()) { if (why) *why = w.err; return false; }
+    for (unsigned w = 0; w < threads; ++w)
+        if (!work[w].err.empty()) { if (why) *why = work[w].err; return false; }
 
     const double t_phase1 = now();
     // Phase 2: a call generated while tile t was current has pos in [t*TILE, (t+1)*TILE + 7), i.e. it belongs to
@@ -162,29 +167,34 @@ bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vec
     const size_t nb = (size_t)ntile + 1;
     std::vector<size_t> bucket_n(nb + 1, 0);
     auto bucket_of = [&](const RibbitCall &c) { return (size_t)(c.pos / TILE); };
-    for (const Worker &w : work)
-        for (const RibbitCall &c : w.calls) {
+    for (unsigned wi = 0; wi < threads; ++wi)
+        for (const RibbitCall &c : work[wi].calls) {
             const size_t bk = bucket_of(c);
             if (bk >= nb) { if (why) *why = "call beyond the end of the record"; return false; }
             ++bucket_n[bk + 1];
         }
     for (size_t k = 0; k < nb; ++k) bucket_n[k + 1] += bucket_n[k];
+    size_t n_flush = 0;
+    for (unsigned wi = 0; wi < threads; ++wi) n_flush += work[wi].flush.size();
+    calls.reserve(bucket_n[nb] + n_flush);      // the flush is appended below: no second half-gigabyte move
     calls.resize(bucket_n[nb]);
     const double t_count = now();
     std::atomic<size_t> next{0};
     std::atomic<bool> bad{false};
     auto phase2 = [&]() {
-        std::vector<RibbitCall> batch, by_motif;
+        CallVec batch, by_motif;
         std::vector<uint32_t> count;
         for (size_t bk; (bk = next.fetch_add(1)) < nb;) {
             batch.clear();
             // bucket bk receives calls generated during tiles bk-1 and bk
-            for (const Worker &w : work)
+            for (unsigned wi = 0; wi < threads; ++wi) {
+                const Worker &w = work[wi];
                 for (int64_t t = (int64_t)bk - 1; t <= (int64_t)bk; ++t) {
                     if (t < 0 || t >= ntile) continue;
                     for (size_t i = w.cut[(size_t)t]; i < w.cut[(size_t)t + 1]; ++i)
                         if (bucket_of(w.calls[i]) == bk) batch.push_back(w.calls[i]);
                 }
+            }
             if (batch.size() != bucket_n[bk + 1] - bucket_n[bk]) { bad = true; return; }
             if (batch.empty()) continue;
             by_motif.resize(batch.size());
@@ -212,8 +222,8 @@ bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vec
                      threads, t_phase1 - t_begin, t_count - t_phase1, now() - t_count, calls.size());
 
     // the end-of-sequence flush comes last, in motif order
-    std::vector<RibbitCall> flush;
-    for (const Worker &w : work) flush.insert(flush.end(), w.flush.begin(), w.flush.end());
+    CallVec flush;
+    for (unsigned wi = 0; wi < threads; ++wi) flush.insert(flush.end(), work[wi].flush.begin(), work[wi].flush.end());
     std::stable_sort(flush.begin(), flush.end(), call_order);
     calls.insert(calls.end(), flush.begin(), flush.end());
     return true;

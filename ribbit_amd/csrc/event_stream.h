@@ -13,6 +13,7 @@
 
 #include "device_planes.h"
 #include "host_planes.h"
+#include "call_vec.h"
 #include "ribbit_hip.h"
 
 namespace rb {
@@ -54,11 +55,11 @@ bool pair_perfect_runs_partial(const EventSource &src, int64_t own_lo, int64_t o
                                std::vector<RibbitRun> &runs, std::vector<uint64_t> &halves, std::string *why);
 
 // parse_perfect_shiftxor.cpp:175-223: runs -> the addSeed calls the perfect scanner makes, in its order
-void perfect_calls_from_runs(const RibbitRun *runs, size_t n_runs, int64_t length, int min_shift, std::vector<RibbitCall> &calls);
+void perfect_calls_from_runs(const RibbitRun *runs, size_t n_runs, int64_t length, int min_shift, CallVec &calls);
 
 // Replay of the per-motif window state machines (window_fsm.h), tile by tile, producing the call list in the
 // reference's call order (scan position major, motif minor, end-of-sequence flush last) without a global
 // sort.  O(events + calls).
-bool replay_window_events(const EventSource &src, const HostPlanes &hp, std::vector<RibbitCall> &calls, std::string *why, unsigned host_threads = 0);
+bool replay_window_events(const EventSource &src, const HostPlanes &hp, CallVec &calls, std::string *why, unsigned host_threads = 0);
 
 }  // namespace rb

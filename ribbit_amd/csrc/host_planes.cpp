@@ -45,7 +45,7 @@ int HostPlanes::range_count(int shift, int start, int end) const {
 
 int HostPlanes::range_count_xa(int mlen, int start, int end) const {
     if (end <= start) return 0;
-    const uint32_t *w = xa.data() + (int64_t)(mlen - xa_m_lo) * xa_stride;
+    const uint32_t *w = xa_words() + (int64_t)(mlen - xa_m_lo) * xa_stride;
     int total = 0;
     const int64_t w0 = start >> 5, w1 = (end - 1) >> 5;
     for (int64_t i = w0; i <= w1; ++i) {

@@ -25,6 +25,8 @@ struct HostPlanes {
     // composed planes XA_m of the anchored stage (fasta_utils.cpp:143-161), motif-major, xa_stride
     // words per motif; written by the anchored kernel and copied back once
     std::vector<uint32_t> xa;
+    const uint32_t *xa_view = nullptr;     // when set: the planes live in memory the caller owns (page-locked D2H target)
+    const uint32_t *xa_words() const { return xa_view ? xa_view : xa.data(); }
     int64_t xa_stride = 0;
     int xa_m_lo = 0, xa_m_hi = -1;
 
@@ -32,7 +34,7 @@ struct HostPlanes {
         length = len;
         hi.assign(nwords, 0); lo.assign(nwords, 0); brk.assign(nwords, 0);
         blocked.clear();
-        xa.clear(); xa_stride = 0; xa_m_lo = 0; xa_m_hi = -1;
+        xa.clear(); xa_view = nullptr; xa_stride = 0; xa_m_lo = 0; xa_m_hi = -1;
     }
     bool has_xa(int mlen) const { return mlen >= xa_m_lo && mlen <= xa_m_hi; }
     // popcount of XA_mlen over [start, end)

@@ -11,6 +11,7 @@
 
 #include "device_planes.h"
 #include "host_planes.h"
+#include "call_vec.h"
 #include "ribbit_hip.h"
 
 namespace rb {
@@ -20,7 +21,7 @@ class WindowFsm {
     WindowFsm(const HostPlanes &planes, int32_t mlen) : hp_(&planes), mlen_(mlen) {}
 
     // calls are appended to *out (may be re-pointed between calls: the caller batches per tile)
-    void set_output(std::vector<RibbitCall> *out) { out_ = out; }
+    void set_output(CallVec *out) { out_ = out; }
 
     // feed one kernel event (window-start position, EV_* kind) in position order; false = malformed
     bool event(int64_t q, uint32_t kind);
@@ -44,7 +45,7 @@ class WindowFsm {
 
     const HostPlanes *hp_;
     int32_t mlen_;
-    std::vector<RibbitCall> *out_ = nullptr;
+    CallVec *out_ = nullptr;
     int64_t pend_start_ = -1, pend_end_ = -1;   // last_starts / last_ends
     int64_t cur_ = -1;                          // current_starts
     bool open_streak_ = false;                  // a START without its END yet
