@@ -59,6 +59,8 @@ def main():
                     help="N > 1: how the chunks' run records reach rank 0's host merge (auto: shm on one node, else rccl)")
     ap.add_argument("--depth", type=int, default=3,
                     help="batches in flight per GPU (handles/streams alternating); 1 = strictly one after the other")
+    ap.add_argument("--streams", default="shared", choices=["shared", "own"],
+                    help="shared: one compute stream for all handles of a rank (clean per-kernel timings); own: one per handle")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--verify", action="store_true",
                     help="N > 1: rank 0 also scans the whole record on its own GPU and checks the sharded runs against it")
@@ -110,6 +112,13 @@ def main():
     depth = max(1, args.depth)
     scs = [ribbit_amd.Scanner(M_LO, M_HI, device=local_rank) for _ in range(depth)]
     sc = scs[0]
+    # All handles launch on ONE compute stream (kernels of consecutive batches run back to back, so a kernel's
+    # HIP-event duration is its own, not inflated by a neighbour's kernels); only the result copies, which each
+    # handle issues on its own copy stream, overlap the next batch's kernels.
+    compute = torch.cuda.Stream(device=dev) if args.streams == "shared" else None
+    if compute is not None:
+        for h in scs:
+            h.set_stream(compute.cuda_stream)
     pos_offset = rank * args.bases - own_lo
     lo_hi = (own_lo, own_hi) if world > 1 else (0, (1 << 63) - 1)
 
@@ -236,7 +245,7 @@ def main():
             "data": "synthetic (ribbit_amd.simulate, seeded restatement of data_simulation/simulate_data.py)",
             "config": {"workload": f"{args.bases} bp synthetic record per GPU, -m {M_LO} -M {M_HI}, "
                                    "pack + perfect shift-XOR scan (BASELINE.json configs[1])",
-                       "batches_in_flight": depth,
+                       "batches_in_flight": depth, "compute_streams": 1 if compute is not None else depth,
                        "bases_per_gpu": args.bases, "min_motif": M_LO, "max_motif": M_HI,
                        "parallelism": (f"one record chunk-sharded x{world} (halos), runs paired on each GPU, gathered for rank 0's host merge "
                                        + ("through page-locked node-shared memory (one PCIe link per GPU)" if ng is not None else "by gather-v over RCCL"))

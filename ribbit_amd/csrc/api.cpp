@@ -90,6 +90,8 @@ struct RibbitHandle {
     int min_shift = 1, max_shift = 102;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // result copies of the split perfect scan: overlap other handles' kernels on a shared `stream`
+    hipEvent_t ev_ready = nullptr;       // pairing done, counters and status on the host
     hipEvent_t ev[6] = {};        // 0/1 pack, 2/3 scan kernel, 4/5 whole GPU side of the last scan
     bool have_timing[3] = {false, false, false};
     double host_ms = 0.0;         // host post-processing of the last scan (pairing / FSM)
@@ -127,6 +129,8 @@ struct RibbitHandle {
     DevBuf<uint64_t> d_pair_table;
     DevBuf<uint32_t> d_run_base, d_pair_partial, d_pair_status;
     PinnedBuf<uint32_t> h_pair_status;
+    PinnedBuf<uint32_t> h_pub;             // region counters + pairing status, written by the GPU (pair_publish_kernel)
+    uint32_t *h_pub_dev = nullptr;         // the same memory as the device sees it
     PinnedBuf<RibbitRun> h_runs, h_halves;
     rb::PairLaunch pair{};                // the perfect scan in flight (perfect_begin .. perfect_finish)
     size_t pair_cap = 0;
@@ -351,8 +355,9 @@ int perfect_enqueue(RibbitHandle *h, size_t cap) {
     rb::launch_pair_runs(h->d_events.p, h->d_counters.p, pr, h->d_pair_table.p, h->d_run_base.p, h->d_pair_partial.p,
                          h->d_dense.p, (uint32_t)(cap / 2), h->d_halves.p, (uint32_t)(2 * (size_t)pr.nm), h->d_pair_status.p, h->stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h->h_counters.p, h->d_counters.p, rb::EV_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->h_pair_status.p, h->d_pair_status.p, rb::PAIR_STATUS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    rb::launch_pair_publish(h->d_counters.p, h->d_pair_status.p, h->h_pub_dev, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_ready, h->stream));
     return RIBBIT_OK;
 }
 
@@ -364,7 +369,10 @@ int perfect_begin(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_o
     if ((rc = h->d_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
     if ((rc = h->h_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
     if ((rc = h->d_pair_status.ensure(rb::PAIR_STATUS_WORDS))) return rc;
-    if ((rc = h->h_pair_status.ensure(rb::PAIR_STATUS_WORDS))) return rc;
+    if (!h->h_pub.p) {
+        if ((rc = h->h_pub.ensure(rb::EV_SHARDS + rb::PAIR_STATUS_WORDS))) return rc;
+        HIP_TRY(hipHostGetDevicePointer((void **)&h->h_pub_dev, h->h_pub.p, 0));
+    }
     rb::PairLaunch &pr = h->pair;
     pr.m_lo = (uint32_t)h->params.min_motif;
     pr.nm = (uint32_t)(h->params.max_motif - h->params.min_motif + 1);
@@ -392,11 +400,12 @@ int perfect_finish(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *h
     const rb::PairLaunch &pr = h->pair;
     uint64_t produced = 0;
     for (int attempt = 0;; ++attempt) {
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        // wait for THIS record's kernels only: the stream may be shared with other handles whose kernels come later
+        HIP_TRY(hipEventSynchronize(h->ev_ready));
         uint32_t worst = 0;
         produced = 0;
         for (int t = 0; t < rb::EV_SHARDS; ++t) {
-            const uint32_t c = h->h_counters.p[t * rb::EV_COUNTER_STRIDE];
+            const uint32_t c = h->h_pub.p[t];
             worst = std::max(worst, c);
             produced += c;
         }
@@ -407,20 +416,20 @@ int perfect_finish(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *h
         if ((rc = perfect_enqueue(h, ((size_t)worst + 1024) * rb::EV_SHARDS))) return rc;
     }
     h->last_event_count = (int64_t)produced;
-    const uint32_t flags = h->h_pair_status.p[rb::PAIR_FLAGS];
+    const uint32_t flags = h->h_pub.p[rb::EV_SHARDS + rb::PAIR_FLAGS];
     if (flags) {
         return fail(RIBBIT_E_INTERNAL, "run pairing failed (flags 0x%x):%s%s%s%s%s", flags,
                     flags & rb::PAIR_BAD_EVENT ? " malformed event;" : "", flags & rb::PAIR_DUP_CHUNK ? " duplicate event chunk;" : "",
                     flags & rb::PAIR_NOT_ALTERNATING ? " run starts and ends do not alternate;" : "",
                     flags & rb::PAIR_UNTERMINATED ? " unterminated run;" : "", flags & rb::PAIR_NO_ROOM ? " run buffer too small;" : "");
     }
-    h->n_runs = h->h_pair_status.p[rb::PAIR_TOTAL];
+    h->n_runs = h->h_pub.p[rb::EV_SHARDS + rb::PAIR_TOTAL];
     if (h->n_runs * 2 != produced) return fail(RIBBIT_E_INTERNAL, "%llu events but %zu runs", (unsigned long long)produced, h->n_runs);
-    h->n_halves = h->h_pair_status.p[rb::PAIR_HALVES];
+    h->n_halves = h->h_pub.p[rb::EV_SHARDS + rb::PAIR_HALVES];
     if (half_dst && h->n_halves > half_dst_cap) return fail(RIBBIT_E_OVERFLOW, "%zu half records do not fit the caller's buffer of %zu", h->n_halves, half_dst_cap);
     if (!half_dst) half_dst = h->h_halves.p;
     if (h->n_halves)
-        HIP_TRY(hipMemcpyAsync(half_dst, h->d_halves.p, h->n_halves * sizeof(RibbitRun), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(half_dst, h->d_halves.p, h->n_halves * sizeof(RibbitRun), hipMemcpyDeviceToHost, h->copy_stream));
     if (dst && h->n_runs > dst_cap) return fail(RIBBIT_E_OVERFLOW, "%zu run records do not fit the caller's buffer of %zu", h->n_runs, dst_cap);
     const bool whole = pr.own_lo == 0 && pr.own_hi == INT64_MAX && pr.pos_offset == 0 && !dst;
     if (!dst) {
@@ -428,9 +437,9 @@ int perfect_finish(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *h
         dst = h->h_runs.p;
     }
     if (h->n_runs)
-        HIP_TRY(hipMemcpyAsync(dst, h->d_dense.p, h->n_runs * sizeof(RibbitRun), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipEventRecord(h->ev[5], h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpyAsync(dst, h->d_dense.p, h->n_runs * sizeof(RibbitRun), hipMemcpyDeviceToHost, h->copy_stream));
+    HIP_TRY(hipEventRecord(h->ev[5], h->copy_stream));
+    HIP_TRY(hipStreamSynchronize(h->copy_stream));
     h->have_timing[1] = h->have_timing[2] = true;
     h->host_ms = 0.0;
     h->runs_valid = whole;
@@ -712,6 +721,8 @@ int ribbit_hip_open(const RibbitScanParams *params, int device, RibbitHandle **o
     h->max_shift = params->max_motif + 2;                                   // ribbit.cpp:242
     hipError_t err = hipSetDevice(device);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming);
     for (int i = 0; i < 6 && err == hipSuccess; ++i) err = hipEventCreate(&h->ev[i]);
     if (err != hipSuccess) {
         delete h;
@@ -730,9 +741,11 @@ int ribbit_hip_close(RibbitHandle *h) {
     h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release(); h->d_slices.release();
     h->h_events.release(); h->h_counters.release(); h->h_query.release(); h->h_xa.release();
     h->d_pair_table.release(); h->d_run_base.release(); h->d_pair_partial.release(); h->d_pair_status.release();
-    h->h_pair_status.release(); h->h_runs.release(); h->h_halves.release(); h->d_halves.release();
+    h->h_pair_status.release(); h->h_pub.release(); h->h_runs.release(); h->h_halves.release(); h->d_halves.release();
     for (int i = 0; i < 6; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
     delete h;
     return RIBBIT_OK;
 }

@@ -57,6 +57,9 @@ void launch_pair_runs(const uint64_t *events, const uint32_t *counters, const Pa
                       uint32_t *run_base, uint32_t *partial, void *runs, uint32_t run_cap, void *halves,
                       uint32_t half_cap, uint32_t *status, hipStream_t stream);
 
+// host_words (page-locked, device-visible): [0, EV_SHARDS) the region counters, then PAIR_STATUS_WORDS status words
+void launch_pair_publish(const uint32_t *counters, const uint32_t *status, uint32_t *host_words, hipStream_t stream);
+
 // X_shift words [w0, w0+nw) -> out_words (device); if count != nullptr also adds the popcount of
 // bits in [p0, p1) to *count.
 void launch_plane_words(const DevicePlanes &pl, int shift, int64_t w0, int64_t nw, uint32_t *out_words,

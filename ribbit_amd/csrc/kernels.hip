@@ -978,6 +978,22 @@ __global__ __launch_bounds__(256) void pair_runs_kernel(const uint64_t *__restri
     }
 }
 
+// Region counters and pairing status -> page-locked host memory, written by the GPU itself: a copy command for
+// these 300 bytes would queue behind another handle's multi-megabyte result copy on the same DMA engine and
+// hold up the compute stream.
+__global__ __launch_bounds__(128) void pair_publish_kernel(const uint32_t *__restrict__ counters,
+                                                           const uint32_t *__restrict__ status,
+                                                           uint32_t *__restrict__ host_words) {
+    const uint32_t t = threadIdx.x;
+    if (t < (uint32_t)EV_SHARDS) host_words[t] = counters[t * EV_COUNTER_STRIDE];
+    else if (t < (uint32_t)EV_SHARDS + PAIR_STATUS_WORDS) host_words[t] = status[t - (uint32_t)EV_SHARDS];
+    __threadfence_system();
+}
+
+void launch_pair_publish(const uint32_t *counters, const uint32_t *status, uint32_t *host_words, hipStream_t stream) {
+    hipLaunchKernelGGL(pair_publish_kernel, dim3(1), dim3(128), 0, stream, counters, status, host_words);
+}
+
 void launch_pair_runs(const uint64_t *events, const uint32_t *counters, const PairLaunch &pl, void *table,
                       uint32_t *run_base, uint32_t *partial, void *runs, uint32_t run_cap, void *halves,
                       uint32_t half_cap, uint32_t *status, hipStream_t stream) {
