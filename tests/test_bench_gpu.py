@@ -1,0 +1,51 @@
+"""GPU test of bench.py's output contract on a small workload: one JSON line with the fields the driver and the
+judge read (metric/value/unit/..., roofline with bound/achieved/peak/frac/traffic, cpu_baseline with
+value/unit/cores/kind/sample), and a chunk-sharded 2-rank run on one GPU verified against the unsharded scan."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contracted_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--bases", "3000000"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "Gbases/s" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 3e6 * 3 / (d["ms_per_step"] * 3e-3) / 1e9) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "traffic" in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel_ms"] > 0
+    assert abs(rf["achieved"] - 3e6 * 0.375 / (rf["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Gbases/s" and cb["value"] > 0 and cb["sample"]
+    assert d["value"] > cb["value"]
+
+
+@pytest.mark.parametrize("exchange", ["shm", "rccl"])
+def test_two_ranks_on_one_gpu_reproduce_the_unsharded_runs(exchange):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533" if exchange == "shm" else "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--bases", "2000000", "--backend", "gloo", "--single-device", "--verify", "--exchange", exchange]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and "cpu_baseline" not in d and "identical to the single-GPU scan" in r.stderr
+    assert ("node-shared" in d["config"]["parallelism"]) == (exchange == "shm")
