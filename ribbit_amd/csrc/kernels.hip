@@ -187,16 +187,67 @@ constexpr int LDS_EXTRA = 40;   // halo + shifted-operand words (supports shifts
 //   END   = Z[p]  & ~D[p-sp]               run of >= sp zeros ends just before p
 // Every qualifying run yields exactly one START and one END (position L for an open run,
 // because brk is 1 from L on), so the host pairs them without any device-side walk.
-__global__ __launch_bounds__(256) void scan_perfect_kernel(DevicePlanes pl, PerfectLaunch pp, int motifs_per_block,
+// D = OR of Z over [p, p+sp) by funnel doubling (spans 2, 4, 4+t3, 4+t3+t4, 4+t3+t4+t5 = sp), then
+// START = Z[p-1] & ~D[p] and END = Z[p] & ~D[p-sp] on the own words.  The shift amounts may differ from lane to
+// lane (queued candidates of several motifs, see scan_perfect_kernel); a zero amount makes its step a no-op.
+template <bool UNIFORM>
+__device__ __forceinline__ uint32_t perfect_edges(const uint32_t (&Z)[K + 2], uint32_t t3, uint32_t t4, uint32_t t5,
+                                                  uint32_t back, uint32_t (&SQ)[K], uint32_t (&EQ)[K]) {
+    uint32_t D[K + 2];
+#pragma unroll
+    for (int j = 0; j < K + 1; j++) D[j] = Z[j] | funnel(Z[j + 1], Z[j], 1);
+    D[K + 1] = Z[K + 1] | (Z[K + 1] >> 1);
+#pragma unroll
+    for (int j = 0; j < K + 1; j++) D[j] = D[j] | funnel(D[j + 1], D[j], 2);
+    D[K + 1] = D[K + 1] | (D[K + 1] >> 2);
+#pragma unroll
+    for (int j = 0; j < K + 1; j++) D[j] = D[j] | funnel(D[j + 1], D[j], t3);
+    D[K + 1] = D[K + 1] | (D[K + 1] >> t3);
+#pragma unroll
+    for (int j = 0; j < K + 1; j++) D[j] = D[j] | funnel(D[j + 1], D[j], t4);
+    if (!UNIFORM || t5) {   // uniform case: only motifs with a cut-off above 16 need the fifth step
+        D[K + 1] = D[K + 1] | (D[K + 1] >> t4);
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) D[j] = D[j] | funnel(D[j + 1], D[j], t5);
+    }
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int j = k + 1;
+        const uint32_t prev_z = funnel(Z[j], Z[j - 1], 31);      // bit b = Z at position b-1
+        const uint32_t d_back = funnel(D[j], D[j - 1], back);    // bit b = D at position b-sp
+        SQ[k] = prev_z & ~D[j];
+        EQ[k] = Z[j] & ~d_back;
+        any |= SQ[k] | EQ[k];
+    }
+    return any;
+}
+
+// per-wave queue of candidate lanes (LDS): the Z window of a lane whose prefilter fired, and which motif it is of
+constexpr int CAND_CAP = 64;          // one wavefront's worth
+#ifndef RB_CAND_DIRECT
+#define RB_CAND_DIRECT 32
+#endif
+constexpr int CAND_DIRECT = RB_CAND_DIRECT;   // a (tile, motif) pair with more candidate lanes than this is scanned in place
+struct CandQueue {
+    uint32_t z[K + 2][CAND_CAP];      // word-major: lane i of a flush reads z[w][i] (conflict free)
+    uint32_t tag[CAND_CAP];           // source lane | motif << 8
+};
+
+#ifndef RB_PERFECT_WAVES
+#define RB_PERFECT_WAVES 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_PERFECT_WAVES, RB_PERFECT_WAVES))) void scan_perfect_kernel(DevicePlanes pl, PerfectLaunch pp, int motifs_per_block,
                                                            uint64_t *__restrict__ events,
                                                            uint32_t *__restrict__ counters) {
     __shared__ uint32_t s_hi[TILE_WORDS + LDS_EXTRA];
     __shared__ uint32_t s_lo[TILE_WORDS + LDS_EXTRA];
     __shared__ uint32_t s_brk[TILE_WORDS + 8];
     __shared__ uint64_t s_stage[4][EV_STAGE];
+    __shared__ CandQueue s_cand[4];
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform on purpose: keeps the motif loop scalar
     const int64_t tile_base = (int64_t)blockIdx.x * TILE_WORDS;   // first word owned by this block
 
     const int bm_lo = pp.m_lo + (int)blockIdx.y * motifs_per_block;
@@ -237,6 +288,45 @@ __global__ __launch_bounds__(256) void scan_perfect_kernel(DevicePlanes pl, Perf
     volatile uint64_t *stage = s_stage[wave];
     int staged = 0;   // wave-uniform
 
+    // Candidate queue.  The doubling chain below is ~2/3 of the VALU work, yet where the prefilter fires it does
+    // so in 2-3 of the 64 lanes (a repeat locus is a few hundred bases of a 16-kb tile; 49 % of the large-motif
+    // (tile, motif) pairs of the synthetic FASTA have such a lane).  Instead of running the chain on the whole
+    // wave for them, the few candidate lanes park their Z window in LDS; once a wavefront's worth has collected
+    // -- over several motifs -- the chain runs once, every lane on a different (source lane, motif) with its own
+    // shift amounts.  A pair's candidates are never split over two flushes, so its events still form one chunk.
+    CandQueue &cq = s_cand[wave];
+    int queued = 0;   // wave-uniform
+    auto flush_candidates = [&]() {
+        if (queued == 0) return;
+        const bool live = lane < queued;
+        const uint32_t tag = live ? cq.tag[lane] : 0u;
+        const uint32_t src = tag & 0xffu, qm = tag >> 8;
+        uint32_t Zq[K + 2];
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) Zq[j] = live ? cq.z[j][lane] : 0xffffffffu;
+        const int c1 = (qm <= 6u) ? 12 - (int)qm : (int)qm;
+        const int sp = live ? min(c1, 32) : 32;
+        const uint32_t t3 = (uint32_t)min(4, sp - 4);
+        const uint32_t t4 = (uint32_t)min(8, sp - 4 - (int)t3);
+        const uint32_t t5 = (uint32_t)(sp - 4) - t3 - t4;
+        uint32_t SQ[K], EQ[K];
+        uint32_t any = perfect_edges<false>(Zq, t3, t4, t5, 32u - (uint32_t)sp, SQ, EQ);
+        if (!live) {
+            any = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++) { SQ[k] = 0; EQ[k] = 0; }
+        }
+        if (__ballot(any != 0) != 0ull) {
+            const uint32_t src_word0 = (uint32_t)tile_base + src * (uint32_t)K;
+            stage_events(SQ, EQ, src_word0, qm, sink, stage, staged, lane, [&](int k, uint32_t b, uint32_t pos) {
+                if (pos >= length) return (uint32_t)EV_END_EOS;
+                return ((s_brk[src * (uint32_t)K + (uint32_t)k + 1u] >> b) & 1u) ? (uint32_t)EV_END_N : (uint32_t)EV_END_ZERO;
+            });
+        }
+        queued = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+
     for (int m = wm_lo; m <= wm_hi; m += 4) {
         const int q = m >> 5;
         const uint32_t r = (uint32_t)m & 31u;
@@ -252,55 +342,44 @@ __global__ __launch_bounds__(256) void scan_perfect_kernel(DevicePlanes pl, Perf
         const uint32_t t5 = (uint32_t)(sp - 4) - t3 - t4;
 
         // Z = mismatch | break, words k = -1 .. K
-        uint32_t Z[K + 2], D[K + 2];
+        uint32_t Z[K + 2];
 #pragma unroll
         for (int j = 0; j < K + 2; j++) {
             const uint32_t hs = funnel(Hq[j + 1], Hq[j], r);
             const uint32_t ls = funnel(Lq[j + 1], Lq[j], r);
             Z[j] = ((H[j] ^ hs) | (Lo[j] ^ ls)) | Bk[j];
         }
-        // Cheap necessary condition before the doubling chain (which is ~2/3 of this loop's VALU ops):
-        // a run of >= 15 zeros covers an aligned byte completely, a run of >= 31 an aligned halfword.
-        // On random DNA 96 % of the (tile, motif) pairs with sp >= 15 have no all-zero byte at all.
-        if (sp >= 15) {
-            const uint32_t ones = sp >= 31 ? 0x00010001u : 0x01010101u;
-            const uint32_t tops = sp >= 31 ? 0x80008000u : 0x80808080u;
+        // Cheap necessary condition for a lane to hold a START or END of this motif: the first / last sp positions
+        // of a run lie inside the lane's 10-word window, and sp >= 7 consecutive zeros cover an aligned nibble,
+        // >= 15 an aligned byte, >= 31 an aligned halfword.  (On random DNA 96 % of the (tile, motif) pairs with
+        // sp >= 15 have no such lane at all.)  sp = 6 (motif 6 only) has no such test and is scanned in place.
+        if (sp >= 7) {
+            const uint32_t ones = sp >= 31 ? 0x00010001u : sp >= 15 ? 0x01010101u : 0x11111111u;
+            const uint32_t tops = sp >= 31 ? 0x80008000u : sp >= 15 ? 0x80808080u : 0x88888888u;
             uint32_t hit = 0;
 #pragma unroll
             for (int j = 0; j < K + 2; j++) hit |= (Z[j] - ones) & ~Z[j];
-            if (__ballot((hit & tops) != 0) == 0ull) continue;
+            const bool cand = (hit & tops) != 0;
+            const unsigned long long mask = __ballot(cand);
+            if (mask == 0ull) continue;
+            const int n = __popcll(mask);
+            if (n <= CAND_DIRECT) {
+                if (queued + n > CAND_CAP) flush_candidates();
+                if (cand) {
+                    const int slot = queued + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+#pragma unroll
+                    for (int j = 0; j < K + 2; j++) cq.z[j][slot] = Z[j];
+                    cq.tag[slot] = (uint32_t)lane | ((uint32_t)m << 8);
+                }
+                queued += n;
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
         }
-        // OR-doubling towards higher positions: spans 2, 4, 4+t3, 4+t3+t4, 4+t3+t4+t5 = sp
-#pragma unroll
-        for (int j = 0; j < K + 1; j++) D[j] = Z[j] | funnel(Z[j + 1], Z[j], 1);
-        D[K + 1] = Z[K + 1] | (Z[K + 1] >> 1);
-#pragma unroll
-        for (int j = 0; j < K + 1; j++) D[j] = D[j] | funnel(D[j + 1], D[j], 2);
-        D[K + 1] = D[K + 1] | (D[K + 1] >> 2);
-#pragma unroll
-        for (int j = 0; j < K + 1; j++) D[j] = D[j] | funnel(D[j + 1], D[j], t3);
-        D[K + 1] = D[K + 1] | (D[K + 1] >> t3);
-#pragma unroll
-        for (int j = 0; j < K + 1; j++) D[j] = D[j] | funnel(D[j + 1], D[j], t4);
-        if (t5) {   // wave-uniform: only motifs with a cut-off above 16
-            D[K + 1] = D[K + 1] | (D[K + 1] >> t4);
-#pragma unroll
-            for (int j = 0; j < K + 1; j++) D[j] = D[j] | funnel(D[j + 1], D[j], t5);
-        }
-
+        // dense pair: scan the whole wave in place (its events are staged now, those of parked candidates later:
+        // either way a (tile, motif) pair's events stay in one piece)
         uint32_t SQ[K], EQ[K];
-        uint32_t any = 0;
-        const uint32_t back = 32u - (uint32_t)sp;
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            const int j = k + 1;
-            const uint32_t prev_z = funnel(Z[j], Z[j - 1], 31);      // bit b = Z at position b-1
-            const uint32_t d_back = funnel(D[j], D[j - 1], back);    // bit b = D at position b-sp
-            SQ[k] = prev_z & ~D[j];
-            EQ[k] = Z[j] & ~d_back;
-            any |= SQ[k] | EQ[k];
-        }
-
+        const uint32_t any = perfect_edges<true>(Z, t3, t4, t5, 32u - (uint32_t)sp, SQ, EQ);
         if (__ballot(any != 0) != 0ull) {
             stage_events(SQ, EQ, word0, (uint32_t)m, sink, stage, staged, lane, [&](int k, uint32_t b, uint32_t pos) {
                 if (pos >= length) return (uint32_t)EV_END_EOS;
@@ -308,6 +387,7 @@ __global__ __launch_bounds__(256) void scan_perfect_kernel(DevicePlanes pl, Perf
             });
         }
     }
+    flush_candidates();
     sink_flush(sink, stage, staged, lane);
 }
 
@@ -348,7 +428,7 @@ __global__ __launch_bounds__(256) void scan_window_kernel(DevicePlanes pl, Perfe
     __shared__ uint64_t s_stage[4][EV_STAGE];
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform on purpose: keeps the motif loop scalar
     const int64_t tile_base = (int64_t)blockIdx.x * TILE_WORDS;
 
     const int bm_lo = pp.m_lo + (int)blockIdx.y * motifs_per_block;
@@ -508,7 +588,7 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
     __shared__ uint64_t s_stage[4][EV_STAGE];
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform on purpose: keeps the motif loop scalar
     const int64_t tile_base = (int64_t)blockIdx.x * anchored_tile_words(hl);   // first OWN word (lane hl, k = 0)
     const int64_t first = tile_base - (int64_t)hl * K - 1;                     // word held at LDS index 0
 
