@@ -25,6 +25,13 @@ __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh
     return __builtin_amdgcn_alignbit(hi, lo, sh);
 }
 
+// v_bitop3_b32: any boolean function of three words in one full-rate instruction.  TT = the function applied to
+// the constants 0xF0, 0xCC, 0xAA in place of a, b, c (e.g. (a ^ b) | c  ->  (0xF0 ^ 0xCC) | 0xAA = 0xBE).
+template <unsigned TT>
+__device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+}
+
 // ---------------------------------------------------------------------------------- pack
 // fasta_utils.cpp:90-115: A/a 00, C/c 01, G/g 10, T/t 11, anything else -> N (code 00).
 // One thread produces one 32-base word of each plane.
@@ -218,7 +225,7 @@ __device__ __forceinline__ uint32_t perfect_edges(const uint32_t (&Z)[K + 2], ui
         const uint32_t d_back = funnel(D[j], D[j - 1], back);    // bit b = D at position b-sp
         SQ[k] = prev_z & ~D[j];
         EQ[k] = Z[j] & ~d_back;
-        any |= SQ[k] | EQ[k];
+        any = bitop3<0xFE>(SQ[k], EQ[k], any);
     }
     return any;
 }
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_PERFECT_
         for (int j = 0; j < K + 2; j++) {
             const uint32_t hs = funnel(Hq[j + 1], Hq[j], r);
             const uint32_t ls = funnel(Lq[j + 1], Lq[j], r);
-            Z[j] = ((H[j] ^ hs) | (Lo[j] ^ ls)) | Bk[j];
+            Z[j] = bitop3<0xF6>(bitop3<0xBE>(H[j], hs, Bk[j]), Lo[j], ls);      // ((H ^ hs) | Bk) | (Lo ^ ls)
         }
         // Cheap necessary condition for a lane to hold a START or END of this motif: the first / last sp positions
         // of a run lie inside the lane's 10-word window, and sp >= 7 consecutive zeros cover an aligned nibble,
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_PERFECT_
             const uint32_t tops = sp >= 31 ? 0x80008000u : sp >= 15 ? 0x80808080u : 0x88888888u;
             uint32_t hit = 0;
 #pragma unroll
-            for (int j = 0; j < K + 2; j++) hit |= (Z[j] - ones) & ~Z[j];
+            for (int j = 0; j < K + 2; j++) hit = bitop3<0xBA>(Z[j] - ones, Z[j], hit);      // ((Z - ones) & ~Z) | hit
             const bool cand = (hit & tops) != 0;
             const unsigned long long mask = __ballot(cand);
             if (mask == 0ull) continue;
