@@ -28,7 +28,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 WORKLOAD_BASES = 100_000_000
 M_LO, M_HI = 2, 100
 ALGO_BYTES_PER_BASE = 0.375      # 2 code bits + 1 N bit per base read by the scan kernel
-ALIGNBIT_SHARE = 81 / 190        # v_alignbit_b32 among the VALU instructions of scan_perfect_kernel's hot loop
+ALIGNBIT_SHARE = 0.31            # v_alignbit_b32 among the executed VALU instructions of scan_perfect_kernel (from its ISA: 20 of
+                                 # ~66 per motif in the filter pass, 61 of ~175 in a run of the doubling chain)
 ALIGNBIT_RATE = 550e9            # wave-instr/s chip-wide at 4 waves/SIMD (profiles/r01b_valu_peak_probe.txt)
 PLAIN_VALU_RATE = 930e9          # v_or / v_xor / v_bitop3, same probe
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -147,24 +148,33 @@ def main():
         h.load_record_device(d_ascii.data_ptr(), d_ascii.numel())
         h.scan_perfect_begin(lo_hi[0], lo_hi[1], pos_offset if world > 1 else 0)
 
-    def complete(k):
+    def collect(k):
+        """batch k's kernels are done: start copying its run records down (no waiting); -> what finish() needs"""
+        h = scs[k % depth]
+        if world == 1 or ng is None:
+            return h.scan_perfect_end(wait=False)
+        if rank == 0 and k > 1:
+            ng.release(k - 1)                             # the previous batch's views are dead from here on
+        ng.wait_free(k)
+        rec, hv = ng.mine(k)
+        n, nh = h.scan_perfect_end(out=rec, halves_out=hv, wait=False)
+        return rec, n, nh
+
+    def finish(k, pending):
         """batch k's run records on the host (rank 0: of every rank)"""
         h = scs[k % depth]
+        h.scan_perfect_wait()
         if world == 1:
-            return h.scan_perfect_end()[0]               # view of the C ABI's own pinned result buffer
+            return pending[0]                             # view of the C ABI's own pinned result buffer
         if ng is not None:
-            if rank == 0 and k > 1:
-                ng.release(k - 1)                         # the previous batch's views are dead from here on
-            ng.wait_free(k)
-            rec, hv = ng.mine(k)
-            n, nh = h.scan_perfect_end(out=rec, halves_out=hv)
+            rec, n, nh = pending
             ng.publish(k, n, nh)
             if rank != 0:
                 return [rec[:n]]
             parts, halves = ng.collect(k)
             # the record's runs: every chunk's records in place (term < 0 = place holder) + the runs cut by chunk edges
             return parts + [ribbit_amd.join_run_halves(halves)]
-        runs, halves = h.scan_perfect_end()
+        runs, halves = pending
         all_runs = gather_array(runs, xdev)
         all_halves = gather_array(halves, xdev)
         if rank == 0:
@@ -176,11 +186,17 @@ def main():
     def run_steps(n, on_step=None):
         first, last = batch[0] + 1, batch[0] + n
         issued, out = first - 1, None
+        for k in range(first, min(first + depth - 2, last) + 1):     # prologue: depth - 1 batches in flight
+            issued += 1
+            issue(issued)
         for k in range(first, last + 1):
-            while issued < min(k + depth - 1, last):      # keep `depth` batches in flight
+            pending = collect(k) if issued >= k else None
+            if issued < last:                             # next batch's kernels are enqueued while k's results cross PCIe
                 issued += 1
                 issue(issued)
-            out = complete(k)
+            if pending is None:
+                pending = collect(k)
+            out = finish(k, pending)
             if on_step:
                 on_step(scs[k % depth], out)
         batch[0] = last

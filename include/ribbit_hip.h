@@ -339,8 +339,12 @@ int ribbit_hip_scan_perfect_chunk(RibbitHandle *h, int64_t own_lo, int64_t own_h
  * kernels run while the previous record's runs cross PCIe -- the double-buffered streaming of a multi-record
  * FASTA (ribbit.cpp:269-280 is the loop being pipelined).  A whole record: own_lo 0, own_hi INT64_MAX, offset 0. */
 int ribbit_hip_scan_perfect_begin(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset);
+/* wait != 0: the records are in place when the call returns.  wait == 0: the counts are final but the records are
+ * still being copied; ribbit_hip_scan_perfect_wait (or the next _begin on the handle) completes the copy -- lets the
+ * caller enqueue the next record's kernels while this one's results cross PCIe. */
 int ribbit_hip_scan_perfect_end(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *half_dst, size_t half_dst_cap,
-                                const RibbitRun **out, size_t *n, const RibbitRun **halves, size_t *n_halves);
+                                int wait, const RibbitRun **out, size_t *n, const RibbitRun **halves, size_t *n_halves);
+int ribbit_hip_scan_perfect_wait(RibbitHandle *h);
 
 /* Worker threads the host-side stages of this handle may use (window state machines, refinement);
  * 0 = default (environment RIBBIT_THREADS, else min(cores, 16)).  A caller that keeps several handles busy at

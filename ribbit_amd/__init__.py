@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_stage_events", "ribbit_hip_xa_words", "ribbit_host_scan_from_events",
     "ribbit_host_perfect_runs_from_events", "ribbit_runs_free", "ribbit_hip_perfect_runs_partial",
     "ribbit_hip_scan_perfect_chunk", "ribbit_hip_host_register", "ribbit_hip_host_unregister",
-    "ribbit_hip_set_host_threads", "ribbit_hip_scan_perfect_begin", "ribbit_hip_scan_perfect_end",
+    "ribbit_hip_set_host_threads", "ribbit_hip_scan_perfect_begin", "ribbit_hip_scan_perfect_end", "ribbit_hip_scan_perfect_wait",
 ]
 
 
@@ -148,8 +148,9 @@ def load_library():
     L.ribbit_hip_host_unregister.argtypes = [vp]
     L.ribbit_hip_set_host_threads.argtypes = [vp, i32]
     L.ribbit_hip_scan_perfect_begin.argtypes = [vp, i64, i64, i64]
-    L.ribbit_hip_scan_perfect_end.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t,
+    L.ribbit_hip_scan_perfect_end.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int,
                                               C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ribbit_hip_scan_perfect_wait.argtypes = [vp]
     L.ribbit_host_scan_from_events.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t,
                                                vp, vp, vp, vp, vp, vp, C.POINTER(SeedLists)]
     L.ribbit_host_perfect_runs_from_events.argtypes = [C.POINTER(ScanParams), C.c_size_t, vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -556,16 +557,23 @@ class Scanner:
         """Enqueue the perfect scan of the loaded record (or of one chunk of it) and return without waiting."""
         self._check(self._L.ribbit_hip_scan_perfect_begin(self._h, own_lo, own_hi, pos_offset))
 
-    def scan_perfect_end(self, out: np.ndarray | None = None, halves_out: np.ndarray | None = None):
-        """Finish the scan begun by scan_perfect_begin; returns like scan_perfect_chunk."""
+    def scan_perfect_wait(self) -> None:
+        self._check(self._L.ribbit_hip_scan_perfect_wait(self._h))
+
+    def scan_perfect_end(self, out: np.ndarray | None = None, halves_out: np.ndarray | None = None, wait: bool = True):
+        """Finish the scan begun by scan_perfect_begin; returns like scan_perfect_chunk.  wait=False: the records
+        (and halves) are still in flight until scan_perfect_wait(); halves are then returned as a view, not a copy."""
         p, n, hp, nh = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
         if out is not None:
             assert out.dtype == RUN_DT and out.flags.c_contiguous and halves_out is not None and halves_out.dtype == RUN_DT
             self._check(self._L.ribbit_hip_scan_perfect_end(self._h, out.ctypes.data, len(out), halves_out.ctypes.data, len(halves_out),
-                                                            C.byref(p), C.byref(n), C.byref(hp), C.byref(nh)))
+                                                            int(wait), C.byref(p), C.byref(n), C.byref(hp), C.byref(nh)))
             return n.value, nh.value
-        self._check(self._L.ribbit_hip_scan_perfect_end(self._h, None, 0, None, 0, C.byref(p), C.byref(n), C.byref(hp), C.byref(nh)))
-        halves = _copy(hp.value, nh.value, RUN_DT)
+        self._check(self._L.ribbit_hip_scan_perfect_end(self._h, None, 0, None, 0, int(wait), C.byref(p), C.byref(n), C.byref(hp), C.byref(nh)))
+        if wait or nh.value == 0:
+            halves = _copy(hp.value, nh.value, RUN_DT)
+        else:
+            halves = np.frombuffer((C.c_char * (nh.value * RUN_DT.itemsize)).from_address(hp.value), dtype=RUN_DT)
         if n.value == 0:
             return np.zeros(0, RUN_DT), halves
         view = np.frombuffer((C.c_char * (n.value * RUN_DT.itemsize)).from_address(p.value), dtype=RUN_DT)

@@ -90,7 +90,8 @@ struct RibbitHandle {
     int min_shift = 1, max_shift = 102;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;   // result copies of the split perfect scan: overlap other handles' kernels on a shared `stream`
+    hipStream_t copy_stream = nullptr;   // post stream of the perfect scan: pairing kernels and result copies, so that they overlap
+                                         // the next record's kernels when several handles share `stream`
     hipEvent_t ev_ready = nullptr;       // pairing done, counters and status on the host
     hipEvent_t ev[6] = {};        // 0/1 pack, 2/3 scan kernel, 4/5 whole GPU side of the last scan
     bool have_timing[3] = {false, false, false};
@@ -135,6 +136,7 @@ struct RibbitHandle {
     rb::PairLaunch pair{};                // the perfect scan in flight (perfect_begin .. perfect_finish)
     size_t pair_cap = 0;
     bool pair_pending = false;
+    bool copy_pending = false;            // result copies enqueued but not yet waited for (ribbit_hip_scan_perfect_end with wait = 0)
     DevBuf<RibbitRun> d_halves;
     size_t n_runs = 0, n_halves = 0;
     rb::CallVec perfect_calls;
@@ -328,6 +330,15 @@ rb::EventSource event_source(const RibbitHandle *h) {
 // Perfect stage on the device end to end: scan kernel -> START/END events (left in their regions, never
 // copied to the host) -> pairing kernels -> RibbitRun records ordered by (motif, start) -> one D2H copy
 // into pinned memory.  The host only checks the counters and the pairing status.
+int perfect_wait(RibbitHandle *h) {
+    if (!h->copy_pending) return RIBBIT_OK;
+    h->copy_pending = false;
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->copy_stream));
+    return RIBBIT_OK;
+}
+
 // The perfect stage in two halves, so that a caller with several handles can keep one record's kernels running
 // while another record's results travel to the host (each handle has its own stream):
 //   perfect_enqueue: memset + scan + pairing kernels + D2H of counters and status, no synchronisation;
@@ -352,17 +363,22 @@ int perfect_enqueue(RibbitHandle *h, size_t cap) {
     rb::launch_scan_perfect(h->planes(), pp, h->d_events.p, h->d_counters.p, h->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    // Everything after the scan (nine small, latency-bound launches, later the result copy) runs on the handle's
+    // own post stream: on a compute stream shared by several handles the next record's pack and scan start right
+    // behind this scan instead of waiting out the pairing chain's launch gaps.
+    HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->ev[3], 0));
     rb::launch_pair_runs(h->d_events.p, h->d_counters.p, pr, h->d_pair_table.p, h->d_run_base.p, h->d_pair_partial.p,
-                         h->d_dense.p, (uint32_t)(cap / 2), h->d_halves.p, (uint32_t)(2 * (size_t)pr.nm), h->d_pair_status.p, h->stream);
+                         h->d_dense.p, (uint32_t)(cap / 2), h->d_halves.p, (uint32_t)(2 * (size_t)pr.nm), h->d_pair_status.p, h->copy_stream);
     HIP_TRY(hipGetLastError());
-    rb::launch_pair_publish(h->d_counters.p, h->d_pair_status.p, h->h_pub_dev, h->stream);
+    rb::launch_pair_publish(h->d_counters.p, h->d_pair_status.p, h->h_pub_dev, h->copy_stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(h->ev_ready, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_ready, h->copy_stream));
     return RIBBIT_OK;
 }
 
 int perfect_begin(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset) {
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    if (h->copy_pending) { int rcw = perfect_wait(h); if (rcw) return rcw; }
     h->runs_valid = h->calls_valid = false;
     h->pair_pending = false;
     int rc;
@@ -392,7 +408,7 @@ int perfect_begin(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_o
     return RIBBIT_OK;
 }
 
-int perfect_finish(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *half_dst, size_t half_dst_cap) {
+int perfect_finish(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *half_dst, size_t half_dst_cap, bool wait = true) {
     if (!h->pair_pending) return fail(RIBBIT_E_STATE, "no perfect scan in flight on this handle");
     h->pair_pending = false;
     int rc;
@@ -439,11 +455,11 @@ int perfect_finish(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *h
     if (h->n_runs)
         HIP_TRY(hipMemcpyAsync(dst, h->d_dense.p, h->n_runs * sizeof(RibbitRun), hipMemcpyDeviceToHost, h->copy_stream));
     HIP_TRY(hipEventRecord(h->ev[5], h->copy_stream));
-    HIP_TRY(hipStreamSynchronize(h->copy_stream));
     h->have_timing[1] = h->have_timing[2] = true;
     h->host_ms = 0.0;
     h->runs_valid = whole;
-    return RIBBIT_OK;
+    h->copy_pending = true;
+    return wait ? perfect_wait(h) : RIBBIT_OK;
 }
 
 int run_perfect_scan_range(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset, RibbitRun *dst, size_t dst_cap,
@@ -1086,10 +1102,15 @@ int ribbit_hip_scan_perfect_begin(RibbitHandle *h, int64_t own_lo, int64_t own_h
     return perfect_begin(h, own_lo, own_hi, pos_offset);
 }
 
+int ribbit_hip_scan_perfect_wait(RibbitHandle *h) {
+    if (!h) return fail(RIBBIT_E_ARG, "null argument");
+    return perfect_wait(h);
+}
+
 int ribbit_hip_scan_perfect_end(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *half_dst, size_t half_dst_cap,
-                                const RibbitRun **out, size_t *n, const RibbitRun **halves, size_t *n_halves) {
+                                int wait, const RibbitRun **out, size_t *n, const RibbitRun **halves, size_t *n_halves) {
     if (!h || !out || !n) return fail(RIBBIT_E_ARG, "null argument");
-    int rc = perfect_finish(h, dst, dst_cap, half_dst, half_dst_cap);
+    int rc = perfect_finish(h, dst, dst_cap, half_dst, half_dst_cap, wait != 0);
     if (rc) return rc;
     *out = dst ? dst : h->h_runs.p;
     *n = h->n_runs;
