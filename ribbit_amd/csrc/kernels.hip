@@ -64,16 +64,31 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
                 w[i] = x;
             }
         }
+        // Four bases per 32-bit word, all byte lanes at once (fasta_utils.cpp:94-114: A 00, C 01, G 10, T 11, any
+        // case; everything else is N).  With b1, b2 = bits 1 and 2 of the character: code = (b2, b1 ^ b2).  The
+        // character is valid iff, lower-cased, it equals 'a' + 2*(lo|hi) + 4*hi + 13*(lo&hi) -- 'a','c','g','t'.
+        // v_dot4_u32_u8 with weights 1,2,4,8 then gathers the four flag bytes of a word into a nibble.
         b = 0;
 #pragma unroll
-        for (int i = 0; i < 32; i++) {
-            const uint32_t c = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
-            const uint32_t u = c | 0x20u;
-            const uint32_t valid = (u == 'a') | (u == 'c') | (u == 'g') | (u == 't');
-            const uint32_t code = ((c >> 1) & 3u) ^ ((c >> 2) & 1u);   // a 0, c 1, g 2, t 3
-            h |= (valid & (code >> 1)) << i;
-            l |= (valid & code & 1u) << i;
-            b |= (valid ^ 1u) << i;
+        for (int i = 0; i < 8; i++) {
+            const uint32_t x = w[i];
+            const uint32_t b2 = (x >> 2) & 0x01010101u;
+            const uint32_t lo1 = ((x >> 1) & 0x01010101u) ^ b2;
+            const uint32_t both = lo1 & b2, either = lo1 | b2;
+            uint32_t expect = (either << 1) + 0x61616161u;
+            expect = (b2 << 2) + expect;
+            expect = (both << 3) + expect;
+            expect = (both << 2) + expect;
+            expect = both + expect;
+            const uint32_t diff = (x | 0x20202020u) ^ expect;
+            // bit 7 of every byte of nz = that byte of diff is non-zero (no carries between bytes)
+            const uint32_t nz = (((diff & 0x7f7f7f7fu) + 0x7f7f7f7fu) | diff) & 0x80808080u;
+            const uint32_t bad = nz >> 7;                       // 0 / 1 per byte
+            const uint32_t ok = bad ^ 0x01010101u;
+            const uint32_t weights = 0x08040201u;
+            h |= __builtin_amdgcn_udot4(b2 & ok, weights, 0u, false) << (4 * i);
+            l |= __builtin_amdgcn_udot4(lo1 & ok, weights, 0u, false) << (4 * i);
+            b |= __builtin_amdgcn_udot4(bad, weights, 0u, false) << (4 * i);
         }
         if (left < 32) b |= 0xffffffffu << (uint32_t)left;   // positions >= L break every run
     }

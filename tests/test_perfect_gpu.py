@@ -141,3 +141,20 @@ def test_begin_end_on_two_handles_interleaved_gives_the_same_runs():
         # the later stages still work on a handle that used the split calls
         a.load_record(seq_a)
         assert len(a.processShiftXORsPerfect()) > 0
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 4099, 70_001])
+def test_pack_of_every_byte_value_matches_oracle(n):
+    """The encode (fasta_utils.cpp:94-114) on arbitrary bytes: A/C/G/T in either case, everything else -- control
+    characters, digits, other letters, bytes >= 128 -- is N.  Odd lengths exercise the unaligned tail."""
+    rs = np.random.RandomState(n)
+    raw = rs.randint(1, 256, size=n).astype(np.uint8)           # no NUL: the record is a C string for the oracle
+    mix = np.where(rs.rand(n) < 0.6, np.frombuffer(b"ACGTacgt", dtype=np.uint8)[rs.randint(0, 8, size=n)], raw)
+    seq = mix.astype(np.uint8).tobytes()
+    with ribbit_amd.Scanner(2, 8) as sc, Oracle(seq, 2, 8) as o:
+        sc.load_record(seq)
+        code, nmask = o.codes(), o.nmask()
+        assert np.array_equal(_unpack(sc.packed_plane(0), n), code >> 1)
+        assert np.array_equal(_unpack(sc.packed_plane(1), n), code & 1)
+        assert np.array_equal(_unpack(sc.packed_plane(2), n), nmask)
+        assert _unpack(sc.packed_plane(2), (n // 32 + 1) * 32)[n:].all()
