@@ -129,12 +129,10 @@ struct RibbitHandle {
     // device-side pairing of the perfect scan: scratch + the pinned run list it lands in
     DevBuf<uint64_t> d_pair_table;
     DevBuf<uint32_t> d_run_base, d_pair_partial, d_pair_status;
-    PinnedBuf<uint32_t> h_pair_status;
     PinnedBuf<uint32_t> h_pub;             // region counters + pairing status, written by the GPU (pair_publish_kernel)
     uint32_t *h_pub_dev = nullptr;         // the same memory as the device sees it
     PinnedBuf<RibbitRun> h_runs, h_halves;
     rb::PairLaunch pair{};                // the perfect scan in flight (perfect_begin .. perfect_finish)
-    size_t pair_cap = 0;
     bool pair_pending = false;
     bool copy_pending = false;            // result copies enqueued but not yet waited for (ribbit_hip_scan_perfect_end with wait = 0)
     DevBuf<RibbitRun> d_halves;
@@ -351,7 +349,6 @@ int perfect_enqueue(RibbitHandle *h, size_t cap) {
     cap = std::min<size_t>((cap + rb::EV_SHARDS - 1) / rb::EV_SHARDS * rb::EV_SHARDS, 0xffffff00u);
     if ((rc = h->d_events.ensure(cap))) return rc;
     if ((rc = h->d_dense.ensure(cap))) return rc;        // cap/2 runs of 16 bytes
-    h->pair_cap = cap;
     HIP_TRY(hipEventRecord(h->ev[4], h->stream));
     HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, rb::EV_COUNTER_WORDS * sizeof(uint32_t), h->stream));
     rb::PerfectLaunch pp;
@@ -757,7 +754,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release(); h->d_slices.release();
     h->h_events.release(); h->h_counters.release(); h->h_query.release(); h->h_xa.release();
     h->d_pair_table.release(); h->d_run_base.release(); h->d_pair_partial.release(); h->d_pair_status.release();
-    h->h_pair_status.release(); h->h_pub.release(); h->h_runs.release(); h->h_halves.release(); h->d_halves.release();
+    h->h_pub.release(); h->h_runs.release(); h->h_halves.release(); h->d_halves.release();
     for (int i = 0; i < 6; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
