@@ -182,6 +182,22 @@ typedef struct RibbitAlignJob {
     int32_t motif_offset;
 } RibbitAlignJob;
 
+/*
+ * What the two striped passes of an alignment determine (ssw.c:843-891: score, end point, second best score outside
+ * the mask window, begin point): everything of StripedSmithWaterman::Alignment except the CIGAR.
+ * flag: 0 ok, 2 the reverse pass scored less than the forward pass, -1 not computed (job too large for the
+ * GPU kernel: query_length > 512 or ppr_length > 1024) -- align those with ribbit_ssw_align.
+ */
+typedef struct RibbitSswEnds {
+    int32_t score, ref_end, query_end, score2, ref_end2, ref_begin, query_begin, flag;
+} RibbitSswEnds;
+
+/* The striped passes of n alignment jobs on the loaded record, batched on the GPU (one alignment per 16-lane DPP
+ * row, the library's stripe order: results are the library's, Aligner::Align at parse_seed.cpp:404 /
+ * parse_smallmotif_seed.cpp:270 with mask length mask_len).  out[j] belongs to jobs[j]. */
+int ribbit_hip_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const char *motif_pool, size_t pool_len,
+                          int32_t mask_len, RibbitSswEnds *out);
+
 /* longestContinuousMatches (parse_seed.cpp:26-44; calls at parse_seed.cpp:366, parse_smallmotif_seed.cpp:234)
  * for every dispatched seed at once, on the GPU: out[i] belongs to dispatch seed i. */
 int ribbit_hip_seed_longest_runs(RibbitHandle *h, const int32_t **out, size_t *n);

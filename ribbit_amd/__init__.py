@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 __all__ = ["RibbitHipError", "ScanParams", "Scanner", "library_path", "load_library", "host_replay_calls", "pack_planes", "pack_bit_planes",
-           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "host_refine_bed", "host_scan_from_events", "host_perfect_runs_from_events", "pair_halves", "ssw_align", "merge_chunk_runs", "join_run_halves",
+           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "ENDS_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "host_refine_bed", "host_scan_from_events", "host_perfect_runs_from_events", "pair_halves", "ssw_align", "merge_chunk_runs", "join_run_halves",
            "RUN_NOT_OWNED", "RUN_HALF_START", "RUN_HALF_END"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -24,6 +24,7 @@ TERM = {"ZERO": 0, "N": 1, "EOS": 2}
 JOB_DT = np.dtype([("seed_index", "<i4"), ("seed_type", "<i4"), ("motif_length", "<i4"), ("atomicity", "<i4"),
                    ("query_start", "<i4"), ("query_length", "<i4"), ("ppr_length", "<i4"), ("small", "<i4"),
                    ("motif_offset", "<i4")])
+ENDS_DT = np.dtype([(n, "<i4") for n in ("score", "ref_end", "query_end", "score2", "ref_end2", "ref_begin", "query_begin", "flag")])
 RUN_DT = np.dtype([("start", "<i4"), ("end", "<i4"), ("mlen", "<i4"), ("term", "<i4")])
 CALL_DT = np.dtype([("pos", "<i4"), ("mlen", "<i4"), ("start", "<i4"), ("end", "<i4")])
 SEED_DT = np.dtype([("start", "<i4"), ("end", "<i4"), ("mlen", "<i4"), ("type", "<i4")])
@@ -46,7 +47,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_stage_events", "ribbit_hip_xa_words", "ribbit_host_scan_from_events",
     "ribbit_host_perfect_runs_from_events", "ribbit_runs_free", "ribbit_hip_perfect_runs_partial",
     "ribbit_hip_scan_perfect_chunk", "ribbit_hip_host_register", "ribbit_hip_host_unregister",
-    "ribbit_hip_set_host_threads", "ribbit_hip_scan_perfect_begin", "ribbit_hip_scan_perfect_end", "ribbit_hip_scan_perfect_wait",
+    "ribbit_hip_set_host_threads", "ribbit_hip_ssw_passes", "ribbit_hip_scan_perfect_begin", "ribbit_hip_scan_perfect_end", "ribbit_hip_scan_perfect_wait",
 ]
 
 
@@ -147,6 +148,7 @@ def load_library():
     L.ribbit_hip_host_register.argtypes = [vp, C.c_size_t]
     L.ribbit_hip_host_unregister.argtypes = [vp]
     L.ribbit_hip_set_host_threads.argtypes = [vp, i32]
+    L.ribbit_hip_ssw_passes.argtypes = [vp, vp, C.c_size_t, C.c_char_p, C.c_size_t, i32, vp]
     L.ribbit_hip_scan_perfect_begin.argtypes = [vp, i64, i64, i64]
     L.ribbit_hip_scan_perfect_end.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int,
                                               C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -579,6 +581,13 @@ class Scanner:
         view = np.frombuffer((C.c_char * (n.value * RUN_DT.itemsize)).from_address(p.value), dtype=RUN_DT)
         view.flags.writeable = False
         return view, halves
+
+    def ssw_passes(self, jobs: np.ndarray, motif_pool: bytes, mask_len: int = 15) -> np.ndarray:
+        """ribbit_hip_ssw_passes: the striped passes of every job (JOB_DT) on the GPU -> ENDS_DT records."""
+        jobs = np.ascontiguousarray(jobs, dtype=JOB_DT)
+        out = np.zeros(len(jobs), ENDS_DT)
+        self._check(self._L.ribbit_hip_ssw_passes(self._h, jobs.ctypes.data, len(jobs), motif_pool, len(motif_pool), mask_len, out.ctypes.data))
+        return out
 
     def host_register(self, address: int, nbytes: int) -> None:
         """Page-lock caller-owned host memory so that scan_perfect_chunk(out=...) DMAs straight into it."""

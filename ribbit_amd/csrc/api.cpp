@@ -149,7 +149,10 @@ struct RibbitHandle {
     DevBuf<int32_t> d_longest;
     DevBuf<uint8_t> d_sym;
     DevBuf<unsigned long long> d_best;
-    DevBuf<int32_t> d_slices;          // {job, first row} per 64-row slice of the long-motif seeds
+    DevBuf<int32_t> d_slices;
+    DevBuf<int32_t> d_ssw_jobs, d_ssw_order, d_ssw_out;   // batched striped passes (ssw_kernels.hip)
+    DevBuf<uint8_t> d_ssw_pool;
+    std::vector<rb::SswEnds> ssw_ends;                     // per job of h->jobs; flag -1 = not computed on the GPU          // {job, first row} per 64-row slice of the long-motif seeds
     bool best_rows_valid = false;
     std::vector<int32_t> best_rows;       // per dispatch seed: mostFrequentLongerMotif's window start, or -1
     std::vector<RibbitAlignJob> jobs;
@@ -752,6 +755,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_ascii.release(); h->d_hi.release(); h->d_lo.release(); h->d_brk.release();
     h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release(); h->d_slices.release();
+    h->d_ssw_jobs.release(); h->d_ssw_order.release(); h->d_ssw_out.release(); h->d_ssw_pool.release();
     h->h_events.release(); h->h_counters.release(); h->h_query.release(); h->h_xa.release();
     h->d_pair_table.release(); h->d_run_base.release(); h->d_pair_partial.release(); h->d_pair_status.release();
     h->h_pub.release(); h->h_runs.release(); h->h_halves.release(); h->d_halves.release();
@@ -888,6 +892,66 @@ int ribbit_hip_seed_longest_runs(RibbitHandle *h, const int32_t **out, size_t *n
     if (rc) return rc;
     *out = h->longest_runs.data();
     *n = h->longest_runs.size();
+    return RIBBIT_OK;
+}
+
+// forward + reverse striped Smith-Waterman passes of every job in one (two) launches; ends[j].flag == -1 where the
+// job is too large for the kernel's LDS budget (the host aligns those)
+static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const char *pool, size_t pool_len, int mask_len,
+                          std::vector<rb::SswEnds> &ends) {
+    static_assert(sizeof(RibbitAlignJob) == 9 * sizeof(int32_t), "job record layout");
+    static_assert(sizeof(rb::SswEnds) == 8 * sizeof(int32_t), "ends record layout");
+    ends.assign(n, rb::SswEnds{});
+    if (n == 0) return RIBBIT_OK;
+    if (n > 0x3fffffffu) return fail(RIBBIT_E_ARG, "too many alignment jobs");
+    if (!h->dev_ascii_src) return fail(RIBBIT_E_STATE, "the record's bases are not resident on the device");
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    // two size classes, each sorted by work so that the four alignments of a wavefront are alike
+    std::vector<int32_t> small, big;
+    for (size_t j = 0; j < n; ++j) {
+        const RibbitAlignJob &jb = jobs[j];
+        if (jb.query_length <= rb::SSW_SMALL_Q && jb.ppr_length <= rb::SSW_SMALL_R) small.push_back((int32_t)j);
+        else if (jb.query_length <= rb::SSW_BIG_Q && jb.ppr_length <= rb::SSW_BIG_R) big.push_back((int32_t)j);
+        else ends[j].flag = -1;
+    }
+    auto by_work = [&](int32_t a, int32_t b) {
+        const int64_t wa = (int64_t)jobs[a].query_length * jobs[a].ppr_length, wb = (int64_t)jobs[b].query_length * jobs[b].ppr_length;
+        return wa != wb ? wa > wb : a < b;
+    };
+    std::sort(small.begin(), small.end(), by_work);
+    std::sort(big.begin(), big.end(), by_work);
+    std::vector<int32_t> order(big);
+    order.insert(order.end(), small.begin(), small.end());
+    if (order.empty()) return RIBBIT_OK;
+    if ((rc = h->d_ssw_jobs.ensure(n * 9))) return rc;
+    if ((rc = h->d_ssw_out.ensure(n * 8))) return rc;
+    if ((rc = h->d_ssw_order.ensure(order.size()))) return rc;
+    if ((rc = h->d_ssw_pool.ensure(std::max<size_t>(pool_len, 1)))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_ssw_jobs.p, jobs, n * sizeof(RibbitAlignJob), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_ssw_order.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    if (pool_len) HIP_TRY(hipMemcpyAsync(h->d_ssw_pool.p, pool, pool_len, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_ssw_out.p, 0xff, n * 8 * sizeof(int32_t), h->stream));      // flag -1 unless a kernel writes the record
+    rb::launch_ssw_passes(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_order.p + big.size(), (int)small.size(),
+                          h->d_ssw_order.p, (int)big.size(), mask_len, h->d_ssw_out.p, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ends.data(), h->d_ssw_out.p, n * sizeof(rb::SswEnds), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const char *motif_pool, size_t pool_len,
+                          int32_t mask_len, RibbitSswEnds *out) {
+    if (!h || (n && (!jobs || !out || !motif_pool))) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    for (size_t j = 0; j < n; ++j)
+        if (jobs[j].atomicity <= 0 || jobs[j].motif_offset < 0 || (size_t)jobs[j].motif_offset + (size_t)jobs[j].atomicity > pool_len)
+            return fail(RIBBIT_E_ARG, "job %zu: motif outside the pool", j);
+    std::vector<rb::SswEnds> ends;
+    int rc = run_ssw_passes(h, jobs, n, motif_pool, pool_len, mask_len, ends);
+    if (rc) return rc;
+    static_assert(sizeof(RibbitSswEnds) == sizeof(rb::SswEnds), "ends record layout");
+    if (n) std::memcpy(out, ends.data(), n * sizeof(RibbitSswEnds));
     return RIBBIT_OK;
 }
 

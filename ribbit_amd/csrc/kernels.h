@@ -78,6 +78,15 @@ void launch_sym(const uint8_t *ascii, int64_t length, uint8_t *sym, hipStream_t 
 void launch_long_motif_rows(const uint8_t *sym, int64_t length, const void *jobs, int64_t njobs, const void *blocks,
                             int64_t nblocks, unsigned long long *best, hipStream_t stream);
 
+// The two striped Smith-Waterman passes (ssw.c:843-891) of njobs alignment jobs (RibbitAlignJob records, 9 ints each):
+// query = record[query_start, +query_length), reference = the job's motif repeated to ppr_length.  Jobs are launched in
+// two size classes (order_small / order_big: job indices, each list sorted by size); out[8*job .. +8) = score,
+// ref_end, query_end, score2, ref_end2, ref_begin, query_begin, flag -- flag -1: too large for its class, not computed.
+constexpr int SSW_SMALL_Q = 128, SSW_SMALL_R = 256, SSW_BIG_Q = 512, SSW_BIG_R = 1024;
+void launch_ssw_passes(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs,
+                       const int32_t *order_small, int n_small, const int32_t *order_big, int n_big, int mask_len,
+                       int32_t *out, hipStream_t stream);
+
 // profiling aid: reads nwords dwords of src with one coalesced dword per lane (known byte count)
 void launch_calib_stream_read(const uint32_t *src, int64_t nwords, uint32_t *sink, hipStream_t stream);
 

@@ -284,10 +284,8 @@ bool banded_traceback(const int8_t *ref, const int8_t *read, int ref_len, int re
 
 }  // namespace
 
-void ssw_align(const char *query, int query_len, const char *ref, int ref_len, int mask_len, SswResult &out) {
-    out = SswResult{};
-    out.ref_begin = -1; out.query_begin = -1;
-    if (query_len <= 0) { out.skipped = true; return; }     // Aligner::Align returns before touching `alignment`
+void ssw_passes(const char *query, int query_len, const char *ref, int ref_len, int mask_len, SswEnds &e) {
+    e = SswEnds{};
     std::vector<int8_t> q((size_t)query_len), r((size_t)std::max(ref_len, 1));
     for (int i = 0; i < query_len; ++i) q[(size_t)i] = translate(query[i]);
     for (int i = 0; i < ref_len; ++i) r[(size_t)i] = translate(ref[i]);
@@ -296,24 +294,35 @@ void ssw_align(const char *query, int query_len, const char *ref, int ref_len, i
     bool wide = false;
     Ends fwd = striped_pass_u8(r.data(), 0, ref_len, q.data(), query_len, 255, mask_len);
     if (fwd.score == 255) { fwd = striped_pass_i16(r.data(), 0, ref_len, q.data(), query_len, 0xffff, mask_len); wide = true; }
-    out.score = fwd.score; out.ref_end = fwd.ref; out.query_end = fwd.read;
-    if (mask_len >= 15) { out.score2 = fwd.score2; out.ref_end2 = fwd.ref2; } else { out.score2 = 0; out.ref_end2 = -1; }
+    e.score = fwd.score; e.ref_end = fwd.ref; e.query_end = fwd.read;
+    if (mask_len >= 15) { e.score2 = fwd.score2; e.ref_end2 = fwd.ref2; } else { e.score2 = 0; e.ref_end2 = -1; }
+    if (e.score == 0 || e.ref_end < 0) { e.ref_end = -1; return; }      // nothing aligned at all: see ssw_finish
 
-    if (out.score == 0 || out.ref_end < 0) {
+    // reverse pass from the end point locates the beginning (ssw.c:874-891)
+    std::vector<int8_t> q_rev(q.begin(), q.begin() + e.query_end + 1);
+    std::reverse(q_rev.begin(), q_rev.end());
+    const Ends rev = wide ? striped_pass_i16(r.data(), 1, e.ref_end + 1, q_rev.data(), e.query_end + 1, e.score, mask_len)
+                          : striped_pass_u8(r.data(), 1, e.ref_end + 1, q_rev.data(), e.query_end + 1, e.score, mask_len);
+    e.ref_begin = rev.ref;
+    e.query_begin = e.query_end - rev.read;
+    if (e.score > rev.score) e.flag = 2;
+}
+
+void ssw_finish(const char *query, int query_len, const char *ref, int ref_len, const SswEnds &e, SswResult &out) {
+    out = SswResult{};
+    out.score = e.score; out.ref_end = e.ref_end; out.query_end = e.query_end;
+    out.score2 = e.score2; out.ref_end2 = e.ref_end2;
+    out.ref_begin = e.ref_begin; out.query_begin = e.query_begin; out.flag = e.flag;
+    if (e.score == 0 || e.ref_end < 0) {
         // nothing aligned at all.  The library would go on to read ref[-1] here (undefined behaviour);
         // defined instead as "no alignment": begin positions stay -1, the CIGAR is one soft clip.
         out.cigar = std::to_string(query_len) + "S";
-        out.ref_end = -1;
+        out.ref_end = -1; out.ref_begin = -1; out.query_begin = -1;
         return;
     }
-    // reverse pass from the end point locates the beginning (ssw.c:874-891)
-    std::vector<int8_t> q_rev(q.begin(), q.begin() + out.query_end + 1);
-    std::reverse(q_rev.begin(), q_rev.end());
-    const Ends rev = wide ? striped_pass_i16(r.data(), 1, out.ref_end + 1, q_rev.data(), out.query_end + 1, out.score, mask_len)
-                          : striped_pass_u8(r.data(), 1, out.ref_end + 1, q_rev.data(), out.query_end + 1, out.score, mask_len);
-    out.ref_begin = rev.ref;
-    out.query_begin = out.query_end - rev.read;
-    if (out.score > rev.score) out.flag = 2;
+    std::vector<int8_t> q((size_t)query_len), r((size_t)std::max(ref_len, 1));
+    for (int i = 0; i < query_len; ++i) q[(size_t)i] = translate(query[i]);
+    for (int i = 0; i < ref_len; ++i) r[(size_t)i] = translate(ref[i]);
 
     std::vector<Op> path;
     const bool too_far = out.ref_end - out.ref_begin > DISTANCE_FILTER || out.query_end - out.query_begin > DISTANCE_FILTER;
@@ -344,6 +353,18 @@ void ssw_align(const char *query, int query_len, const char *ref, int ref_len, i
     close_run();
     const int tail = query_len - out.query_end - 1;
     if (tail > 0) put(tail, 'S');
+}
+
+void ssw_align(const char *query, int query_len, const char *ref, int ref_len, int mask_len, SswResult &out) {
+    if (query_len <= 0) {       // Aligner::Align returns before touching `alignment`
+        out = SswResult{};
+        out.ref_begin = -1; out.query_begin = -1;
+        out.skipped = true;
+        return;
+    }
+    SswEnds ends;
+    ssw_passes(query, query_len, ref, ref_len, mask_len, ends);
+    ssw_finish(query, query_len, ref, ref_len, ends, out);
 }
 
 }  // namespace rb

@@ -1,0 +1,95 @@
+"""GPU leg of the alignment row (f1): the batched striped passes of ribbit_hip_ssw_passes (one alignment per DPP row,
+ssw_kernels.hip) against the REFERENCE library itself (oracle/_ref/libssw_ref.so, compiled from the reference's
+vendored ssw.c / ssw_cpp.cpp) -- score, end point, second best score and begin point -- and, through
+Scanner.refine_bed, the BED text of records whose alignments all went through the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+import ribbit_amd
+from test_ssw import REF_SO, _mutate, _rand, ref_align
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libssw_ref.so not built")]
+
+
+def _batch(pairs):
+    """pairs: (query, motif, ppr_len) -> record, jobs, pool: the queries become slices of one record"""
+    record, pool = bytearray(), bytearray()
+    jobs = np.zeros(len(pairs), ribbit_amd.JOB_DT)
+    for k, (query, motif, ppr_len) in enumerate(pairs):
+        jobs[k]["query_start"], jobs[k]["query_length"] = len(record), len(query)
+        jobs[k]["ppr_length"], jobs[k]["atomicity"], jobs[k]["motif_offset"] = ppr_len, len(motif), len(pool)
+        jobs[k]["motif_length"] = len(motif)
+        record += query + b"N" * 3                       # a gap, so that an off-by-one in a slice shows
+        pool += motif
+    return bytes(record), jobs, bytes(pool)
+
+
+def _check_batch(pairs, mask_len=15):
+    record, jobs, pool = _batch(pairs)
+    with ribbit_amd.Scanner(2, 8) as sc:
+        sc.load_record(record)
+        got = sc.ssw_passes(jobs, pool, mask_len)
+    n_gpu = 0
+    for k, (query, motif, ppr_len) in enumerate(pairs):
+        if got[k]["flag"] == -1:
+            assert len(query) > 512 or ppr_len > 1024, (k, len(query), ppr_len)
+            continue
+        n_gpu += 1
+        ref = motif * (ppr_len // len(motif) + 2)
+        want, _ = ref_align(query, ref, ppr_len, mask_len)
+        g = got[k]
+        if want["sw_score"] == 0:                        # the library reads ref[-1] here (UB); defined as "no alignment"
+            assert g["score"] == 0 and g["ref_end"] == -1, (k, g)
+            continue
+        have = (g["score"], g["ref_end"], g["query_end"], g["score2"], g["ref_end2"], g["ref_begin"], g["query_begin"])
+        ref_vals = (want["sw_score"], want["ref_end"], want["query_end"], want["sw_score_next_best"], want["ref_end_next_best"],
+                    want["ref_begin"], want["query_begin"])
+        assert have == ref_vals, (k, query, motif, ppr_len, have, ref_vals)
+    return n_gpu
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_repeat_like_jobs_match_reference_library(seed):
+    rs = np.random.RandomState(900 + seed)
+    pairs = []
+    for _ in range(400):
+        m = int(rs.randint(1, 30))
+        motif = _rand(rs, m)
+        units = int(rs.randint(2, 40))
+        rot = int(rs.randint(0, m))
+        pure = (motif * (units + 2))[rot:rot + m * units + int(rs.randint(0, m))]
+        query = _mutate(rs, pure, float(rs.choice([0.0, 0.03, 0.1, 0.2])))
+        if query:
+            pairs.append((query, motif, len(query) + m + int(0.15 * len(query))))
+    assert _check_batch(pairs) > 250
+
+
+def test_random_pairs_and_unknown_bases_match_reference_library():
+    rs = np.random.RandomState(77)
+    pairs = []
+    for _ in range(500):
+        q = _rand(rs, int(rs.randint(1, 120)), b"ACGTN" if rs.random_sample() < 0.2 else b"ACGTacgtU")
+        motif = _rand(rs, int(rs.randint(1, 200)))       # a long "motif" = an arbitrary reference
+        pairs.append((q, motif, len(motif)))
+    assert _check_batch(pairs) == len(pairs)
+
+
+def test_long_alignments_take_the_16bit_path_and_oversized_jobs_are_left_to_the_host():
+    rs = np.random.RandomState(7)
+    pairs = []
+    for n in (130, 140, 200, 300, 400, 500, 512, 513, 600, 2500):
+        motif = _rand(rs, int(rs.randint(2, 12)))
+        pure = (motif * (n // len(motif) + 2))[:n]
+        query = _mutate(rs, pure, 0.05)[:n]
+        pairs.append((query, motif, len(query) + len(motif) + int(0.15 * len(query))))
+    n_gpu = _check_batch(pairs)
+    assert 6 <= n_gpu < len(pairs)
+
+
+def test_mask_length_below_15_disables_the_second_best():
+    rs = np.random.RandomState(3)
+    motif = _rand(rs, 5)
+    pairs = [(_mutate(rs, motif * 12, 0.1), motif, 80) for _ in range(40)]
+    assert _check_batch(pairs, mask_len=7) == len(pairs)
