@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "device_planes.h"
@@ -1009,7 +1010,7 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
     if (!h || !prm || !sequence_id || !text || !len) return fail(RIBBIT_E_ARG, "null argument");
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
     h->best_rows_valid = false;
-    static double t_rows = 0, t_text = 0;
+    static double t_rows = 0, t_text = 0, t_jobs = 0;
     static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
     double t0 = now_ms();
     int rc = build_best_rows(h, *prm);
@@ -1025,9 +1026,30 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
         h->host_ascii_valid = true;
     }
     h->bed.clear();
-    rb::refine_to_bed(h->host, h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sequence_id, h->bed, h->host_threads);
+    // Optional (RIBBIT_GPU_SSW=1): first-level alignments set up on host threads, the striped passes of all of them in
+    // one GPU batch, the host then only runs the tracebacks (whole alignments for oversized jobs and the flank
+    // recursion).  Off by default: measured on a 20-Mbp record with 16 host threads the batch (0.4 M alignments: 5 ms
+    // of kernel for the 95 % short ones, 28 ms for the long ones, plus set-up and transfers) costs what it saves,
+    // and with many short records in flight it delays the other records' scans.
+    static const bool gpu_ssw = std::getenv("RIBBIT_GPU_SSW") != nullptr;
+    unsigned threads = h->host_threads ? h->host_threads : std::min(std::thread::hardware_concurrency(), 16u);
+    if (!h->host_threads)
+        if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
+    const std::vector<RibbitAlignJob> *jobs = nullptr;
+    if (gpu_ssw && !h->dispatch.empty()) {
+        const double tj = now_ms();
+        rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), h->jobs, h->motif_pool, threads);
+        const double tp = now_ms();
+        if ((rc = run_ssw_passes(h, h->jobs.data(), h->jobs.size(), h->motif_pool.data(), h->motif_pool.size(), 15, h->ssw_ends))) return rc;
+        if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs: set-up %.1f ms, GPU striped passes incl. transfers %.1f ms\n", h->jobs.size(), tp - tj, now_ms() - tp);
+        jobs = &h->jobs;
+    }
+    t_jobs += now_ms() - t0;
+    t0 = now_ms();
+    rb::refine_to_bed(h->host, h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sequence_id, h->bed,
+                      h->host_threads, jobs, jobs ? &h->ssw_ends : nullptr);
     t_text += now_ms() - t0;
-    if (profile) std::fprintf(stderr, "[refine_bed] cumulative: GPU scans of the seeds %.1f ms, host refinement + BED %.1f ms\n", t_rows, t_text);
+    if (profile) std::fprintf(stderr, "[refine_bed] cumulative: GPU scans of the seeds %.1f ms, alignment set-up + GPU striped passes %.1f ms, host refinement + BED %.1f ms\n", t_rows, t_jobs, t_text);
     *text = h->bed.c_str();
     *len = h->bed.size();
     return RIBBIT_OK;

@@ -219,15 +219,13 @@ int usable_length_host(const HostPlanes &hp, int start, int end, int m) {
     return (end - start) + m;
 }
 
-void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const std::vector<RibbitSeed> &dispatch,
-                      const int32_t *longest_runs, const int32_t *best_rows, std::vector<RibbitAlignJob> &jobs,
-                      std::string &motif_pool) {
-    jobs.clear();
-    motif_pool.clear();
-    const Bases b(hp);
+namespace {
+void build_align_jobs_range(const Bases &b, const RibbitRefineParams &prm, const std::vector<RibbitSeed> &dispatch,
+                            const int32_t *longest_runs, const int32_t *best_rows, size_t lo, size_t hi,
+                            std::vector<RibbitAlignJob> &jobs, std::string &motif_pool) {
     std::vector<uint32_t> classes;
     std::vector<int> starts, ends;
-    for (size_t i = 0; i < dispatch.size(); ++i) {
+    for (size_t i = lo; i < hi; ++i) {
         const RibbitSeed &seed = dispatch[i];
         const int m = seed.mlen;
         if (m > 10 && seed.end - seed.start < 0.9 * m) continue;                    // parse_seed.cpp:360
@@ -266,6 +264,35 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
         }
     }
 }
+}  // namespace
+
+void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const std::vector<RibbitSeed> &dispatch,
+                      const int32_t *longest_runs, const int32_t *best_rows, std::vector<RibbitAlignJob> &jobs,
+                      std::string &motif_pool, unsigned host_threads) {
+    jobs.clear();
+    motif_pool.clear();
+    const Bases b(hp);
+    const size_t n = dispatch.size();
+    const unsigned threads = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads ? host_threads : 1, n / 1024 + 1));
+    if (threads == 1) { build_align_jobs_range(b, prm, dispatch, longest_runs, best_rows, 0, n, jobs, motif_pool); return; }
+    // seeds are independent here: chunks on worker threads, concatenated in seed order with the motif offsets rebased
+    const size_t chunk = 2048, nchunks = (n + chunk - 1) / chunk;
+    std::vector<std::vector<RibbitAlignJob>> part_jobs(nchunks);
+    std::vector<std::string> part_pool(nchunks);
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([&]() {
+            for (size_t c; (c = next.fetch_add(1)) < nchunks;)
+                build_align_jobs_range(b, prm, dispatch, longest_runs, best_rows, c * chunk, std::min(n, (c + 1) * chunk), part_jobs[c], part_pool[c]);
+        });
+    for (std::thread &th : pool) th.join();
+    for (size_t c = 0; c < nchunks; ++c) {
+        const int32_t base = (int32_t)motif_pool.size();
+        for (RibbitAlignJob &j : part_jobs[c]) { j.motif_offset += base; jobs.push_back(j); }
+        motif_pool += part_pool[c];
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Alignment post-processing and BED rows
@@ -280,7 +307,7 @@ struct Stopwatch {
 };
 // (profiling only; the sums are racy across threads and therefore approximate)
 double g_t_align = 0, g_t_small = 0, g_t_long = 0;
-long g_n_align = 0;
+long g_n_align = 0, g_n_known = 0;
 
 struct CigarOp { int len; char op; };
 
@@ -391,12 +418,33 @@ struct Writer {
         return std::string(sequence + start, (size_t)std::min(len, b.L - start));
     }
     bool saw_empty_query = false;   // the one order dependence between seeds: see refine_to_bed
-    std::string align(const std::string &query, const std::string &motif, int ppr_len) {
+    // first-level alignments whose striped passes the GPU has done already: the jobs of the current seed, in the
+    // order in which small_seed / long_seed reach them (build_align_jobs follows the same control flow)
+    const RibbitAlignJob *jobs = nullptr;
+    const SswEnds *ends = nullptr;
+    size_t next_job = 0, last_job = 0;
+    void begin_seed(size_t first, size_t last) { next_job = first; last_job = last; }
+    // query_start < 0: not a first-level alignment (flank recursion), always aligned here
+    std::string align(const std::string &query, const std::string &motif, int ppr_len, int query_start = -1) {
+        const SswEnds *known = nullptr;
+        if (query_start >= 0 && jobs && next_job < last_job) {
+            const RibbitAlignJob &jb = jobs[next_job];
+            const SswEnds &e = ends[next_job];
+            ++next_job;
+            if (e.flag != -1 && jb.query_start == query_start && jb.ppr_length == ppr_len &&
+                (int)query.size() == std::min(jb.query_length, b.L - jb.query_start) && jb.atomicity == (int)motif.size())
+                known = &e;
+        }
         if (query.empty()) { saw_empty_query = true; return last_cigar; }
         std::string ref;
         while ((long)ref.size() <= (long)ppr_len) ref += motif;
         SswResult res;
-        { Stopwatch sw(&g_t_align); ++g_n_align; ssw_align(query.data(), (int)query.size(), ref.data(), ppr_len, 15, res); }
+        {
+            Stopwatch sw(&g_t_align);
+            ++g_n_align;
+            if (known) { ++g_n_known; ssw_finish(query.data(), (int)query.size(), ref.data(), ppr_len, *known, res); }
+            else ssw_align(query.data(), (int)query.size(), ref.data(), ppr_len, 15, res);
+        }
         last_cigar = res.cigar;
         return last_cigar;
     }
@@ -416,7 +464,7 @@ struct Writer {
             Wide unit; unit.limb[0] = classes[k];
             const std::string motif = spell(unit, m, atom);
             const int qlen = ends[k] - starts[k];
-            const std::string cigar = align(slice(starts[k], qlen), motif, padded_length(qlen, m, qlen, prm.purity_threshold));
+            const std::string cigar = align(slice(starts[k], qlen), motif, padded_length(qlen, m, qlen, prm.purity_threshold), std::max(starts[k], 0));
             const Repeat r = digest_cigar(starts[k], qlen, cigar, atom, false, prm);
             const int units = count_units(b, r.start, r.end - r.start, atom, classes[k] >> (2 * (m - atom)));
             if (units >= prm.perfect_units[atom] && r.end - r.start >= prm.min_length[atom]) row(r, motif, atom, m, seed.type);
@@ -434,7 +482,8 @@ struct Writer {
         const int atom = long_atomicity(unit, m);
         if (m % atom != 0) return;
         const std::string motif = spell(unit, m, atom);
-        const std::string cigar = align(slice(start, seq_len), motif, padded_length(seq_len, m, seq_len, prm.purity_threshold));
+        const std::string cigar = align(slice(start, seq_len), motif, padded_length(seq_len, m, seq_len, prm.purity_threshold),
+                                        depth == 0 ? std::max(start, 0) : -1);
         const Repeat r = digest_cigar(start, seq_len, cigar, atom, true, prm);
         if (r.alignment_length >= prm.min_length[atom] && r.end - r.start >= prm.min_length[m]) row(r, motif, atom, m, type);
         // flanks on either side of the aligned repeat, if at least MINIMUM_LENGTH[m] long (:443-463)
@@ -454,11 +503,21 @@ struct Writer {
 
 void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
                    const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
-                   const std::string &sequence_id, std::string &bed, unsigned host_threads) {
+                   const std::string &sequence_id, std::string &bed, unsigned host_threads,
+                   const std::vector<RibbitAlignJob> *jobs, const std::vector<SswEnds> *ends) {
     const Bases b(hp);
+    // first job of every seed (jobs are in seed order)
+    std::vector<uint32_t> job_first;
+    if (jobs && ends && ends->size() == jobs->size()) {
+        job_first.assign(dispatch.size() + 1, (uint32_t)jobs->size());
+        for (size_t j = jobs->size(); j-- > 0;) job_first[(size_t)(*jobs)[j].seed_index] = (uint32_t)j;
+        for (size_t i = dispatch.size(); i-- > 0;) job_first[i] = std::min(job_first[i], job_first[i + 1]);
+    }
     auto run_range = [&](size_t lo, size_t hi, Writer &w) {
+        if (!job_first.empty()) { w.jobs = jobs->data(); w.ends = ends->data(); }
         for (size_t i = lo; i < hi; ++i) {
             const RibbitSeed &seed = dispatch[i];
+            if (!job_first.empty()) w.begin_seed(job_first[i], job_first[i + 1]);
             if (seed.mlen <= 10) w.small_seed(seed, longest_runs[i]);
             else w.long_seed(seed.start, seed.end, seed.mlen, seed.type, longest_runs[i], best_rows ? best_rows[i] : -1, 0);
         }
@@ -501,8 +560,8 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
         bed += w.os.str();
     }
     if (std::getenv("RIBBIT_PROFILE"))
-        std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld  (summed over threads) align %.2fs  small-motif discovery %.2fs  long-motif consensus %.2fs\n",
-                     dispatch.size(), threads, g_n_align, g_t_align, g_t_small, g_t_long);
+        std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld (%ld with GPU passes)  (summed over threads) align %.2fs  small-motif discovery %.2fs  long-motif consensus %.2fs\n",
+                     dispatch.size(), threads, g_n_align, g_n_known, g_t_align, g_t_small, g_t_long);
 }
 
 }  // namespace rb

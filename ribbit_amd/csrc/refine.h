@@ -13,6 +13,7 @@
 
 #include "host_planes.h"
 #include "ribbit_hip.h"
+#include "ssw_exact.h"
 
 namespace rb {
 
@@ -21,7 +22,7 @@ namespace rb {
 // (computed by long_motif_rows_kernel), or -1 to compute it on the host.
 void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const std::vector<RibbitSeed> &dispatch,
                       const int32_t *longest_runs, const int32_t *best_rows, std::vector<RibbitAlignJob> &jobs,
-                      std::string &motif_pool);
+                      std::string &motif_pool, unsigned host_threads = 1);
 
 // seed_sequence_length of parse_seed.cpp:342-349: seed + one motif, cut at the first N
 int usable_length_host(const HostPlanes &hp, int start, int end, int m);
@@ -36,6 +37,9 @@ int longest_run_host(const HostPlanes &hp, int mlen, int start, int end);
 // and the BED rows (11 tab-separated columns) appended to `bed`.  sequence = the record's bases.
 void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
                    const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
-                   const std::string &sequence_id, std::string &bed, unsigned host_threads = 0);
+                   const std::string &sequence_id, std::string &bed, unsigned host_threads = 0,
+                   const std::vector<RibbitAlignJob> *jobs = nullptr, const std::vector<SswEnds> *ends = nullptr);
+// jobs / ends (optional): the first-level alignment jobs of build_align_jobs and the end points of their striped
+// passes as the GPU computed them (flag -1 = not computed); such alignments only need the traceback here.
 
 }  // namespace rb

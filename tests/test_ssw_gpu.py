@@ -93,3 +93,33 @@ def test_mask_length_below_15_disables_the_second_best():
     motif = _rand(rs, 5)
     pairs = [(_mutate(rs, motif * 12, 0.1), motif, 80) for _ in range(40)]
     assert _check_batch(pairs, mask_len=7) == len(pairs)
+
+
+def test_bed_is_identical_with_the_striped_passes_on_the_gpu(tmp_path):
+    """RIBBIT_GPU_SSW=1 routes every first-level alignment's passes through ssw_passes_kernel; the BED text must not
+    change (and equals the oracle pipeline's, which aligns with the reference library)."""
+    import subprocess
+    from cases import large_motif_cases, simulated_cases
+    from oracle_lib import Oracle
+    from ribbit_amd.simulate import write_fasta
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    records = [("sim", simulated_cases()[1][1]), ("big", large_motif_cases()[0][1])]
+    fa = tmp_path / "in.fa"
+    write_fasta(str(fa), records)
+    want = ""
+    for name, seq in records:
+        with Oracle(seq, 2, 100) as o:
+            o.run_all()
+            want += o.refine_bed(name)
+    for flag in ("1", None):
+        env = dict(os.environ)
+        env.pop("RIBBIT_GPU_SSW", None)
+        if flag:
+            env["RIBBIT_GPU_SSW"] = flag
+        env["RIBBIT_PROFILE"] = "1"
+        bed = tmp_path / f"out_{flag}.bed"
+        r = subprocess.run([os.path.join(root, "ribbit_amd", "ribbit-hip"), "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "100"],
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert bed.read_text() == want
+        assert ("with GPU passes" in r.stderr and "(0 with GPU passes)" not in r.stderr.split("[refine]")[-1]) == bool(flag)
