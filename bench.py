@@ -135,7 +135,9 @@ def main():
         probe, _ = sc.scan_perfect_chunk(own_lo, own_hi, pos_offset)
         cap = max(int(a[0]) for a in allgather_array(np.array([len(probe)], dtype=np.int64), xdev))
         ng = open_node_gather(ribbit_amd.RUN_DT, 2 * cap + 4096, 2 * (M_HI - M_LO + 1), nslots=depth + 1)
-        for addr, nbytes in ng.my_cells():
+        if ng is None and rank == 0:
+            print("node-shared segment unavailable: gathering over RCCL instead", file=sys.stderr)
+        for addr, nbytes in (ng.my_cells() if ng is not None else []):
             try:
                 sc.host_register(addr, nbytes)
             except ribbit_amd.RibbitHipError as e:       # still correct, the copies are just staged by the runtime

@@ -83,15 +83,32 @@ def same_node() -> bool:
 
 def open_node_gather(dtype, cap: int, half_cap: int, nslots: int = 2):
     """Collective: rank 0 creates the node-shared segment (ribbit_amd.node_gather), its name is broadcast and
-    the other ranks attach.  cap / half_cap must be the same on all ranks."""
+    the other ranks attach.  cap / half_cap must be the same on all ranks.  Returns None on every rank when the
+    segment cannot be created or attached (e.g. /dev/shm too small): the caller then gathers over RCCL."""
     from .node_gather import NodeGather
     rank, world = dist.get_rank(), dist.get_world_size()
-    ng = NodeGather(dtype, cap, half_cap, rank, world, nslots=nslots) if rank == 0 else None
-    box = [ng.name if rank == 0 else None]
+    ng = None
+    if rank == 0:
+        try:
+            ng = NodeGather(dtype, cap, half_cap, rank, world, nslots=nslots)
+        except OSError:
+            ng = None
+    box = [ng.name if ng is not None else None]
     dist.broadcast_object_list(box, src=0)
-    if rank != 0:
-        ng = NodeGather(dtype, cap, half_cap, rank, world, name=box[0], nslots=nslots)
-    dist.barrier()
+    ok = 1
+    if rank != 0 and box[0] is not None:
+        try:
+            ng = NodeGather(dtype, cap, half_cap, rank, world, name=box[0], nslots=nslots)
+        except (OSError, ValueError):
+            ok = 0
+    if box[0] is None:
+        ok = 0
+    flags = [None] * world
+    dist.all_gather_object(flags, ok)
+    if not all(flags):
+        if ng is not None:
+            ng.close()
+        return None
     return ng
 
 

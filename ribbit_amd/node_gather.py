@@ -44,7 +44,13 @@ class NodeGather:
         fd = os.open(self.name, (os.O_CREAT | os.O_EXCL | os.O_RDWR) if self._owner else os.O_RDWR, 0o600)
         try:
             if self._owner:
-                os.ftruncate(fd, self.nbytes)            # zero-filled: no step published, nothing released
+                # reserve the pages now (zero-filled: no step published, nothing released): a tmpfs that is too small
+                # must fail here with ENOSPC, not later with SIGBUS on first touch
+                try:
+                    os.posix_fallocate(fd, 0, self.nbytes)
+                except OSError:
+                    os.unlink(self.name)
+                    raise
             elif os.fstat(fd).st_size != self.nbytes:
                 raise ValueError(f"{self.name}: segment size differs from this rank's cap/half_cap/world")
             self._map = mmap.mmap(fd, self.nbytes, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE)

@@ -98,3 +98,10 @@ def test_join_run_halves_pairs_by_motif_and_position_and_rejects_garbage():
     whole = np.array([(1, 20, 3, 0), (0, 0, 0, ribbit_amd.RUN_NOT_OWNED), (500, 600, 2, 1)], dtype=dt)
     merged = ribbit_amd.merge_chunk_runs([whole], [a, b])
     assert list(merged["mlen"]) == [2, 3, 5, 5, 9] and list(merged["start"]) == [500, 1, 100, 7000, 50]
+
+
+def test_a_segment_that_does_not_fit_fails_at_creation_and_leaves_nothing_behind():
+    before = set(os.listdir("/dev/shm"))
+    with pytest.raises(OSError):
+        NodeGather(ribbit_amd.RUN_DT, 10 ** 13, 2, rank=0, world=1)          # 160 TB
+    assert set(os.listdir("/dev/shm")) == before
