@@ -158,3 +158,16 @@ def test_pack_of_every_byte_value_matches_oracle(n):
         assert np.array_equal(_unpack(sc.packed_plane(1), n), code & 1)
         assert np.array_equal(_unpack(sc.packed_plane(2), n), nmask)
         assert _unpack(sc.packed_plane(2), (n // 32 + 1) * 32)[n:].all()
+
+
+@pytest.mark.parametrize("seed,bases,m_lo,m_hi", [(71, 3_000_000, 2, 100), (72, 2_000_000, 5, 40), (73, 1_500_000, 30, 200), (74, 2_000_000, 2, 14)])
+def test_perfect_calls_on_megabase_records_match_oracle(seed, bases, m_lo, m_hi):
+    """Hundreds of tiles per record: the candidate queue of the perfect scan fills and flushes across motifs, pairs
+    run in place when dense, runs cross tile edges -- all against the oracle's perfect stage (calls and seeds)."""
+    from ribbit_amd.simulate import simulate_sequence
+    seq, _ = simulate_sequence(bases, seed, m_lo, min(m_hi, 100), n_block_rate=0.2)
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc, Oracle(seq, m_lo, m_hi) as o:
+        sc.load_record(seq)
+        o.run_perfect()
+        assert np.array_equal(sc.perfect_calls(), o.calls(LIST_PERFECT).astype(ribbit_amd.CALL_DT))
+        assert np.array_equal(sc.processShiftXORsPerfect(), o.seeds(LIST_PERFECT).astype(ribbit_amd.SEED_DT))
