@@ -48,13 +48,33 @@ def cpu_baseline(seq: bytes):
             "sample": f"first {len(sample)} bases of the workload, encode + sweep + perfect scan + addSeed, m={M_LO}..{M_HI}, {dt:.1f} s"}
 
 
+def full_path_sample(sc, seq: bytes, bases: int):
+    """The whole per-sequence path of BASELINE.json configs[2] (perfect + substitution + anchored scans, the three
+    seed merges, dispatch, refinement, BED text) on a bounded sample of the workload: reported next to the scan
+    metric because it is what an end-to-end run waits for (host merges and refinement)."""
+    sample = seq[:bases]
+    t0 = time.perf_counter()
+    sc.load_record(sample)
+    perfect, subst, anchored = sc.processShiftXORsAnchored()
+    dispatch = sc.dispatch_seeds()
+    t1 = time.perf_counter()
+    bed = sc.refine_bed("bench")
+    t2 = time.perf_counter()
+    return {"bases": len(sample), "value": len(sample) / (t2 - t0) / 1e9, "unit": "Gbases/s", "seconds": t2 - t0,
+            "scans_and_merges_s": t1 - t0, "refinement_and_bed_s": t2 - t1, "seeds": int(len(perfect) + len(subst) + len(anchored)),
+            "dispatched": int(len(dispatch)), "bed_rows": bed.count("\n"),
+            "what": "FASTA record -> BED text, -m 2 -M 100: three scans + seed merges + dispatch + refinement (host-bound)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bases", type=int, default=WORKLOAD_BASES, help="bases per GPU (default: BASELINE config 2)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the full-path sample")
+    ap.add_argument("--full-path-bases", type=int, default=10_000_000,
+                    help="size of the whole-path sample reported next to the scan metric (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "shm", "rccl"],
                     help="N > 1: how the chunks' run records reach rank 0's host merge (auto: shm on one node, else rccl)")
@@ -285,6 +305,8 @@ def main():
             out["roofline"]["valu"] = {"wave_instr_per_launch": n_valu, "alignbit_share": ALIGNBIT_SHARE,
                                        "issue_rate_wave_instr_per_s": {"v_alignbit_b32": ALIGNBIT_RATE, "other": PLAIN_VALU_RATE},
                                        "issue_bound_ms": roof_ms, "frac": roof_ms / kavg}
+        if world == 1 and not args.no_cpu_baseline and args.full_path_bases > 0:
+            out["full_path_sample"] = full_path_sample(sc, seq, min(args.full_path_bases, args.bases))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seq)
         print(json.dumps(out), flush=True)

@@ -36,6 +36,8 @@ def test_single_gpu_line_has_the_contracted_fields():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Gbases/s" and cb["value"] > 0 and cb["sample"]
     assert d["value"] > cb["value"]
+    fp = d["full_path_sample"]
+    assert fp["bases"] == 3_000_000 and fp["bed_rows"] > 1000 and 0 < fp["value"] < d["value"] and fp["unit"] == "Gbases/s"
 
 
 @pytest.mark.parametrize("exchange", ["shm", "rccl"])
