@@ -32,6 +32,7 @@ ALIGNBIT_SHARE = 0.31            # v_alignbit_b32 among the executed VALU instru
                                  # ~66 per motif in the filter pass, 61 of ~175 in a run of the doubling chain)
 ALIGNBIT_RATE = 550e9            # wave-instr/s chip-wide at 4 waves/SIMD (profiles/r01b_valu_peak_probe.txt)
 PLAIN_VALU_RATE = 930e9          # v_or / v_xor / v_bitop3, same probe
+CPU_FULL_PATH_BASES = 1_000_000  # whole-path CPU oracle sample (a few seconds)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 CPU_SAMPLE_BASES = 20_000_000
 
@@ -60,7 +61,16 @@ def full_path_sample(sc, seq: bytes, bases: int):
     t1 = time.perf_counter()
     bed = sc.refine_bed("bench")
     t2 = time.perf_counter()
+    # the same path through the CPU oracle (single thread) on a smaller sample, for scale
+    from oracle_lib import Oracle
+    small = seq[:min(len(sample), CPU_FULL_PATH_BASES)]
+    c0 = time.perf_counter()
+    with Oracle(small, M_LO, M_HI) as o:
+        o.run_all()
+        o.refine_bed("bench")
+    cpu_dt = time.perf_counter() - c0
     return {"bases": len(sample), "value": len(sample) / (t2 - t0) / 1e9, "unit": "Gbases/s", "seconds": t2 - t0,
+            "cpu_port": {"value": len(small) / cpu_dt / 1e9, "unit": "Gbases/s", "cores": 1, "bases": len(small), "seconds": cpu_dt},
             "scans_and_merges_s": t1 - t0, "refinement_and_bed_s": t2 - t1, "seeds": int(len(perfect) + len(subst) + len(anchored)),
             "dispatched": int(len(dispatch)), "bed_rows": bed.count("\n"),
             "what": "FASTA record -> BED text, -m 2 -M 100: three scans + seed merges + dispatch + refinement (host-bound)"}
