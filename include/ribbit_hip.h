@@ -362,6 +362,11 @@ int ribbit_hip_scan_perfect_end(RibbitHandle *h, RibbitRun *dst, size_t dst_cap,
                                 int wait, const RibbitRun **out, size_t *n, const RibbitRun **halves, size_t *n_halves);
 int ribbit_hip_scan_perfect_wait(RibbitHandle *h);
 
+/* HIP events behind ribbit_hip_last_timing_ms are recorded by default; every record is a barrier packet between two
+ * kernels of the stream (~6 us each on MI355X).  A caller that streams many records can switch them off per handle
+ * (ribbit_hip_last_timing_ms then fails with RIBBIT_E_STATE for the pack / scan / GPU-side intervals). */
+int ribbit_hip_set_timing(RibbitHandle *h, int32_t enabled);
+
 /* Worker threads the host-side stages of this handle may use (window state machines, refinement);
  * 0 = default (environment RIBBIT_THREADS, else min(cores, 16)).  A caller that keeps several handles busy at
  * once -- ribbit-hip does, one per in-flight FASTA record (ribbit.cpp:269-280 processes them one by one) --

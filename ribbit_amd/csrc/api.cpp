@@ -96,6 +96,7 @@ struct RibbitHandle {
     hipEvent_t ev_ready = nullptr;       // pairing done, counters and status on the host
     hipEvent_t ev[6] = {};        // 0/1 pack, 2/3 scan kernel, 4/5 whole GPU side of the last scan
     bool have_timing[3] = {false, false, false};
+    bool timing = true;           // record the HIP events behind ribbit_hip_last_timing_ms (each costs a barrier packet on the stream)
     double host_ms = 0.0;         // host post-processing of the last scan (pairing / FSM)
     unsigned host_threads = 0;    // worker threads of the host stages (0 = RIBBIT_THREADS or min(cores, 16))
 
@@ -208,11 +209,11 @@ int pack_loaded_ascii(RibbitHandle *h, const uint8_t *dev_ascii, int64_t length)
     if ((rc = h->d_hi.ensure((size_t)h->total_words))) return rc;
     if ((rc = h->d_lo.ensure((size_t)h->total_words))) return rc;
     if ((rc = h->d_brk.ensure((size_t)h->total_words))) return rc;
-    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     rb::launch_pack(dev_ascii, length, h->d_hi.p, h->d_lo.p, h->d_brk.p, h->total_words, h->stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-    h->have_timing[0] = true;
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    h->have_timing[0] = h->timing;
     h->lists = rb::SeedLists{};
     h->lists.length = length;
     h->lists.min_motif = h->params.min_motif;
@@ -353,14 +354,14 @@ int perfect_enqueue(RibbitHandle *h, size_t cap) {
     cap = std::min<size_t>((cap + rb::EV_SHARDS - 1) / rb::EV_SHARDS * rb::EV_SHARDS, 0xffffff00u);
     if ((rc = h->d_events.ensure(cap))) return rc;
     if ((rc = h->d_dense.ensure(cap))) return rc;        // cap/2 runs of 16 bytes
-    HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[4], h->stream));
     HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, rb::EV_COUNTER_WORDS * sizeof(uint32_t), h->stream));
     rb::PerfectLaunch pp;
     pp.m_lo = h->params.min_motif;
     pp.m_hi = h->params.max_motif;
     pp.ev_cap = (uint32_t)cap;
     pr.region_cap = pp.ev_cap / (uint32_t)rb::EV_SHARDS;
-    HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     rb::launch_scan_perfect(h->planes(), pp, h->d_events.p, h->d_counters.p, h->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev[3], h->stream));
@@ -455,8 +456,8 @@ int perfect_finish(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *h
     }
     if (h->n_runs)
         HIP_TRY(hipMemcpyAsync(dst, h->d_dense.p, h->n_runs * sizeof(RibbitRun), hipMemcpyDeviceToHost, h->copy_stream));
-    HIP_TRY(hipEventRecord(h->ev[5], h->copy_stream));
-    h->have_timing[1] = h->have_timing[2] = true;
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->copy_stream));
+    h->have_timing[1] = h->have_timing[2] = h->timing;
     h->host_ms = 0.0;
     h->runs_valid = whole;
     h->copy_pending = true;
@@ -1199,6 +1200,13 @@ int ribbit_hip_scan_perfect_end(RibbitHandle *h, RibbitRun *dst, size_t dst_cap,
     *n = h->n_runs;
     if (halves) *halves = half_dst ? half_dst : h->h_halves.p;
     if (n_halves) *n_halves = h->n_halves;
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_set_timing(RibbitHandle *h, int32_t enabled) {
+    if (!h) return fail(RIBBIT_E_ARG, "null argument");
+    h->timing = enabled != 0;
+    if (!h->timing) h->have_timing[0] = h->have_timing[1] = h->have_timing[2] = false;
     return RIBBIT_OK;
 }
 
