@@ -136,6 +136,7 @@ struct RibbitHandle {
     PinnedBuf<RibbitRun> h_runs, h_halves;
     rb::PairLaunch pair{};                // the perfect scan in flight (perfect_begin .. perfect_finish)
     bool pair_pending = false;
+    bool counters_clean = false;          // d_counters zeroed by the pack kernel and not used since
     bool copy_pending = false;            // result copies enqueued but not yet waited for (ribbit_hip_scan_perfect_end with wait = 0)
     DevBuf<RibbitRun> d_halves;
     size_t n_runs = 0, n_halves = 0;
@@ -210,7 +211,9 @@ int pack_loaded_ascii(RibbitHandle *h, const uint8_t *dev_ascii, int64_t length)
     if ((rc = h->d_lo.ensure((size_t)h->total_words))) return rc;
     if ((rc = h->d_brk.ensure((size_t)h->total_words))) return rc;
     if (h->timing) HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-    rb::launch_pack(dev_ascii, length, h->d_hi.p, h->d_lo.p, h->d_brk.p, h->total_words, h->stream);
+    if ((rc = h->d_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
+    rb::launch_pack(dev_ascii, length, h->d_hi.p, h->d_lo.p, h->d_brk.p, h->total_words, h->d_counters.p, rb::EV_COUNTER_WORDS, h->stream);
+    h->counters_clean = true;      // until a scan kernel runs
     HIP_TRY(hipGetLastError());
     if (h->timing) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     h->have_timing[0] = h->timing;
@@ -260,6 +263,7 @@ int collect_events(RibbitHandle *h, int which) {
         if ((rc = h->d_dense.ensure(cap))) return rc;
         HIP_TRY(hipEventRecord(h->ev[4], h->stream));
         HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, rb::EV_COUNTER_WORDS * sizeof(uint32_t), h->stream));
+        h->counters_clean = false;
         rb::PerfectLaunch pp;
         pp.m_lo = h->params.min_motif;
         pp.m_hi = h->params.max_motif;
@@ -355,7 +359,8 @@ int perfect_enqueue(RibbitHandle *h, size_t cap) {
     if ((rc = h->d_events.ensure(cap))) return rc;
     if ((rc = h->d_dense.ensure(cap))) return rc;        // cap/2 runs of 16 bytes
     if (h->timing) HIP_TRY(hipEventRecord(h->ev[4], h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, rb::EV_COUNTER_WORDS * sizeof(uint32_t), h->stream));
+    if (!h->counters_clean) HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, rb::EV_COUNTER_WORDS * sizeof(uint32_t), h->stream));
+    h->counters_clean = false;
     rb::PerfectLaunch pp;
     pp.m_lo = h->params.min_motif;
     pp.m_hi = h->params.max_motif;

@@ -9,8 +9,9 @@ namespace rb {
 
 // fasta_utils.cpp:78-115 -> packed planes.  total_words counts the LEAD padding too; the three
 // output pointers are the raw allocations (NOT advanced by LEAD_WORDS).
+// zero_words (may be null): n_zero words the kernel also clears (the event counters of the scan that follows).
 void launch_pack(const uint8_t *dev_ascii, int64_t length, uint32_t *hi, uint32_t *lo, uint32_t *brk,
-                 int64_t total_words, hipStream_t stream);
+                 int64_t total_words, uint32_t *zero_words, int n_zero, hipStream_t stream);
 
 struct PerfectLaunch {
     int m_lo, m_hi;        // motif (== shift) range scanned

@@ -37,8 +37,12 @@ __device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
 // One thread produces one 32-base word of each plane.
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii, int64_t length,
                                                    uint32_t *__restrict__ hi, uint32_t *__restrict__ lo,
-                                                   uint32_t *__restrict__ brk, int64_t total_words) {
+                                                   uint32_t *__restrict__ brk, int64_t total_words,
+                                                   uint32_t *__restrict__ zero_words, int n_zero) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the event counters of the scan that follows, zeroed here to save that scan a fill launch
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < n_zero; i += 256) zero_words[i] = 0u;
     if (t >= total_words) return;
     const int64_t p0 = (t - LEAD_WORDS) * 32;
     uint32_t h = 0, l = 0, b = 0xffffffffu;
@@ -96,11 +100,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
 }
 
 void launch_pack(const uint8_t *dev_ascii, int64_t length, uint32_t *hi, uint32_t *lo, uint32_t *brk,
-                 int64_t total_words, hipStream_t stream) {
+                 int64_t total_words, uint32_t *zero_words, int n_zero, hipStream_t stream) {
     const int threads = 256;
     const int64_t blocks = (total_words + threads - 1) / threads;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(threads), 0, stream, dev_ascii, length, hi, lo, brk,
-                       total_words);
+                       total_words, zero_words, n_zero);
 }
 
 // ---------------------------------------------------------------------- event staging
