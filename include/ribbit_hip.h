@@ -362,6 +362,10 @@ int ribbit_hip_scan_perfect_end(RibbitHandle *h, RibbitRun *dst, size_t dst_cap,
                                 int wait, const RibbitRun **out, size_t *n, const RibbitRun **halves, size_t *n_halves);
 int ribbit_hip_scan_perfect_wait(RibbitHandle *h);
 
+/* Test hook: the first guess of the event-buffer capacity of the scans (0 = automatic).  A guess that is too small
+ * makes a scan overflow its regions, after which it is sized for the fullest region and run again. */
+int ribbit_hip_debug_set_event_capacity(RibbitHandle *h, size_t events);
+
 /* HIP events behind ribbit_hip_last_timing_ms are recorded by default; every record is a barrier packet between two
  * kernels of the stream (~6 us each on MI355X).  A caller that streams many records can switch them off per handle
  * (ribbit_hip_last_timing_ms then fails with RIBBIT_E_STATE for the pack / scan / GPU-side intervals). */

@@ -136,6 +136,7 @@ struct RibbitHandle {
     PinnedBuf<RibbitRun> h_runs, h_halves;
     rb::PairLaunch pair{};                // the perfect scan in flight (perfect_begin .. perfect_finish)
     bool pair_pending = false;
+    size_t debug_first_cap = 0;           // ribbit_hip_debug_set_event_capacity: first guess of the event capacity (tests of the overflow path)
     bool counters_clean = false;          // d_counters zeroed by the pack kernel and not used since
     bool copy_pending = false;            // result copies enqueued but not yet waited for (ribbit_hip_scan_perfect_end with wait = 0)
     DevBuf<RibbitRun> d_halves;
@@ -255,6 +256,7 @@ int collect_events(RibbitHandle *h, int which) {
     const size_t per_base_x4 = which == 0 ? 1 : which == 1 ? 2 : (size_t)std::max(16, (h->params.max_motif - h->params.min_motif + 1) / 6);
     size_t cap = std::max<size_t>((size_t)1 << 20, (size_t)h->length * per_base_x4 / 4);
     cap = std::max(cap, h->d_events.cap);
+    if (h->debug_first_cap) cap = h->debug_first_cap;
     const rb::DevicePlanes pl = h->planes();
     uint32_t produced = 0;
     for (int attempt = 0;; ++attempt) {
@@ -409,7 +411,8 @@ int perfect_begin(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_o
     if ((rc = h->d_pair_table.ensure(entries))) return rc;
     if ((rc = h->d_run_base.ensure(entries))) return rc;
     if ((rc = h->d_pair_partial.ensure(entries / 1024 + 2))) return rc;
-    const size_t cap = std::max(std::max<size_t>((size_t)1 << 20, (size_t)(h->length / 4)), h->d_events.cap);
+    const size_t cap = h->debug_first_cap ? h->debug_first_cap
+                                          : std::max(std::max<size_t>((size_t)1 << 20, (size_t)(h->length / 4)), h->d_events.cap);
     if ((rc = perfect_enqueue(h, cap))) return rc;
     h->pair_pending = true;
     return RIBBIT_OK;
@@ -1205,6 +1208,12 @@ int ribbit_hip_scan_perfect_end(RibbitHandle *h, RibbitRun *dst, size_t dst_cap,
     *n = h->n_runs;
     if (halves) *halves = half_dst ? half_dst : h->h_halves.p;
     if (n_halves) *n_halves = h->n_halves;
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_debug_set_event_capacity(RibbitHandle *h, size_t events) {
+    if (!h) return fail(RIBBIT_E_ARG, "null argument");
+    h->debug_first_cap = events;
     return RIBBIT_OK;
 }
 

@@ -171,3 +171,21 @@ def test_perfect_calls_on_megabase_records_match_oracle(seed, bases, m_lo, m_hi)
         o.run_perfect()
         assert np.array_equal(sc.perfect_calls(), o.calls(LIST_PERFECT).astype(ribbit_amd.CALL_DT))
         assert np.array_equal(sc.processShiftXORsPerfect(), o.seeds(LIST_PERFECT).astype(ribbit_amd.SEED_DT))
+
+
+def test_event_buffer_overflow_is_retried_with_a_larger_buffer():
+    """First guess of the event capacity far too small (64 events per region): every stage must notice the
+    overflow, size its regions for the fullest one and come out with the same lists."""
+    name, seq, m_lo, m_hi = simulated_cases()[1]
+    with ribbit_amd.Scanner(m_lo, m_hi) as ref, ribbit_amd.Scanner(m_lo, m_hi) as sc:
+        ref.load_record(seq)
+        want_runs = ref.scan_perfect_runs()
+        want = ref.processShiftXORsAnchored()
+        sc.debug_set_event_capacity(64 * 64)
+        sc.load_record(seq)
+        assert np.array_equal(sc.scan_perfect_runs().view("<i4"), want_runs.view("<i4"))
+        sc.load_record(seq); sc.scan_perfect_begin()
+        assert np.array_equal(sc.scan_perfect_end()[0].view("<i4"), want_runs.view("<i4"))
+        got = sc.processShiftXORsAnchored()
+        for a, b in zip(got, want):
+            assert np.array_equal(a.view("<i4"), b.view("<i4"))
