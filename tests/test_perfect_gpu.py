@@ -189,3 +189,20 @@ def test_event_buffer_overflow_is_retried_with_a_larger_buffer():
         got = sc.processShiftXORsAnchored()
         for a, b in zip(got, want):
             assert np.array_equal(a.view("<i4"), b.view("<i4"))
+
+
+@pytest.mark.parametrize("length", [16383, 16384, 16385, 32767, 32768, 32769, 15871, 15872, 15873, 8 * 16384])
+def test_record_lengths_at_tile_boundaries_with_a_run_open_at_the_end(length):
+    """The end-of-sequence event sits at position L: exactly on, just before and just after a tile boundary of the
+    perfect / window kernels (16384 bases) and of the anchored kernel (15872), with a repeat still running there."""
+    rs = np.random.RandomState(length)
+    body = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rs.randint(0, 4, size=length - 90)])
+    seq = body + (b"CAT" * 30)
+    assert len(seq) == length
+    with ribbit_amd.Scanner(2, 20) as sc, Oracle(seq, 2, 20) as o:
+        sc.load_record(seq)
+        o.run_all()
+        assert np.array_equal(sc.perfect_calls().view("<i4"), o.calls(LIST_PERFECT).view("<i4"))
+        perfect, subst, anchored = sc.processShiftXORsAnchored()
+        assert np.array_equal(perfect.view("<i4"), o.seeds(LIST_PERFECT).view("<i4"))
+        assert np.array_equal(sc.dispatch_seeds().view("<i4"), o.dispatch().view("<i4"))
