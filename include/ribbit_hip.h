@@ -362,6 +362,13 @@ int ribbit_hip_scan_perfect_end(RibbitHandle *h, RibbitRun *dst, size_t dst_cap,
                                 int wait, const RibbitRun **out, size_t *n, const RibbitRun **halves, size_t *n_halves);
 int ribbit_hip_scan_perfect_wait(RibbitHandle *h);
 
+/* Test hook: run the device-side pairing on a caller-made event stream of a record of `length` bases,
+ * as if one scan had left it in one region.  *flags = 0 for a well-formed stream, otherwise the PAIR_* bits of
+ * device_planes.h (1 malformed event, 2 duplicate chunk, 4 starts and ends do not alternate, 8 unterminated run,
+ * 16 no room); runs receives min(*n_runs, runs_cap) records. */
+int ribbit_hip_debug_pair_events(RibbitHandle *h, const uint64_t *events, size_t n, int64_t length, RibbitRun *runs, size_t runs_cap,
+                                 size_t *n_runs, uint32_t *flags);
+
 /* Test hook: the first guess of the event-buffer capacity of the scans (0 = automatic).  A guess that is too small
  * makes a scan overflow its regions, after which it is sized for the fullest region and run again. */
 int ribbit_hip_debug_set_event_capacity(RibbitHandle *h, size_t events);

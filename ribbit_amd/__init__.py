@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_stage_events", "ribbit_hip_xa_words", "ribbit_host_scan_from_events",
     "ribbit_host_perfect_runs_from_events", "ribbit_runs_free", "ribbit_hip_perfect_runs_partial",
     "ribbit_hip_scan_perfect_chunk", "ribbit_hip_host_register", "ribbit_hip_host_unregister",
-    "ribbit_hip_set_host_threads", "ribbit_hip_ssw_passes", "ribbit_hip_set_timing", "ribbit_hip_debug_set_event_capacity", "ribbit_hip_scan_perfect_begin", "ribbit_hip_scan_perfect_end", "ribbit_hip_scan_perfect_wait",
+    "ribbit_hip_set_host_threads", "ribbit_hip_ssw_passes", "ribbit_hip_set_timing", "ribbit_hip_debug_set_event_capacity", "ribbit_hip_debug_pair_events", "ribbit_hip_scan_perfect_begin", "ribbit_hip_scan_perfect_end", "ribbit_hip_scan_perfect_wait",
 ]
 
 
@@ -150,6 +150,7 @@ def load_library():
     L.ribbit_hip_set_host_threads.argtypes = [vp, i32]
     L.ribbit_hip_set_timing.argtypes = [vp, i32]
     L.ribbit_hip_debug_set_event_capacity.argtypes = [vp, C.c_size_t]
+    L.ribbit_hip_debug_pair_events.argtypes = [vp, vp, C.c_size_t, i64, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
     L.ribbit_hip_ssw_passes.argtypes = [vp, vp, C.c_size_t, C.c_char_p, C.c_size_t, i32, vp]
     L.ribbit_hip_scan_perfect_begin.argtypes = [vp, i64, i64, i64]
     L.ribbit_hip_scan_perfect_end.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int,
@@ -429,6 +430,14 @@ class Scanner:
             self.close()
         except Exception:
             pass
+
+    def debug_pair_events(self, events: np.ndarray, length: int):
+        """-> (runs, flags): the device-side pairing on a caller-made event stream (uint64 events in buffer order)"""
+        ev = np.ascontiguousarray(events, dtype="<u8")
+        runs = np.zeros(max(len(ev), 1), RUN_DT)
+        n, flags = C.c_size_t(), C.c_uint32()
+        self._check(self._L.ribbit_hip_debug_pair_events(self._h, ev.ctypes.data, len(ev), length, runs.ctypes.data, len(runs), C.byref(n), C.byref(flags)))
+        return runs[:min(n.value, len(runs))], flags.value
 
     def debug_set_event_capacity(self, events: int) -> None:
         self._check(self._L.ribbit_hip_debug_set_event_capacity(self._h, events))

@@ -1211,6 +1211,46 @@ int ribbit_hip_scan_perfect_end(RibbitHandle *h, RibbitRun *dst, size_t dst_cap,
     return RIBBIT_OK;
 }
 
+int ribbit_hip_debug_pair_events(RibbitHandle *h, const uint64_t *events, size_t n, int64_t length, RibbitRun *runs, size_t runs_cap,
+                                 size_t *n_runs, uint32_t *flags) {
+    if (!h || (n && !events) || !n_runs || !flags || (runs_cap && !runs)) return fail(RIBBIT_E_ARG, "null argument");
+    if (length < 0 || n > ((size_t)1 << 24)) return fail(RIBBIT_E_ARG, "bad size");
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    rb::PairLaunch pr{};
+    pr.m_lo = (uint32_t)h->params.min_motif;
+    pr.nm = (uint32_t)(h->params.max_motif - h->params.min_motif + 1);
+    pr.ntile = (uint32_t)(length / rb::TILE_BASES + 1);
+    pr.own_lo = 0; pr.own_hi = INT64_MAX; pr.pos_offset = 0;
+    pr.region_cap = (uint32_t)std::max<size_t>(n, 1);                  // the whole stream sits in region 0
+    const size_t entries = (size_t)pr.nm * pr.ntile, cap = (size_t)pr.region_cap * rb::EV_SHARDS;
+    DevBuf<uint64_t> d_ev, d_table, d_runs;
+    DevBuf<uint32_t> d_cnt, d_base, d_part, d_status;
+    DevBuf<RibbitRun> d_half;
+    if ((rc = d_ev.ensure(cap)) || (rc = d_table.ensure(entries)) || (rc = d_runs.ensure(cap)) || (rc = d_cnt.ensure(rb::EV_COUNTER_WORDS)) ||
+        (rc = d_base.ensure(entries)) || (rc = d_part.ensure(entries / 1024 + 2)) || (rc = d_status.ensure(rb::PAIR_STATUS_WORDS)) ||
+        (rc = d_half.ensure(2 * (size_t)pr.nm)))
+        return rc;
+    std::vector<uint32_t> counters(rb::EV_COUNTER_WORDS, 0), status(rb::PAIR_STATUS_WORDS, 0);
+    counters[0] = (uint32_t)n;
+    int ret = RIBBIT_OK;
+    do {
+        if (n && hipMemcpy(d_ev.p, events, n * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) { ret = fail(RIBBIT_E_DEVICE, "copy failed"); break; }
+        if (hipMemcpy(d_cnt.p, counters.data(), counters.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) { ret = fail(RIBBIT_E_DEVICE, "copy failed"); break; }
+        rb::launch_pair_runs(d_ev.p, d_cnt.p, pr, d_table.p, d_base.p, d_part.p, d_runs.p, (uint32_t)(cap / 2), d_half.p, 2 * pr.nm, d_status.p, h->stream);
+        if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy(status.data(), d_status.p, status.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+            ret = fail(RIBBIT_E_DEVICE, "pairing kernels failed");
+            break;
+        }
+        *flags = status[rb::PAIR_FLAGS];
+        *n_runs = status[rb::PAIR_TOTAL];
+        const size_t take = std::min(*n_runs, runs_cap);
+        if (take && hipMemcpy(runs, d_runs.p, take * sizeof(RibbitRun), hipMemcpyDeviceToHost) != hipSuccess) ret = fail(RIBBIT_E_DEVICE, "copy failed");
+    } while (false);
+    d_ev.release(); d_table.release(); d_runs.release(); d_cnt.release(); d_base.release(); d_part.release(); d_status.release(); d_half.release();
+    return ret;
+}
+
 int ribbit_hip_debug_set_event_capacity(RibbitHandle *h, size_t events) {
     if (!h) return fail(RIBBIT_E_ARG, "null argument");
     h->debug_first_cap = events;
