@@ -37,10 +37,10 @@ def _piece(rs):
     return bytes(body)
 
 
-def fuzz_case(seed: int):
-    """-> (sequence, m_lo, m_hi)"""
+def fuzz_case(seed: int, scale: int = 1):
+    """-> (sequence, m_lo, m_hi); scale > 1 stretches the records over many kernel tiles"""
     rs = np.random.RandomState(seed)
-    target = int(rs.choice([0, 1, 5, 9, 40, 300, 2000, 6000, 20000], p=[.01, .01, .02, .02, .04, .2, .4, .2, .1]))
+    target = scale * int(rs.choice([0, 1, 5, 9, 40, 300, 2000, 6000, 20000], p=[.01, .01, .02, .02, .04, .2, .4, .2, .1]))
     parts, n = [], 0
     while n < target:
         p = _piece(rs)

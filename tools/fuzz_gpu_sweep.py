@@ -1,5 +1,6 @@
 """One-off wide fuzz on the GPU box: whole path against the oracle for seeds [lo, hi) of tests/fuzz.py.
-Usage: python tools/fuzz_gpu_sweep.py <lo> <hi>  (prints mismatching seeds; progress every 200 cases)"""
+Usage: python tools/fuzz_gpu_sweep.py <lo> <hi> [scale]  (prints mismatching seeds; progress every 200 cases;
+scale stretches every record: 16 puts most of them over several 16-kb kernel tiles)"""
 import os
 import sys
 import time
@@ -14,9 +15,10 @@ from fuzz import fuzz_case
 from oracle_lib import LIST_ANCHORED, LIST_PERFECT, LIST_SUBST, Oracle
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 bad, t0 = 0, time.time()
 for seed in range(lo, hi):
-    seq, m_lo, m_hi = fuzz_case(seed)
+    seq, m_lo, m_hi = fuzz_case(seed, scale)
     with ribbit_amd.Scanner(m_lo, m_hi) as sc, Oracle(seq, m_lo, m_hi) as o:
         sc.load_record(seq)
         o.run_all()
@@ -30,6 +32,6 @@ for seed in range(lo, hi):
     if not ok:
         bad += 1
         print(f"MISMATCH seed {seed}: {len(seq)} bases -m {m_lo} -M {m_hi}", flush=True)
-    if (seed - lo) % 200 == 199:
+    if (seed - lo) % (200 if scale == 1 else 20) == (199 if scale == 1 else 19):
         print(f"... {seed - lo + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 print(f"seeds [{lo}, {hi}): {bad} mismatches")
