@@ -27,7 +27,7 @@ struct Wide {
     }
     unsigned base_at(int index_from_low) const {       // 2-bit field number index_from_low
         const int bit = 2 * index_from_low;
-        return bit >= 256 ? 0u : (unsigned)(limb[bit >> 6] >> (bit & 63)) & 3u;
+        return (bit < 0 || bit >= 256) ? 0u : (unsigned)(limb[bit >> 6] >> (bit & 63)) & 3u;
     }
 };
 
@@ -69,17 +69,19 @@ int small_atomicity(uint32_t word, int m) {
 
 // calculateAtomicityLongMotif (bitseq_utils.cpp:116-137): smallest shift f < m - m/3 with
 // unit >> 2f == low 2(m-f) bits of unit, i.e. base i == base i+f for every i with both inside the
-// low m bases ... and every higher 2-bit field of `unit` (beyond base m-1) must be zero, which holds
-// while m <= 128.
+// low m bases ... and every higher 2-bit field of `unit` (beyond base m-1) must be zero.  For m > 128 the
+// reference's 256-bit integer has dropped the leading bases of the unit and the test degenerates accordingly
+// (e.g. every f >= 128 compares zero with the masked low fields); the same arithmetic is reproduced here.
 int long_atomicity(const Wide &unit, int m) {
+    // uint256_t arithmetic of the reference, field by field: (unit >> 2f) has base i+f in field i and zeros from
+    // field 128-f on (all zeros once f >= 128); (mask & unit) keeps the fields below m-f (all 128 once m-f >= 128)
     for (int f = 1; f < m - m / 3; ++f) {
         bool same = true;
-        for (int i = 0; i < 128 - f && same; ++i) {
-            const unsigned shifted = unit.base_at(i + f);
+        for (int i = 0; i < 128 && same; ++i) {
+            const unsigned shifted = i + f < 128 ? unit.base_at(i + f) : 0u;
             const unsigned masked = i < m - f ? unit.base_at(i) : 0u;
             same = shifted == masked;
         }
-        for (int i = 128 - f; i < 128 && same; ++i) same = (i < m - f ? unit.base_at(i) : 0u) == 0u;
         if (same) return f;
     }
     return m;
