@@ -73,3 +73,72 @@ def test_cli_help_exits_1():
     assert r.returncode == 1 and "--min-motif-length" in r.stderr
     r = subprocess.run([BIN], capture_output=True, text=True)
     assert r.returncode == 1 and "Please specify an input fasta file" in r.stderr
+
+
+def _reference_tables(m_lo, m_hi, min_length=None, min_units=None, perfect_units=None):
+    """MINIMUM_LENGTH / PERFECT_UNITS as ribbit.cpp:143-174 and :210-235 fill them.  An option value is an int
+    ("same for every motif size in range") or a dict read from a two-column file."""
+    def dual(value):
+        return {k: value for k in range(m_lo, m_hi + 1)} if isinstance(value, int) else dict(value)
+    ml, pu = {}, {}
+    if min_length is not None:
+        ml = dual(min_length)
+    elif min_units is not None:
+        ml = {k: k * v for k, v in dual(min_units).items()}
+    else:
+        ml = {k: max(12, 2 * k) for k in range(m_lo, m_hi + 1)}
+    if perfect_units is not None:
+        pu = dual(perfect_units)
+    else:
+        pu = {m: {1: 8, 2: 4, 3: 3}.get(m, 2) for m in range(1, m_hi + 1)}
+    for m in range(m_lo, m_hi + 1):
+        for f in range(1, m // 2 + 1):
+            if m % f:
+                continue
+            if f not in ml:
+                ml[f] = ml.setdefault(m, 0)          # operator[] inserts 0 for a missing key
+            if f not in pu:
+                pu[f] = pu.setdefault(m, 0) * (m // f)
+    return ml, pu
+
+
+def _oracle_params(m_lo, m_hi, ml, pu):
+    from oracle_lib import RefineParams as OracleRefineParams
+    import ctypes as C
+    from oracle_lib import lib
+    rp = OracleRefineParams()
+    lib().rbo_refine_params_default(C.byref(rp), m_lo, m_hi)
+    for k in range(1024):
+        rp.min_length[k] = ml.get(k, 0)
+        rp.perfect_units[k] = pu.get(k, 0)
+    return rp
+
+
+@pytest.mark.parametrize("label,m_lo,m_hi,flags,tables", [
+    ("min_length_number", 2, 12, ["-l", "20"], dict(min_length=20)),
+    ("min_units_number", 2, 12, ["--min-units", "4"], dict(min_units=4)),
+    ("perfect_units_number", 3, 12, ["--perfect-units", "3"], dict(perfect_units=3)),
+    ("both_numbers", 4, 30, ["--min-units=3", "--perfect-units", "2"], dict(min_units=3, perfect_units=2)),
+    ("files", 2, 10, None, dict(min_units={2: 8, 3: 5, 4: 4, 5: 4, 6: 3, 8: 3, 10: 2}, perfect_units={2: 5, 3: 4, 4: 3, 5: 3, 6: 2, 7: 2, 9: 2})),
+])
+def test_cli_length_and_unit_options_follow_the_reference_tables(tmp_path, label, m_lo, m_hi, flags, tables):
+    """-l / --min-units / --perfect-units as numbers and as two-column files (ribbit.cpp:25-64,143-174), incl. the
+    completion of the tables for factors of the selected motif sizes (:210-235): BED against the oracle pipeline
+    run with the tables a restatement of those lines produces."""
+    seq = simulated_cases()[2][1] + simulated_cases()[0][1][:40_000]
+    fa, bed = tmp_path / "in.fa", tmp_path / "out.bed"
+    write_fasta(str(fa), [("rec", seq)])
+    if flags is None:
+        flags = []
+        for opt, key in (("--min-units", "min_units"), ("--perfect-units", "perfect_units")):
+            path = tmp_path / f"{key}.tsv"
+            path.write_text("".join(f"{k}\t{v}\n" for k, v in tables[key].items()))
+            flags += [opt, str(path)]
+    r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed), "-m", str(m_lo), "-M", str(m_hi)] + flags, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ml, pu = _reference_tables(m_lo, m_hi, **tables)
+    with Oracle(seq, m_lo, m_hi) as o:
+        o.run_all()
+        want = o.refine_bed("rec", _oracle_params(m_lo, m_hi, ml, pu))
+    assert bed.read_text() == want
+    assert want.count("\n") > 20
