@@ -41,3 +41,30 @@ def test_merges_and_bed_rows_agree_with_the_oracle_on_fuzzed_records(block):
             if HAVE_REF_SSW and len(seq):
                 got = ribbit_amd.host_refine_bed(m_lo, m_hi, seq, xa, stride, o.dispatch(), "fz")
                 assert got.split("\n") == o.refine_bed("fz").split("\n"), tag
+
+
+def test_refinement_with_random_length_and_unit_tables_agrees_with_the_oracle():
+    """MINIMUM_LENGTH / PERFECT_UNITS other than the defaults (what -l / --min-units / --perfect-units set)."""
+    import ctypes as C
+    from oracle_lib import RefineParams as OracleRefineParams, lib as oracle_lib_handle
+    if not HAVE_REF_SSW:
+        pytest.skip("oracle/_ref/libssw_ref.so not built")
+    for seed in range(12000, 12040):
+        seq, m_lo, m_hi = fuzz_case(seed)
+        if len(seq) < 40:
+            continue
+        rs = np.random.RandomState(seed)
+        style = rs.randint(0, 3)
+        orp, prp = OracleRefineParams(), ribbit_amd.RefineParams()
+        oracle_lib_handle().rbo_refine_params_default(C.byref(orp), m_lo, m_hi)
+        ribbit_amd.load_library().ribbit_refine_params_default(C.byref(prp), m_lo, m_hi)
+        for k in range(1024):
+            ml = int(rs.randint(0, 40)) if style == 0 else k * int(rs.randint(1, 6)) if style == 1 else orp.min_length[k]
+            pu = int(rs.randint(0, 6)) if style != 1 else orp.perfect_units[k]
+            orp.min_length[k] = prp.min_length[k] = ml
+            orp.perfect_units[k] = prp.perfect_units[k] = pu
+        with Oracle(seq, m_lo, m_hi) as o:
+            o.run_all()
+            xa, stride = ribbit_amd.pack_bit_planes([o.plane(m) for m in range(m_lo, m_hi + 1)], len(seq))
+            got = ribbit_amd.host_refine_bed(m_lo, m_hi, seq, xa, stride, o.dispatch(), "fz", prp)
+            assert got.split("\n") == o.refine_bed("fz", orp).split("\n"), f"seed {seed} style {style}"
