@@ -142,3 +142,41 @@ def test_cli_length_and_unit_options_follow_the_reference_tables(tmp_path, label
         want = o.refine_bed("rec", _oracle_params(m_lo, m_hi, ml, pu))
     assert bed.read_text() == want
     assert want.count("\n") > 20
+
+
+def test_cli_reads_fasta_the_way_getline_does(tmp_path):
+    """ribbit.cpp:269-280: every line that does not start with '>' is appended as it is -- blank lines add nothing,
+    a carriage return (Windows line ends) becomes a base that encodes as N, the name is the header up to the first
+    space (the whole rest of the line, carriage return included, when there is none)."""
+    sims = simulated_cases()
+    a, b, c = sims[0][1][:30_000], sims[2][1][:30_000], sims[1][1][:20_000]
+
+    def wrap(seq, width, eol):
+        return b"".join(seq[i:i + width] + eol for i in range(0, len(seq), width))
+
+    text = (b">chrA description with spaces\n" + wrap(a, 60, b"\n") + b"\n\n"
+            + b">chrB\r\n" + wrap(b, 70, b"\r\n")
+            + b">chrC\tTabbed\n" + wrap(c, 80, b"\n") + c[:10])            # no newline at the end of the file
+    fa, bed = tmp_path / "in.fa", tmp_path / "out.bed"
+    fa.write_bytes(text)
+    r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "12"], capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # what the reader hands to processSequence
+    records, name, seq = [], None, b""
+    for line in text.split(b"\n"):
+        if line[:1] == b">":
+            if seq:
+                records.append((name, seq))
+            sp = line.find(b" ")
+            name, seq = (line[1:] if sp < 0 else line[1:sp]), b""
+        else:
+            seq += line
+    records.append((name, seq))
+    assert [n for n, _ in records] == [b"chrA", b"chrB\r", b"chrC\tTabbed"] and b"\r" in records[1][1]
+    want = b""
+    for n, s in records:
+        with Oracle(s, 2, 12) as o:
+            o.run_all()
+            want += o.refine_bed(n.decode()).encode()
+    assert bed.read_bytes() == want and want.count(b"\n") > 100
+    assert r.stderr.count(b"Processing sequence") == 2                       # not for the last record (:280)
