@@ -81,7 +81,8 @@ class SeedLists(C.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libribbit_hip.so")
+    # RIBBIT_HIP_LIBRARY: another build of the same library (the sanitizer build of the CPU tests)
+    return os.environ.get("RIBBIT_HIP_LIBRARY") or os.path.join(_HERE, "libribbit_hip.so")
 
 
 _lib = None

@@ -1,0 +1,51 @@
+"""The host half of the product (seed merges, window state machines, refinement, own Smith-Waterman, BED writer) under
+AddressSanitizer + UBSan: `make -C ribbit_amd/csrc asan` builds the library with its HOST code instrumented, and a
+child interpreter replays oracle call logs through the host-only entry points on adversarial records, including the
+motif sizes above 192 bases whose atomicity test once read out of bounds.  (GPU sanitizers are not available on the
+pool; the kernels are covered by the parity tests.)"""
+import glob
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ASAN_SO = os.path.join(ROOT, "ribbit_amd", "libribbit_hip_asan.so")
+
+CHILD = r"""
+import sys
+sys.path[:0] = [%(tests)r, %(root)r]
+import numpy as np
+import ribbit_amd
+from fuzz import fuzz_case
+from oracle_lib import LIST_ANCHORED, LIST_PERFECT, LIST_SUBST, Oracle
+cases = [(s, 1) for s in range(9000, 9040)] + [(82531, 16), (86001, 16), (86007, 16)]
+for seed, scale in cases:
+    seq, m_lo, m_hi = fuzz_case(seed, scale)
+    with Oracle(seq, m_lo, m_hi) as o:
+        o.run_perfect(); pc = o.calls(LIST_PERFECT)
+        o.run_subst(); sc = o.calls(LIST_SUBST)
+        o.run_anchor_planes()
+        xa, stride = ribbit_amd.pack_bit_planes([o.plane(m) for m in range(m_lo, m_hi + 1)], len(seq))
+        o.run_anchored(); o.run_dispatch()
+        r = ribbit_amd.host_replay_calls(m_lo, m_hi, seq, pc, sc, o.calls(LIST_ANCHORED), xa, stride)
+        assert np.array_equal(r["dispatch"].view("<i4"), o.dispatch().view("<i4")), seed
+        if len(seq):
+            ribbit_amd.host_refine_jobs(m_lo, m_hi, seq, xa, stride, o.dispatch())
+            assert ribbit_amd.host_refine_bed(m_lo, m_hi, seq, xa, stride, o.dispatch(), "fz") == o.refine_bed("fz"), seed
+print("host-sanitizer-run-ok")
+"""
+
+
+def test_host_code_clean_under_sanitizers():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "ribbit_amd", "csrc"), "asan"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and os.path.exists(ASAN_SO), r.stderr[-3000:]
+    rts = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    if not rts:
+        pytest.skip("clang's shared ASan runtime not found")
+    env = dict(os.environ, LD_PRELOAD=rts[0], RIBBIT_HIP_LIBRARY=ASAN_SO, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([sys.executable, "-c", CHILD % {"tests": os.path.join(ROOT, "tests"), "root": ROOT}], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "host-sanitizer-run-ok" in out.stdout, out.stderr[-4000:]
