@@ -57,6 +57,9 @@ struct u256 {
 struct View {
     const uint8_t *code, *nmask;
     int L;
+    /* D4: a position below 0 (reachable only after a motif window that starts before the record, where the
+     * reference has already terminated in substr) reads as base A, not N */
+    uint8_t code_at(int p) const { return p < 0 ? 0 : code[p]; }
 };
 
 /* longestContinuousMatches, parse_seed.cpp:26-44 (on the bits of plane[start..end)) */
@@ -126,7 +129,7 @@ void possible_motifs(const View &v, int seed_start, int seed_sequence_length, in
     const int min_len = prm.min_length[m], min_units = prm.perfect_units[m];
     uint32_t window = 0;
     for (int j = seed_start; j < seed_end; j++) {
-        window = (window & ~3u) | v.code[j];                                            /* :99 window[0]=right, [1]=left */
+        window = (window & ~3u) | v.code_at(j);                                         /* :99 window[0]=right, [1]=left */
         const uint32_t motif = repeat_class(window, m);
         const int wstart = j - (m - 1), wend = j + 1;
         const uint32_t next = ((window << 2) | (window >> ((m - 1) * 2))) & wmask;      /* :115 */
@@ -456,7 +459,7 @@ int motif_units_of(const View &v, int start, int length, int m, uint32_t unit) {
     const uint32_t wmask = (m >= 16) ? 0xffffffffu : ((1u << (2 * m)) - 1u);
     uint32_t window = 0;
     for (int j = start; j < seed_end; j++) {
-        window = (window & ~3u) | v.code[j];
+        window = (window & ~3u) | v.code_at(j);
         if (j - start >= (0.9 * m) - 1) {
             const uint32_t motif = repeat_class(window, m);
             if (pos.find(motif) == pos.end()) { pos[motif] = j - (m - 1); units[motif] = 1; }

@@ -42,8 +42,10 @@ struct Bases {
             sym[(size_t)p] = (hp.brk[w] & bit) ? 4 : (uint8_t)((((hp.hi[w] & bit) != 0) << 1) | ((hp.lo[w] & bit) != 0));
         }
     }
-    unsigned code(int p) const { return sym[(size_t)p] & 3u; }       // N encodes as 00 (fasta_utils.cpp:111-113)
-    bool is_n(int p) const { return p < L && sym[(size_t)p] == 4; }
+    // N encodes as 00 (fasta_utils.cpp:111-113).  D4: a position below 0 -- reachable only after a motif window that
+    // starts before the record, where the reference has already terminated in substr -- reads as base A, not N.
+    unsigned code(int p) const { return p < 0 ? 0u : sym[(size_t)p] & 3u; }
+    bool is_n(int p) const { return p >= 0 && p < L && sym[(size_t)p] == 4; }
 };
 
 // calculateRepeatClass (bitseq_utils.cpp:185-221): lexicographically smallest rotation of an m-base word

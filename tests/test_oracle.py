@@ -138,10 +138,15 @@ def test_oracle_clean_under_sanitizers():
         "import oracle_lib, cases\n"
         "oracle_lib._lib = None\n"
         "oracle_lib.build = lambda asan=False: %r\n"
-        "for name, seq, lo, hi in cases.edge_cases():\n"
+        "import fuzz\n"
+        "todo = [(seq, lo, hi) for name, seq, lo, hi in cases.edge_cases()]\n"
+        "todo += [fuzz.fuzz_case(s) for s in range(130000, 130060)] + [fuzz.fuzz_case(82531, 16)]\n"
+        "for seq, lo, hi in todo:\n"
         "    with oracle_lib.Oracle(seq, lo, hi) as o:\n"
         "        o.run_all()\n"
-        "        o.refine_jobs()\n"
+        "        if len(seq):\n"
+        "            o.refine_jobs()\n"
+        "            o.refine_bed('x')\n"
         "print('sanitizer-run-ok')\n"
     ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), so)
     asan_rt = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
