@@ -302,16 +302,15 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
 // Alignment post-processing and BED rows
 namespace {
 
-// RIBBIT_PROFILE=1: wall-clock split of the refinement stages on stderr
+// RIBBIT_PROFILE=1: wall-clock split of the refinement stages on stderr (summed over the worker threads)
+std::atomic<long long> g_t_align{0}, g_t_small{0}, g_t_long{0};       // nanoseconds
+std::atomic<long> g_n_align{0}, g_n_known{0};
 struct Stopwatch {
-    double *acc;
+    std::atomic<long long> *acc;
     std::chrono::steady_clock::time_point t0;
-    explicit Stopwatch(double *a) : acc(a), t0(std::chrono::steady_clock::now()) {}
-    ~Stopwatch() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    explicit Stopwatch(std::atomic<long long> *a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~Stopwatch() { acc->fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed); }
 };
-// (profiling only; the sums are racy across threads and therefore approximate)
-double g_t_align = 0, g_t_small = 0, g_t_long = 0;
-long g_n_align = 0, g_n_known = 0;
 
 struct CigarOp { int len; char op; };
 
@@ -565,7 +564,7 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
     }
     if (std::getenv("RIBBIT_PROFILE"))
         std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld (%ld with GPU passes)  (summed over threads) align %.2fs  small-motif discovery %.2fs  long-motif consensus %.2fs\n",
-                     dispatch.size(), threads, g_n_align, g_n_known, g_t_align, g_t_small, g_t_long);
+                     dispatch.size(), threads, g_n_align.load(), g_n_known.load(), g_t_align.load() * 1e-9, g_t_small.load() * 1e-9, g_t_long.load() * 1e-9);
 }
 
 }  // namespace rb
