@@ -292,36 +292,39 @@ int collect_events(RibbitHandle *h, int which) {
     h->last_event_count = produced;
     h->produced = produced;
     if ((rc = h->h_events.ensure(std::max<size_t>(produced, 1)))) return rc;
+    // Events arrive as position-ordered chunks, exactly one per (motif, tile) that has any event.  A kernel indexes
+    // them in a direct-address table keyed (motif, tile) -- every event looks at its neighbours -- so the host
+    // neither sorts nor walks the events to find the chunks.
+    const uint32_t m_lo = (uint32_t)h->params.min_motif;
+    const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
+    const uint32_t tile_bases = which == 2 ? (uint32_t)rb::anchored_tile_words(rb::anchored_halo_lanes(h->params.max_motif)) * 32u
+                                           : (uint32_t)rb::TILE_BASES;
+    const size_t ntile = (size_t)(h->length / tile_bases + 1);
+    if (nm * ntile > 0xfffffff0u) return fail(RIBBIT_E_ARG, "record too long for %zu motif sizes", nm);
+    if ((rc = h->d_pair_table.ensure(nm * ntile))) return rc;
+    if ((rc = h->d_pair_status.ensure(rb::PAIR_STATUS_WORDS))) return rc;
+    rb::launch_chunk_table(h->d_dense.p, h->d_counters.p, m_lo, (uint32_t)nm, (uint32_t)ntile, tile_bases, h->d_pair_table.p, h->d_pair_status.p, h->stream);
+    HIP_TRY(hipGetLastError());
+    h->chunk_table.resize(nm * ntile);
+    h->table_ntile = ntile;
+    uint32_t table_status = 0;
+    HIP_TRY(hipMemcpyAsync(h->chunk_table.data(), h->d_pair_table.p, nm * ntile * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&table_status, h->d_pair_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     if (produced) {
         HIP_TRY(hipMemcpyAsync(h->h_events.p, h->d_dense.p, (size_t)produced * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     }
     HIP_TRY(hipEventRecord(h->ev[5], h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->have_timing[1] = h->have_timing[2] = true;
-
-    // Events arrive as position-ordered chunks, exactly one per (motif, tile) that has any event.
-    // Index them in a direct-address table keyed (motif, tile): O(events), no sort.
-    const uint64_t *ev = h->h_events.p;
-    const uint32_t m_lo = (uint32_t)h->params.min_motif;
-    const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
-    const uint32_t tile_bases = which == 2 ? (uint32_t)rb::anchored_tile_words(rb::anchored_halo_lanes(h->params.max_motif)) * 32u
-                                           : (uint32_t)rb::TILE_BASES;
-    const size_t ntile = (size_t)(h->length / tile_bases + 1);
+    if (table_status & 1u) return fail(RIBBIT_E_INTERNAL, "malformed event (motif or tile outside the launch)");
+    if (table_status & 2u) return fail(RIBBIT_E_INTERNAL, "duplicate event chunk");
+    // {first + 1, end}  ->  {offset, count}
     struct Chunk { uint32_t off, n; };
     static_assert(sizeof(Chunk) == sizeof(uint64_t), "chunk table entry is one 64-bit word");
-    h->chunk_table.assign(nm * ntile, 0);
-    h->table_ntile = ntile;
     Chunk *table = reinterpret_cast<Chunk *>(h->chunk_table.data());
-    for (size_t i = 0; i < produced;) {
-        const uint32_t m = rb::ev_mlen(ev[i]);
-        const uint32_t tile = rb::ev_pos(ev[i]) / tile_bases;
-        size_t j = i + 1;
-        while (j < produced && rb::ev_mlen(ev[j]) == m && rb::ev_pos(ev[j]) / tile_bases == tile) ++j;
-        if (m < m_lo || m - m_lo >= nm || tile >= ntile) return fail(RIBBIT_E_INTERNAL, "malformed event (motif %u, tile %u)", m, tile);
-        const size_t key = (size_t)(m - m_lo) * ntile + tile;
-        if (table[key].n) return fail(RIBBIT_E_INTERNAL, "duplicate event chunk (motif %u, tile %u)", m, tile);
-        table[key] = Chunk{(uint32_t)i, (uint32_t)(j - i)};
-        i = j;
+    for (size_t k = 0; k < nm * ntile; ++k) {
+        const uint32_t first1 = table[k].off, end = table[k].n;
+        table[k] = first1 ? Chunk{first1 - 1u, end - (first1 - 1u)} : Chunk{0, 0};
     }
     return RIBBIT_OK;
 }

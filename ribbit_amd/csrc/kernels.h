@@ -61,6 +61,11 @@ void launch_pair_runs(const uint64_t *events, const uint32_t *counters, const Pa
 // host_words (page-locked, device-visible): [0, EV_SHARDS) the region counters, then PAIR_STATUS_WORDS status words
 void launch_pair_publish(const uint32_t *counters, const uint32_t *status, uint32_t *host_words, hipStream_t stream);
 
+// After launch_compact_events: table[(motif - m_lo) * ntile + tile] = {first event index + 1, index past the last event}
+// of that (motif, tile) chunk of `dense` (both 0: no chunk); *status != 0: malformed stream.
+void launch_chunk_table(const uint64_t *dense, const uint32_t *counters, uint32_t m_lo, uint32_t nm, uint32_t ntile,
+                        uint32_t tile_bases, void *table, uint32_t *status, hipStream_t stream);
+
 // X_shift words [w0, w0+nw) -> out_words (device); if count != nullptr also adds the popcount of
 // bits in [p0, p1) to *count.
 void launch_plane_words(const DevicePlanes &pl, int shift, int64_t w0, int64_t nw, uint32_t *out_words,

@@ -880,6 +880,35 @@ __global__ __launch_bounds__(256) void compact_events_kernel(const uint64_t *__r
     }
 }
 
+// (motif, tile) chunk table of the compacted event buffer of a window scan, for the host replay: entry
+// (motif - m_lo) * ntile + tile = {index of the chunk's first event, index past its last}.  The host used to find
+// the chunk boundaries by walking all events (0.9 G of them for a 250-Mbp record); here every event looks at its
+// neighbours instead.  status: bit 0 malformed event, bit 1 a (motif, tile) pair with two chunks.
+__global__ __launch_bounds__(256) void chunk_table_kernel(const uint64_t *__restrict__ dense, const uint32_t *__restrict__ counters,
+                                                          uint32_t m_lo, uint32_t nm, uint32_t ntile, uint32_t tile_bases,
+                                                          uint2 *__restrict__ table, uint32_t *__restrict__ status) {
+    const uint32_t n = counters[EV_SUMMARY];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint64_t e = dense[i];
+        const uint32_t mi = ev_mlen(e) - m_lo, tile = ev_pos(e) / tile_bases;
+        if (mi >= nm || tile >= ntile) { atomicOr(status, 1u); continue; }
+        const uint32_t key = mi * ntile + tile;
+        bool first = i == 0, last = i + 1 == n;
+        if (!first) { const uint64_t p = dense[i - 1]; first = ev_mlen(p) - m_lo != mi || ev_pos(p) / tile_bases != tile; }
+        if (!last) { const uint64_t q = dense[i + 1]; last = ev_mlen(q) - m_lo != mi || ev_pos(q) / tile_bases != tile; }
+        if (first && atomicExch(&table[key].x, i + 1u) != 0u) atomicOr(status, 2u);      // stored + 1: 0 = no chunk
+        if (last) table[key].y = i + 1u;
+    }
+}
+
+void launch_chunk_table(const uint64_t *dense, const uint32_t *counters, uint32_t m_lo, uint32_t nm, uint32_t ntile,
+                        uint32_t tile_bases, void *table, uint32_t *status, hipStream_t stream) {
+    (void)hipMemsetAsync(table, 0, (size_t)nm * ntile * sizeof(uint2), stream);
+    (void)hipMemsetAsync(status, 0, sizeof(uint32_t), stream);
+    hipLaunchKernelGGL(chunk_table_kernel, dim3(4096), dim3(256), 0, stream, dense, counters, m_lo, nm, ntile, tile_bases,
+                       (uint2 *)table, status);
+}
+
 void launch_compact_events(const uint64_t *events, uint32_t ev_cap, uint32_t *counters, uint64_t *dense,
                            hipStream_t stream) {
     hipLaunchKernelGGL(compact_events_kernel, dim3(EV_SHARDS, 16), dim3(256), 0, stream, events,
