@@ -551,8 +551,8 @@ int advance_to_subst(RibbitHandle *h) {
 // fused anchored kernel (anchor planes + composition + 6-of-8 window scan) + state machine ->
 // the addSeed call list of processShiftXORsAnchored (parse_anchored_shiftxor.cpp:580-723); also
 // materialises the composed planes XA_m and copies them to the host for the merges' range reads.
-int build_anchored_calls(RibbitHandle *h) {
-    if (h->anchored_calls_valid) return RIBBIT_OK;
+// fused anchored kernel, its events and the composed planes on the host (what both replays below start from)
+int scan_anchored_events(RibbitHandle *h) {
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
     if (h->params.max_motif > rb::ANCHORED_MAX_MOTIF)
         return fail(RIBBIT_E_ARG, "the anchored stage of this build supports max_motif <= %d (got %d)", rb::ANCHORED_MAX_MOTIF, h->params.max_motif);
@@ -571,6 +571,13 @@ int build_anchored_calls(RibbitHandle *h) {
     h->host.xa_m_hi = h->params.max_motif;
     HIP_TRY(hipMemcpyAsync(h->h_xa.p, h->d_xa.p, nm * (size_t)h->xa_stride * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return RIBBIT_OK;
+}
+
+int build_anchored_calls(RibbitHandle *h) {
+    if (h->anchored_calls_valid) return RIBBIT_OK;
+    int rc = scan_anchored_events(h);
+    if (rc) return rc;
     const double t0 = now_ms();
     std::string why;
     if (!rb::replay_window_events(event_source(h), h->host, h->anchored_calls, &why, h->host_threads)) return fail(RIBBIT_E_INTERNAL, "%s", why.c_str());
@@ -583,42 +590,78 @@ int build_anchored_calls(RibbitHandle *h) {
 // but the end-of-sequence flush keeps the returned cursors only for the first of the two calls it
 // makes when a motif has both a pending group and an unmerged open streak
 // (parse_anchored_shiftxor.cpp:713 vs :688,:697,:706,:717).
-void replay_anchored_calls(rb::SeedLists &lists, const rb::CallVec &calls, int64_t length) {
+struct AnchoredReplay {
+    rb::SeedLists &lists;
     rb::Cursor2 cur;
     int pending_end = -1;   // largest seed_end among in-loop calls that only moved the cursors (:133-153)
-    auto catch_up = [&]() {
+    void catch_up() {
         if (pending_end < 0) return;
         cur.perfect = rb::advance_cursor(lists.perfect, cur.perfect, pending_end);
         cur.subst = rb::advance_cursor(lists.subst, cur.subst, pending_end);
         pending_end = -1;
-    };
-    for (size_t i = 0; i < calls.size(); ++i) {
-        const RibbitCall &c = calls[i];
-        const bool flush = c.pos == (int32_t)length;
-        const bool first_of_two = flush && i + 1 < calls.size() && calls[i + 1].pos == c.pos && calls[i + 1].mlen == c.mlen;
-        const bool keeps_cursor = !flush || first_of_two;
+    }
+    void call(const RibbitCall &c, bool keeps_cursor) {
         if (c.end - c.start < rb::anchored_seedlen_cutoff(c.mlen)) {
             if (keeps_cursor) pending_end = std::max(pending_end, c.end);
-            continue;
+            return;
         }
         catch_up();
         const rb::Cursor2 next = rb::anchored_add(lists, c.start, c.end, c.mlen, cur, RIBBIT_RANK_A);
         if (keeps_cursor) cur = next;
     }
+    // calls[first, n): the tail of a call list that may hold the end-of-sequence flush
+    void run(const RibbitCall *calls, size_t n, int64_t length) {
+        for (size_t i = 0; i < n; ++i) {
+            const RibbitCall &c = calls[i];
+            const bool flush = c.pos == (int32_t)length;
+            const bool first_of_two = flush && i + 1 < n && calls[i + 1].pos == c.pos && calls[i + 1].mlen == c.mlen;
+            call(c, !flush || first_of_two);
+        }
+    }
+};
+
+void replay_anchored_calls(rb::SeedLists &lists, const rb::CallVec &calls, int64_t length) {
+    AnchoredReplay r{lists, rb::Cursor2{}};
+    r.run(calls.data(), calls.size(), length);
+}
+
+// the same from the compact form (event_stream.h): only the calls that pass the length filter were kept, each with
+// the largest end of the filtered-out calls before it
+void replay_anchored_compact(rb::SeedLists &lists, const rb::CompactCalls &cc, int64_t length) {
+    AnchoredReplay r{lists, rb::Cursor2{}};
+    for (size_t i = 0; i < cc.calls.size(); ++i) {
+        r.pending_end = std::max(r.pending_end, cc.pend_before[i]);
+        r.call(cc.calls[i], true);
+    }
+    r.pending_end = std::max(r.pending_end, cc.tail_pend);
+    r.run(cc.flush.data(), cc.flush.size(), length);
 }
 
 int advance_to_anchored(RibbitHandle *h) {
     if (h->stage_done >= STAGE_ANCHORED) return RIBBIT_OK;
     int rc = advance_to_subst(h);
     if (rc) return rc;
-    if ((rc = build_anchored_calls(h))) return rc;
+    // the full call list only when it has been asked for (ribbit_hip_anchored_calls); otherwise the compact form:
+    // nine calls in ten fail the length filter and are never materialised
+    rb::CompactCalls compact;
+    const bool full = h->anchored_calls_valid;
+    if (!full) {
+        if ((rc = scan_anchored_events(h))) return rc;
+        const double t0 = now_ms();
+        std::string why;
+        rb::CallVec unused;
+        if (!rb::replay_window_events(event_source(h), h->host, unused, &why, h->host_threads, &compact, rb::anchored_seedlen_cutoff))
+            return fail(RIBBIT_E_INTERNAL, "%s", why.c_str());
+        h->host_ms = now_ms() - t0;
+    }
     const rb::HostPlanes *hp = &h->host;
     // from here on "plane m" means the composed plane XA_m (fasta_utils.cpp:159)
     h->lists.range_count = [hp](int shift, int start, int end) {
         return hp->has_xa(shift) ? hp->range_count_xa(shift, start, end) : hp->range_count(shift, start, end);
     };
     h->lists.anchored.clear();
-    replay_anchored_calls(h->lists, h->anchored_calls, h->length);
+    if (full) replay_anchored_calls(h->lists, h->anchored_calls, h->length);
+    else replay_anchored_compact(h->lists, compact, h->length);
     rb::dispatch_order(h->lists, h->dispatch);
     h->stage_done = STAGE_ANCHORED;
     return RIBBIT_OK;

@@ -69,3 +69,20 @@ def test_all_composed_planes_at_large_motifs(name, seq, m_lo, m_hi):
         sc.anchored_calls()
         for m in range(m_lo, m_hi + 1, 7):
             assert np.array_equal(sc.plane_bits(m), o.plane(m)), f"composed plane {m}"
+
+
+@pytest.mark.parametrize("name,seq,m_lo,m_hi", ALL, ids=[c[0] for c in ALL])
+def test_seed_lists_without_asking_for_the_call_list_first(name, seq, m_lo, m_hi):
+    """processShiftXORsAnchored straight after load: the anchored calls then only exist in their compact form
+    (calls that fail the length filter are never materialised, only the largest end between two kept calls)."""
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc, Oracle(seq, m_lo, m_hi) as o:
+        sc.load_record(seq)
+        o.run_all()
+        perfect, subst, anchored = sc.processShiftXORsAnchored()
+        assert np.array_equal(perfect.view("<i4"), o.seeds(LIST_PERFECT).view("<i4"))
+        assert np.array_equal(subst.view("<i4"), o.seeds(LIST_SUBST).view("<i4"))
+        assert np.array_equal(anchored.view("<i4"), o.seeds(LIST_ANCHORED).view("<i4"))
+        assert np.array_equal(sc.dispatch_seeds().view("<i4"), o.dispatch().view("<i4"))
+        assert sc.guard_hits() == o.guard_hits()
+        # and the full list is still available afterwards
+        assert np.array_equal(sc.anchored_calls().view("<i4"), o.calls(LIST_ANCHORED).view("<i4"))
