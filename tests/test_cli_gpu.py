@@ -180,3 +180,16 @@ def test_cli_reads_fasta_the_way_getline_does(tmp_path):
             want += o.refine_bed(n.decode()).encode()
     assert bed.read_bytes() == want and want.count(b"\n") > 100
     assert r.stderr.count(b"Processing sequence") == 2                       # not for the last record (:280)
+
+
+def test_whole_path_on_a_two_megabase_record_matches_oracle():
+    """Scale check of the whole path (scans, compact anchored calls, merges, refinement on worker threads, BED) on
+    a record of ~125 kernel tiles with N blocks and lower case, against the oracle pipeline."""
+    from ribbit_amd.simulate import simulate_sequence
+    seq, _ = simulate_sequence(2_000_000, 97, 2, 100, n_block_rate=0.2, lower_rate=0.2)
+    with ribbit_amd.Scanner(2, 100) as sc, Oracle(seq, 2, 100) as o:
+        sc.load_record(seq)
+        o.run_all()
+        got = sc.refine_bed("chrTest")
+        want = o.refine_bed("chrTest")
+    assert got == want and want.count("\n") > 15_000
