@@ -11,6 +11,17 @@ import ribbit_amd
 from oracle_lib import Oracle
 from ribbit_amd.simulate import simulate_sequence
 
+import threading
+
+
+def _heartbeat():
+    t0 = time.time()
+    while True:
+        time.sleep(60)
+        print(f"... {time.time() - t0:.0f} s", flush=True)
+
+
+threading.Thread(target=_heartbeat, daemon=True).start()
 bases = int(sys.argv[1])
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 seq, _ = simulate_sequence(bases, seed, 2, 100, n_block_rate=0.1, lower_rate=0.1)
