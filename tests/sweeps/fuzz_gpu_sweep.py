@@ -1,5 +1,5 @@
 """One-off wide fuzz on the GPU box: whole path against the oracle for seeds [lo, hi) of tests/fuzz.py.
-Usage: python tools/fuzz_gpu_sweep.py <lo> <hi> [scale]  (prints mismatching seeds; progress every 200 cases;
+Usage: python tests/sweeps/fuzz_gpu_sweep.py <lo> <hi> [scale]  (prints mismatching seeds; progress every 200 cases;
 scale stretches every record: 16 puts most of them over several 16-kb kernel tiles)"""
 import os
 import sys
@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ribbit_amd

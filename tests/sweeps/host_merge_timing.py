@@ -1,14 +1,14 @@
 """Time the product's host-side merges on this machine's CPU (no GPU): the oracle produces the call logs and
 the composed planes of a simulated record, ribbit_host_replay_calls replays them.  Usage:
-    python tools/host_merge_timing.py [bases=2000000]"""
+    python tests/sweeps/host_merge_timing.py [bases=2000000]"""
 import os
 import sys
 import time
 
 import numpy as np
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import ribbit_amd
 from ribbit_amd.simulate import simulate_sequence
 from oracle_lib import LIST_ANCHORED, LIST_PERFECT, LIST_SUBST, Oracle

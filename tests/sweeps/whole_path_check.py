@@ -1,10 +1,10 @@
 """One-off scale check on the GPU box: the whole path on a simulated record against the oracle pipeline.
-Usage: python tools/whole_path_check.py <bases> [seed]   (the oracle needs ~10 s per Mbp)"""
+Usage: python tests/sweeps/whole_path_check.py <bases> [seed]   (the oracle needs ~10 s per Mbp)"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ribbit_amd
