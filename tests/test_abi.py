@@ -34,9 +34,12 @@ def test_abi_version_and_defaults(hip_lib):
 
 def test_no_oracle_dependency_in_product():
     # the product must never link, import or call oracle/ code
-    for dirpath, _, files in os.walk(os.path.join(ROOT, "ribbit_amd")):
+    # (tools/ is not product either, but it is not test infrastructure: the scripts there must not use the oracle;
+    #  the checkers that do live under tests/sweeps/)
+    for top in ("ribbit_amd", "tools"):
+      for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
         for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+            if f.endswith((".py", ".sh", ".cpp", ".hip", ".h", "Makefile")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_lib" not in src and "ribbit_oracle" not in src and "rbo_" not in src, os.path.join(dirpath, f)
     import subprocess
