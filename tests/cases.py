@@ -83,3 +83,23 @@ def large_motif_cases():
         ("M990_long_units", _rand(1500, 63) + _rand(800, 64) * 3 + _rand(600, 65) + _mutate(_rand(600, 66), 4, 0.03, 67) + _rand(900, 68), 500, 990),
         ("M111_first_above_one_halo_lane", big[:6000], 90, 111),
     ]
+
+
+def structured_cases():
+    """Long regular structures: runs that span many kernel tiles (the pairing kernel's search for a run's END over
+    empty tiles, all-ones lanes in the anchored kernel's run-length scan), periodic N, a record that is mostly N."""
+    homo = _rand(700, 71) + b"A" * 40_000 + _rand(900, 72)        # > 2 kernel tiles; the merges are quadratic in such a run
+    dinuc = bytearray(b"AC" * 30_000)
+    for p in range(4_999, len(dinuc), 5_000):
+        dinuc[p] = ord("G")                                   # one mismatch every 5 kb
+    dinuc = _rand(500, 73) + bytes(dinuc) + _rand(500, 74)
+    n_every = bytearray(simulate_sequence(150_000, 75, 2, 40)[0])
+    n_every[::1000] = b"N" * len(n_every[::1000])
+    mostly_n = b"N" * 65_000 + b"CAG" * 400 + b"N" * 70_000 + _rand(3_000, 76) + b"TTAGGG" * 300 + b"N" * 20_000
+    return [
+        ("homopolymer_40k_small_m", homo, 2, 20),
+        ("homopolymer_40k_large_m", homo, 100, 300),
+        ("dinucleotide_60k_sparse_mismatches", dinuc, 2, 12),
+        ("n_every_1000", bytes(n_every), 2, 40),
+        ("mostly_n", mostly_n, 2, 30),
+    ]

@@ -7,12 +7,12 @@ import numpy as np
 import pytest
 
 import ribbit_amd
-from cases import edge_cases, large_motif_cases, simulated_cases
+from cases import edge_cases, large_motif_cases, simulated_cases, structured_cases
 from oracle_lib import LIST_ANCHORED, LIST_PERFECT, LIST_SUBST, Oracle
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-ALL = edge_cases() + simulated_cases() + large_motif_cases()
+ALL = edge_cases() + simulated_cases() + large_motif_cases() + structured_cases()
 
 
 @pytest.mark.parametrize("name,seq,m_lo,m_hi", ALL, ids=[c[0] for c in ALL])

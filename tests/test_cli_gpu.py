@@ -7,14 +7,14 @@ import subprocess
 import pytest
 
 import ribbit_amd
-from cases import edge_cases, large_motif_cases, simulated_cases
+from cases import edge_cases, large_motif_cases, simulated_cases, structured_cases
 from oracle_lib import Oracle
 from ribbit_amd.simulate import write_fasta
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "ribbit_amd", "ribbit-hip")
-ALL = edge_cases() + simulated_cases() + large_motif_cases()
+ALL = edge_cases() + simulated_cases() + large_motif_cases() + structured_cases()
 
 
 @pytest.mark.parametrize("name,seq,m_lo,m_hi", ALL, ids=[c[0] for c in ALL])
