@@ -411,8 +411,9 @@ int ribbit_host_perfect_runs_from_events(const RibbitScanParams *params, size_t 
 void ribbit_runs_free(RibbitRun *runs);
 
 /* Timing of the last call, milliseconds.  what: 0 pack kernel, 1 last scan kernel, 2 GPU side of
- * the last scan (kernel + compaction + read-back), all by HIP events on the launch stream;
- * 3 host post-processing of the last scan (wall clock). */
+ * the last scan (kernel + pairing + state machine + sort + read-back), all by HIP events on the launch stream;
+ * 3 everything after the pairing of the last window stage (device state machine, sort, read-back; wall clock);
+ * 4 the sequential host merge of the last window stage (wall clock). */
 int ribbit_hip_last_timing_ms(const RibbitHandle *h, int what, double *ms);
 /* Profiling aid (no effect on results): streams `nbytes` of the loaded record's ASCII buffer /
  * planes through calib_stream_read_kernel so that a PMC pass contains a launch with a known byte

@@ -97,7 +97,9 @@ struct RibbitHandle {
     hipEvent_t ev[6] = {};        // 0/1 pack, 2/3 scan kernel, 4/5 whole GPU side of the last scan
     bool have_timing[3] = {false, false, false};
     bool timing = true;           // record the HIP events behind ribbit_hip_last_timing_ms (each costs a barrier packet on the stream)
-    double host_ms = 0.0;         // host post-processing of the last scan (pairing / FSM)
+    double host_ms = 0.0;         // post-processing of the last scan after its pairing (device state machine, sort, read-back), wall clock
+    double merge_ms = 0.0;        // sequential host merge of the last window stage, wall clock
+    bool xa_on_device = false;    // the anchored kernel has written the composed planes of the loaded record
     unsigned host_threads = 0;    // worker threads of the host stages (0 = RIBBIT_THREADS or min(cores, 16))
 
     bool loaded = false;
@@ -141,6 +143,17 @@ struct RibbitHandle {
     bool copy_pending = false;            // result copies enqueued but not yet waited for (ribbit_hip_scan_perfect_end with wait = 0)
     DevBuf<RibbitRun> d_halves;
     size_t n_runs = 0, n_halves = 0;
+    // window stages on the device (window_stage.hip): scratch of the streak -> call pipeline and its pinned results
+    DevBuf<uint32_t> d_eval, d_first_rev, d_word_tmp, d_last_word, d_bitmap, d_edge_tmp, d_edge_end1, d_ws_counters;
+    bool eval_valid = false;              // d_eval / d_first_rev belong to the loaded record
+    DevBuf<uint64_t> d_group, d_sort_keys, d_sort_vals, d_edge_keys, d_edge_vals, d_edge_keys2, d_edge_vals2;
+    DevBuf<int32_t> d_min_span, d_pend;
+    DevBuf<RibbitCall> d_flush;
+    DevBuf<uint8_t> d_scratch;
+    PinnedBuf<RibbitCall> h_calls, h_flush;
+    PinnedBuf<int32_t> h_pend;
+    PinnedBuf<uint32_t> h_ws;
+    int64_t last_streaks = 0, last_calls = 0, last_edge_calls = 0;
     rb::CallVec perfect_calls;
     bool subst_calls_valid = false;
     rb::CallVec subst_calls;
@@ -201,6 +214,8 @@ int pack_loaded_ascii(RibbitHandle *h, const uint8_t *dev_ascii, int64_t length)
     h->longest_valid = false;
     h->best_rows_valid = false;
     h->host_planes_valid = false;
+    h->eval_valid = false;
+    h->xa_on_device = false;
     h->stage_done = STAGE_NONE;
     h->length = length;
     const int64_t nwords = length / 32 + 1;   // word holding position L is included
@@ -405,6 +420,7 @@ int perfect_begin(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_o
     pr.m_lo = (uint32_t)h->params.min_motif;
     pr.nm = (uint32_t)(h->params.max_motif - h->params.min_motif + 1);
     pr.ntile = (uint32_t)(h->length / rb::TILE_BASES + 1);
+    pr.tile_bases = (uint32_t)rb::TILE_BASES;
     pr.own_lo = own_lo; pr.own_hi = own_hi; pr.pos_offset = pos_offset;
     const size_t half_cap = 2 * (size_t)pr.nm;
     if ((rc = h->d_halves.ensure(half_cap))) return rc;
@@ -506,18 +522,234 @@ int advance_to_perfect(RibbitHandle *h) {
     return RIBBIT_OK;
 }
 
-// window scan (1 mismatch) + per-motif state machine -> the addSeed call list of
+// ---- window stages on the device ---------------------------------------------------------------------
+// scan kernel -> pass-streak START / END events (left in their regions) -> pairing kernels -> one 16-byte record per
+// streak, motif-major by start, in d_dense.  which: 1 window scan (1 mismatch), 2 fused anchored scan.
+int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks) {
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    if (h->copy_pending && (rc = perfect_wait(h))) return rc;      // d_dense / d_events are shared with the perfect stage
+    if ((rc = h->d_counters.ensure(rb::EV_COUNTER_WORDS))) return rc;
+    if ((rc = h->d_pair_status.ensure(rb::PAIR_STATUS_WORDS))) return rc;
+    if (!h->h_pub.p) {
+        if ((rc = h->h_pub.ensure(rb::EV_SHARDS + rb::PAIR_STATUS_WORDS))) return rc;
+        HIP_TRY(hipHostGetDevicePointer((void **)&h->h_pub_dev, h->h_pub.p, 0));
+    }
+    rb::PairLaunch pr{};
+    pr.m_lo = (uint32_t)h->params.min_motif;
+    pr.nm = (uint32_t)(h->params.max_motif - h->params.min_motif + 1);
+    pr.tile_bases = which == 2 ? (uint32_t)rb::anchored_tile_words(rb::anchored_halo_lanes(h->params.max_motif)) * 32u : (uint32_t)rb::TILE_BASES;
+    pr.ntile = (uint32_t)(h->length / pr.tile_bases + 1);
+    pr.own_lo = 0; pr.own_hi = INT64_MAX; pr.pos_offset = 0;
+    const size_t entries = (size_t)pr.nm * pr.ntile;
+    if (entries > 0xfffffff0u) return fail(RIBBIT_E_ARG, "record too long for %u motif sizes", pr.nm);
+    if ((rc = h->d_pair_table.ensure(entries))) return rc;
+    if ((rc = h->d_run_base.ensure(entries))) return rc;
+    if ((rc = h->d_pair_partial.ensure(entries / 1024 + 2))) return rc;
+    if ((rc = h->d_halves.ensure(2 * (size_t)pr.nm))) return rc;
+    // typical event densities on repeat-rich sequence: 0.25 per base (1-mismatch windows), 3.7 (anchored windows at 99
+    // motif sizes); a too small first guess costs a second launch
+    const size_t per_base_x4 = which == 1 ? 2 : (size_t)std::max(16, (h->params.max_motif - h->params.min_motif + 1) / 6);
+    size_t cap = std::max<size_t>((size_t)1 << 20, (size_t)h->length * per_base_x4 / 4);
+    cap = std::max(cap, h->d_events.cap);
+    if (h->debug_first_cap) cap = h->debug_first_cap;
+    const rb::DevicePlanes pl = h->planes();
+    uint64_t produced = 0;
+    for (int attempt = 0;; ++attempt) {
+        cap = std::min<size_t>((cap + rb::EV_SHARDS - 1) / rb::EV_SHARDS * rb::EV_SHARDS, 0xffffff00u);
+        if ((rc = h->d_events.ensure(cap))) return rc;
+        if ((rc = h->d_dense.ensure(cap))) return rc;          // cap / 2 streak records of 16 bytes
+        HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+        if (!h->counters_clean) HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, rb::EV_COUNTER_WORDS * sizeof(uint32_t), h->stream));
+        h->counters_clean = false;
+        rb::PerfectLaunch pp;
+        pp.m_lo = h->params.min_motif;
+        pp.m_hi = h->params.max_motif;
+        pp.ev_cap = (uint32_t)cap;
+        pr.region_cap = pp.ev_cap / (uint32_t)rb::EV_SHARDS;
+        HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+        if (which == 1) rb::launch_scan_window(pl, pp, 1, h->d_events.p, h->d_counters.p, h->stream);
+        else rb::launch_scan_anchored(pl, pp, h->d_xa.p, h->xa_stride, h->d_events.p, h->d_counters.p, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+        rb::launch_pair_runs(h->d_events.p, h->d_counters.p, pr, h->d_pair_table.p, h->d_run_base.p, h->d_pair_partial.p,
+                             h->d_dense.p, (uint32_t)(cap / 2), h->d_halves.p, (uint32_t)(2 * (size_t)pr.nm), h->d_pair_status.p, h->stream);
+        HIP_TRY(hipGetLastError());
+        rb::launch_pair_publish(h->d_counters.p, h->d_pair_status.p, h->h_pub_dev, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        uint32_t worst = 0;
+        produced = 0;
+        for (int t = 0; t < rb::EV_SHARDS; ++t) { worst = std::max(worst, h->h_pub.p[t]); produced += h->h_pub.p[t]; }
+        if (worst <= pr.region_cap) break;
+        if (attempt == 2 || (size_t)worst * rb::EV_SHARDS > 0xffffff00u)
+            return fail(RIBBIT_E_OVERFLOW, "event buffer overflow: fullest region needs %u events", worst);
+        cap = ((size_t)worst + 1024) * rb::EV_SHARDS;
+    }
+    h->have_timing[1] = true;
+    h->last_event_count = (int64_t)produced;
+    const uint32_t flags = h->h_pub.p[rb::EV_SHARDS + rb::PAIR_FLAGS];
+    if (flags)
+        return fail(RIBBIT_E_INTERNAL, "streak pairing failed (flags 0x%x):%s%s%s%s%s", flags,
+                    flags & rb::PAIR_BAD_EVENT ? " malformed event;" : "", flags & rb::PAIR_DUP_CHUNK ? " duplicate event chunk;" : "",
+                    flags & rb::PAIR_NOT_ALTERNATING ? " streak starts and ends do not alternate;" : "",
+                    flags & rb::PAIR_UNTERMINATED ? " unterminated streak;" : "", flags & rb::PAIR_NO_ROOM ? " streak buffer too small;" : "");
+    const uint32_t n = h->h_pub.p[rb::EV_SHARDS + rb::PAIR_TOTAL];
+    if ((uint64_t)n * 2 != produced) return fail(RIBBIT_E_INTERNAL, "%llu events but %u streaks", (unsigned long long)produced, n);
+    if (h->h_pub.p[rb::EV_SHARDS + rb::PAIR_HALVES]) return fail(RIBBIT_E_INTERNAL, "streak cut by the own range of a whole record");
+    *n_streaks = n;
+    h->last_streaks = n;
+    return RIBBIT_OK;
+}
+
+// What a window stage hands the host merges (see rb::CompactCalls): views of handle-owned pinned memory.
+struct DeviceCalls {
+    const RibbitCall *calls = nullptr;   // in call order; compact mode: only those that pass the length filter
+    size_t n = 0;
+    const int32_t *pend = nullptr;       // compact mode: per call, largest end of any earlier call that matters (-1: none); null = all -1
+    int32_t tail_pend = -1;              // largest end of any in-loop call
+    const RibbitCall *flush = nullptr;   // end-of-sequence calls, motif order
+    size_t n_flush = 0;
+};
+
+// The whole window stage on the device (window_stage.hip).  full: every call, unfiltered (the call-list entry points
+// and the parity tests); otherwise only the calls that pass min_span, with their cursor bounds.
+int window_stage_device(RibbitHandle *h, int which, bool full, int (*min_span)(int), DeviceCalls *out) {
+    int rc;
+    uint32_t n = 0;
+    static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
+    const double t_scan = now_ms();
+    if ((rc = scan_and_pair_streaks(h, which, &n))) return rc;
+    const double t0 = now_ms();
+    const uint32_t nm = (uint32_t)(h->params.max_motif - h->params.min_motif + 1);
+    const uint32_t n_words = (uint32_t)(h->length / 32 + 1);
+    int key_bits = 10;
+    while (((int64_t)1 << (key_bits - 10)) <= h->length + 8) ++key_bits;
+    size_t scratch = rb::window_stage_scratch_bytes(n, n_words, n, std::max<size_t>(n / 16, (size_t)1 << 16), key_bits);
+    if ((rc = h->d_scratch.ensure(scratch))) return rc;
+    if ((rc = h->d_word_tmp.ensure(n_words + 1))) return rc;
+    if (!h->eval_valid) {
+        if ((rc = h->d_eval.ensure(n_words + 1))) return rc;
+        if ((rc = h->d_first_rev.ensure(n_words + 1))) return rc;
+        HIP_TRY(rb::launch_eval_planes(h->d_brk.p + rb::LEAD_WORDS, n_words, h->d_eval.p, h->d_first_rev.p, h->d_word_tmp.p, h->d_scratch.p, h->d_scratch.cap, h->stream));
+        HIP_TRY(hipGetLastError());
+        h->eval_valid = true;
+    }
+    if ((rc = h->d_group.ensure(std::max<size_t>(n, 1)))) return rc;
+    const RibbitRun *runs = reinterpret_cast<const RibbitRun *>(h->d_dense.p);
+    HIP_TRY(rb::launch_group_starts(runs, n, (uint32_t)h->params.min_motif, h->d_group.p, h->d_scratch.p, h->d_scratch.cap, h->stream));
+    HIP_TRY(hipGetLastError());
+    // length filter of the stage (seedlen_cutoffs), per motif
+    std::vector<int32_t> spans(nm, 0);
+    if (!full) for (uint32_t mi = 0; mi < nm; ++mi) spans[mi] = min_span(h->params.min_motif + (int)mi);
+    if ((rc = h->d_min_span.ensure(nm))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_min_span.p, spans.data(), nm * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    if ((rc = h->d_flush.ensure(nm))) return rc;
+    if ((rc = h->d_ws_counters.ensure(rb::WS_WORDS))) return rc;
+    if ((rc = h->d_bitmap.ensure(n_words + 1))) return rc;
+    if ((rc = h->h_ws.ensure(rb::WS_WORDS))) return rc;
+    if ((rc = h->h_flush.ensure(nm))) return rc;
+    size_t edge_cap = std::max<size_t>(h->d_edge_keys.cap, std::max<size_t>((size_t)1 << 16, n / 16));
+    // the events are spent: their buffer (2 x 8 bytes per streak at least) receives the unsorted calls
+    uint64_t *keys = h->d_events.p, *vals = h->d_events.p + h->d_events.cap / 2;
+    uint32_t n_main = 0, n_edge = 0;
+    for (int attempt = 0;; ++attempt) {
+        if (!full) {
+            if ((rc = h->d_edge_keys.ensure(edge_cap)) || (rc = h->d_edge_vals.ensure(edge_cap))) return rc;
+            HIP_TRY(hipMemsetAsync(h->d_bitmap.p, 0, ((size_t)n_words + 1) * sizeof(uint32_t), h->stream));
+        }
+        HIP_TRY(hipMemsetAsync(h->d_flush.p, 0, nm * sizeof(RibbitCall), h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_ws_counters.p, 0, rb::WS_WORDS * sizeof(uint32_t), h->stream));
+        rb::WindowCallsLaunch w{};
+        w.runs = runs; w.n_streaks = n; w.group = h->d_group.p;
+        w.eval = h->d_eval.p; w.first_rev = h->d_first_rev.p; w.brk = h->d_brk.p + rb::LEAD_WORDS; w.n_words = n_words;
+        w.length = h->length; w.m_lo = (uint32_t)h->params.min_motif; w.nm = nm; w.min_span = h->d_min_span.p; w.full = full ? 1 : 0;
+        w.keys = keys; w.vals = vals; w.cap = (uint32_t)(h->d_events.cap / 2);
+        w.edge_keys = h->d_edge_keys.p; w.edge_vals = h->d_edge_vals.p; w.edge_cap = full ? 0u : (uint32_t)edge_cap;
+        w.flush = h->d_flush.p; w.bitmap = h->d_bitmap.p; w.counters = h->d_ws_counters.p;
+        rb::launch_window_calls(w, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->h_ws.p, h->d_ws_counters.p, rb::WS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->h_flush.p, h->d_flush.p, nm * sizeof(RibbitCall), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        n_main = h->h_ws.p[rb::WS_N_MAIN];
+        n_edge = h->h_ws.p[rb::WS_N_EDGE];
+        if (n_edge <= edge_cap || full) break;
+        if (attempt == 1) return fail(RIBBIT_E_INTERNAL, "edge-call list overflow");
+        edge_cap = (size_t)n_edge + 1024;
+    }
+    const double t_calls = now_ms();
+    uint32_t wflags = h->h_ws.p[rb::WS_FLAGS];
+    if (wflags) return fail(RIBBIT_E_INTERNAL, "window state machine on the device failed (flags 0x%x)", wflags);
+    if (n_main > h->d_events.cap / 2) return fail(RIBBIT_E_INTERNAL, "more calls than streaks");
+    // call order: scan position major, motif minor
+    scratch = rb::window_stage_scratch_bytes(0, n_words, n_main, n_edge, key_bits);
+    if ((rc = h->d_scratch.ensure(scratch))) return rc;
+    if ((rc = h->d_sort_keys.ensure(std::max<size_t>(n_main, 1))) || (rc = h->d_sort_vals.ensure(std::max<size_t>(n_main, 1)))) return rc;
+    HIP_TRY(rb::launch_sort_calls(keys, vals, h->d_sort_keys.p, h->d_sort_vals.p, n_main, key_bits, h->d_scratch.p, h->d_scratch.cap, h->stream));
+    HIP_TRY(hipGetLastError());
+    const bool bounds = !full && n_edge > 0 && n_main > 0;
+    if (bounds) {
+        if ((rc = h->d_edge_keys2.ensure(n_edge)) || (rc = h->d_edge_vals2.ensure(n_edge))) return rc;
+        if ((rc = h->d_edge_tmp.ensure(n_edge)) || (rc = h->d_edge_end1.ensure(n_edge))) return rc;
+        if ((rc = h->d_last_word.ensure(n_words + 1))) return rc;
+        if ((rc = h->d_pend.ensure(n_main))) return rc;
+        HIP_TRY(rb::launch_sort_calls(h->d_edge_keys.p, h->d_edge_vals.p, h->d_edge_keys2.p, h->d_edge_vals2.p, n_edge, key_bits, h->d_scratch.p, h->d_scratch.cap, h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_pend.p, 0xff, (size_t)n_main * sizeof(int32_t), h->stream));
+        HIP_TRY(rb::launch_edge_bounds(h->d_edge_keys2.p, h->d_edge_vals2.p, n_edge, h->d_edge_tmp.p, h->d_edge_end1.p, h->d_bitmap.p, h->d_word_tmp.p,
+                                       h->d_last_word.p, n_words, h->d_sort_keys.p, n_main, h->d_pend.p, h->d_ws_counters.p, h->d_scratch.p, h->d_scratch.cap, h->stream));
+        HIP_TRY(hipGetLastError());
+    }
+    // 16-byte call records for the host; the streak records are spent, their buffer takes them
+    RibbitCall *d_calls = reinterpret_cast<RibbitCall *>(h->d_dense.p);
+    rb::launch_assemble_calls(h->d_sort_keys.p, h->d_sort_vals.p, n_main, d_calls, h->stream);
+    HIP_TRY(hipGetLastError());
+    if ((rc = h->h_calls.ensure(std::max<size_t>(n_main, 1)))) return rc;
+    if (n_main) HIP_TRY(hipMemcpyAsync(h->h_calls.p, d_calls, (size_t)n_main * sizeof(RibbitCall), hipMemcpyDeviceToHost, h->stream));
+    if (bounds) {
+        if ((rc = h->h_pend.ensure(n_main))) return rc;
+        HIP_TRY(hipMemcpyAsync(h->h_pend.p, h->d_pend.p, (size_t)n_main * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->h_ws.p, h->d_ws_counters.p, rb::WS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipEventRecord(h->ev[5], h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->have_timing[2] = true;
+    wflags = h->h_ws.p[rb::WS_FLAGS];
+    if (wflags) return fail(RIBBIT_E_INTERNAL, "cursor bounds of the edge calls failed (flags 0x%x)", wflags);
+    // end-of-sequence calls: at most one per motif, already in motif order; close the gaps
+    size_t nf = 0;
+    for (uint32_t mi = 0; mi < nm; ++mi)
+        if (h->h_flush.p[mi].mlen != 0) h->h_flush.p[nf++] = h->h_flush.p[mi];
+    out->calls = h->h_calls.p;
+    out->n = n_main;
+    out->pend = bounds ? h->h_pend.p : nullptr;
+    out->tail_pend = (int32_t)h->h_ws.p[rb::WS_MAX_END] - 1;
+    out->flush = h->h_flush.p;
+    out->n_flush = nf;
+    h->last_calls = n_main;
+    h->last_edge_calls = n_edge;
+    h->host_ms = now_ms() - t0;
+    if (profile)
+        std::fprintf(stderr, "[window stage %d%s] scan + pairing %.1f ms (%u streaks), group scan + calls kernel %.1f ms, sort + bounds + read-back %.1f ms: "
+                     "%u calls, %u edge calls, %zu flush calls\n", which, full ? " full" : "", t0 - t_scan, n, t_calls - t0, now_ms() - t_calls, n_main, n_edge, nf);
+    return RIBBIT_OK;
+}
+
+void full_calls_from_device(const DeviceCalls &dc, rb::CallVec &calls) {
+    calls.resize(dc.n + dc.n_flush);
+    if (dc.n) std::memcpy(calls.data(), dc.calls, dc.n * sizeof(RibbitCall));
+    if (dc.n_flush) std::memcpy(calls.data() + dc.n, dc.flush, dc.n_flush * sizeof(RibbitCall));
+}
+
+// window scan (1 mismatch) + per-motif state machine, both on the device -> the addSeed call list of
 // processShiftXORswithSubstitutions (parse_substitute_shiftxor.cpp:430-574)
 int build_subst_calls(RibbitHandle *h) {
     if (h->subst_calls_valid) return RIBBIT_OK;
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
-    int rc = ensure_host_planes(h);
+    DeviceCalls dc;
+    int rc = window_stage_device(h, 1, true, nullptr, &dc);
     if (rc) return rc;
-    if ((rc = collect_events(h, 1))) return rc;
-    const double t0 = now_ms();
-    std::string why;
-    if (!rb::replay_window_events(event_source(h), h->host, h->subst_calls, &why, h->host_threads)) return fail(RIBBIT_E_INTERNAL, "%s", why.c_str());
-    h->host_ms = now_ms() - t0;
+    full_calls_from_device(dc, h->subst_calls);
     h->subst_calls_valid = true;
     return RIBBIT_OK;
 }
@@ -535,34 +767,60 @@ void replay_subst_calls(rb::SeedLists &lists, const RibbitCall *calls, size_t n)
     }
 }
 
+// the same from what the device stage kept: calls that pass the filter, each with the largest end of any earlier call
+// that can matter to its cursor; the end-of-sequence calls come unfiltered
+void replay_subst_compact(rb::SeedLists &lists, const DeviceCalls &dc) {
+    int from_index = 0;
+    for (size_t i = 0; i < dc.n; ++i) {
+        const RibbitCall &c = dc.calls[i];
+        if (dc.pend && dc.pend[i] >= 0) from_index = rb::advance_cursor(lists.perfect, from_index, dc.pend[i]);
+        from_index = rb::subst_add(lists, c.start, c.end, c.mlen, from_index, RIBBIT_RANK_S);
+    }
+    int pending_end = dc.tail_pend;
+    for (size_t i = 0; i < dc.n_flush; ++i) {
+        const RibbitCall &c = dc.flush[i];
+        if (c.end - c.start < rb::subst_seedlen_cutoff(c.mlen)) { pending_end = std::max(pending_end, c.end); continue; }
+        if (pending_end >= 0) { from_index = rb::advance_cursor(lists.perfect, from_index, pending_end); pending_end = -1; }
+        from_index = rb::subst_add(lists, c.start, c.end, c.mlen, from_index, RIBBIT_RANK_S);
+    }
+}
+
 int advance_to_subst(RibbitHandle *h) {
     if (h->stage_done >= STAGE_SUBST) return RIBBIT_OK;
     int rc = advance_to_perfect(h);
     if (rc) return rc;
-    if ((rc = build_subst_calls(h))) return rc;
+    if ((rc = ensure_host_planes(h))) return rc;
     const rb::HostPlanes *hp = &h->host;
     h->lists.range_count = [hp](int shift, int start, int end) { return hp->range_count(shift, start, end); };
     h->lists.subst.clear();
-    replay_subst_calls(h->lists, h->subst_calls.data(), h->subst_calls.size());
+    if (h->subst_calls_valid) {
+        replay_subst_calls(h->lists, h->subst_calls.data(), h->subst_calls.size());
+    } else {
+        DeviceCalls dc;
+        if ((rc = window_stage_device(h, 1, false, rb::subst_seedlen_cutoff, &dc))) return rc;
+        const double t0 = now_ms();
+        replay_subst_compact(h->lists, dc);
+        h->merge_ms = now_ms() - t0;
+    }
     h->stage_done = STAGE_SUBST;
     return RIBBIT_OK;
 }
 
-// fused anchored kernel (anchor planes + composition + 6-of-8 window scan) + state machine ->
-// the addSeed call list of processShiftXORsAnchored (parse_anchored_shiftxor.cpp:580-723); also
-// materialises the composed planes XA_m and copies them to the host for the merges' range reads.
-// fused anchored kernel, its events and the composed planes on the host (what both replays below start from)
-int scan_anchored_events(RibbitHandle *h) {
+// The anchored stage's kernel needs room for the composed planes XA_m (they stay in HBM: the device-side refinement
+// scans read them; the host merges recompute the few bits they need from the packed planes).
+int prepare_anchored(RibbitHandle *h) {
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
     if (h->params.max_motif > rb::ANCHORED_MAX_MOTIF)
         return fail(RIBBIT_E_ARG, "the anchored stage of this build supports max_motif <= %d (got %d)", rb::ANCHORED_MAX_MOTIF, h->params.max_motif);
-    int rc = ensure_host_planes(h);
-    if (rc) return rc;
     const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
     h->xa_stride = ((h->length / 32 + 1) + 7) / 8 * 8 + 16;
-    if ((rc = h->d_xa.ensure(nm * (size_t)h->xa_stride))) return rc;
-    if ((rc = collect_events(h, 2))) return rc;
-    // composed planes -> host (the sequential merges read a few bits at a time, far too often for a GPU round trip each)
+    return h->d_xa.ensure(nm * (size_t)h->xa_stride);
+}
+
+// composed planes -> host (the sequential merges read a few bits at a time, far too often for a GPU round trip each)
+int fetch_xa_host(RibbitHandle *h) {
+    int rc;
+    const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
     if ((rc = h->h_xa.ensure(nm * (size_t)h->xa_stride))) return rc;      // page-locked: the copy runs at link speed
     h->host.xa.clear();
     h->host.xa_view = h->h_xa.p;
@@ -574,14 +832,16 @@ int scan_anchored_events(RibbitHandle *h) {
     return RIBBIT_OK;
 }
 
+// fused anchored kernel (anchor planes + composition + 6-of-8 window scan) + state machine, on the device ->
+// the addSeed call list of processShiftXORsAnchored (parse_anchored_shiftxor.cpp:580-723)
 int build_anchored_calls(RibbitHandle *h) {
     if (h->anchored_calls_valid) return RIBBIT_OK;
-    int rc = scan_anchored_events(h);
+    int rc = prepare_anchored(h);
     if (rc) return rc;
-    const double t0 = now_ms();
-    std::string why;
-    if (!rb::replay_window_events(event_source(h), h->host, h->anchored_calls, &why, h->host_threads)) return fail(RIBBIT_E_INTERNAL, "%s", why.c_str());
-    h->host_ms = now_ms() - t0;
+    DeviceCalls dc;
+    if ((rc = window_stage_device(h, 2, true, nullptr, &dc))) return rc;
+    full_calls_from_device(dc, h->anchored_calls);
+    h->xa_on_device = true;
     h->anchored_calls_valid = true;
     return RIBBIT_OK;
 }
@@ -625,16 +885,16 @@ void replay_anchored_calls(rb::SeedLists &lists, const rb::CallVec &calls, int64
     r.run(calls.data(), calls.size(), length);
 }
 
-// the same from the compact form (event_stream.h): only the calls that pass the length filter were kept, each with
-// the largest end of the filtered-out calls before it
-void replay_anchored_compact(rb::SeedLists &lists, const rb::CompactCalls &cc, int64_t length) {
+// and from what the device stage kept (DeviceCalls): the bound of a call covers every earlier call, which by
+// advance_cursor's monotonicity is the same as covering those since the previous kept call
+void replay_anchored_device(rb::SeedLists &lists, const DeviceCalls &dc, int64_t length) {
     AnchoredReplay r{lists, rb::Cursor2{}};
-    for (size_t i = 0; i < cc.calls.size(); ++i) {
-        r.pending_end = std::max(r.pending_end, cc.pend_before[i]);
-        r.call(cc.calls[i], true);
+    for (size_t i = 0; i < dc.n; ++i) {
+        if (dc.pend) r.pending_end = std::max(r.pending_end, dc.pend[i]);
+        r.call(dc.calls[i], true);
     }
-    r.pending_end = std::max(r.pending_end, cc.tail_pend);
-    r.run(cc.flush.data(), cc.flush.size(), length);
+    r.pending_end = std::max(r.pending_end, dc.tail_pend);
+    r.run(dc.flush, dc.n_flush, length);
 }
 
 int advance_to_anchored(RibbitHandle *h) {
@@ -642,27 +902,26 @@ int advance_to_anchored(RibbitHandle *h) {
     int rc = advance_to_subst(h);
     if (rc) return rc;
     // the full call list only when it has been asked for (ribbit_hip_anchored_calls); otherwise the compact form:
-    // nine calls in ten fail the length filter and are never materialised
-    rb::CompactCalls compact;
+    // nine calls in ten fail the length filter and never leave the device
+    DeviceCalls dc;
     const bool full = h->anchored_calls_valid;
     if (!full) {
-        if ((rc = scan_anchored_events(h))) return rc;
-        const double t0 = now_ms();
-        std::string why;
-        rb::CallVec unused;
-        if (!rb::replay_window_events(event_source(h), h->host, unused, &why, h->host_threads, &compact, rb::anchored_seedlen_cutoff))
-            return fail(RIBBIT_E_INTERNAL, "%s", why.c_str());
-        h->host_ms = now_ms() - t0;
+        if ((rc = prepare_anchored(h))) return rc;
+        if ((rc = window_stage_device(h, 2, false, rb::anchored_seedlen_cutoff, &dc))) return rc;
+        h->xa_on_device = true;
     }
+    if ((rc = fetch_xa_host(h))) return rc;
     const rb::HostPlanes *hp = &h->host;
     // from here on "plane m" means the composed plane XA_m (fasta_utils.cpp:159)
     h->lists.range_count = [hp](int shift, int start, int end) {
         return hp->has_xa(shift) ? hp->range_count_xa(shift, start, end) : hp->range_count(shift, start, end);
     };
     h->lists.anchored.clear();
+    const double t0 = now_ms();
     if (full) replay_anchored_calls(h->lists, h->anchored_calls, h->length);
-    else replay_anchored_compact(h->lists, compact, h->length);
+    else replay_anchored_device(h->lists, dc, h->length);
     rb::dispatch_order(h->lists, h->dispatch);
+    h->merge_ms = now_ms() - t0;
     h->stage_done = STAGE_ANCHORED;
     return RIBBIT_OK;
 }
@@ -809,12 +1068,18 @@ int ribbit_hip_close(RibbitHandle *h) {
     if (!h) return RIBBIT_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     h->d_ascii.release(); h->d_hi.release(); h->d_lo.release(); h->d_brk.release();
     h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release(); h->d_slices.release();
     h->d_ssw_jobs.release(); h->d_ssw_order.release(); h->d_ssw_out.release(); h->d_ssw_pool.release();
     h->h_events.release(); h->h_counters.release(); h->h_query.release(); h->h_xa.release();
     h->d_pair_table.release(); h->d_run_base.release(); h->d_pair_partial.release(); h->d_pair_status.release();
     h->h_pub.release(); h->h_runs.release(); h->h_halves.release(); h->d_halves.release();
+    h->d_eval.release(); h->d_first_rev.release(); h->d_word_tmp.release(); h->d_last_word.release(); h->d_bitmap.release();
+    h->d_edge_tmp.release(); h->d_edge_end1.release(); h->d_ws_counters.release(); h->d_group.release(); h->d_sort_keys.release();
+    h->d_sort_vals.release(); h->d_edge_keys.release(); h->d_edge_vals.release(); h->d_edge_keys2.release(); h->d_edge_vals2.release();
+    h->d_min_span.release(); h->d_pend.release(); h->d_flush.release(); h->d_scratch.release();
+    h->h_calls.release(); h->h_flush.release(); h->h_pend.release(); h->h_ws.release();
     for (int i = 0; i < 6; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -1267,6 +1532,7 @@ int ribbit_hip_debug_pair_events(RibbitHandle *h, const uint64_t *events, size_t
     pr.m_lo = (uint32_t)h->params.min_motif;
     pr.nm = (uint32_t)(h->params.max_motif - h->params.min_motif + 1);
     pr.ntile = (uint32_t)(length / rb::TILE_BASES + 1);
+    pr.tile_bases = (uint32_t)rb::TILE_BASES;
     pr.own_lo = 0; pr.own_hi = INT64_MAX; pr.pos_offset = 0;
     pr.region_cap = (uint32_t)std::max<size_t>(n, 1);                  // the whole stream sits in region 0
     const size_t entries = (size_t)pr.nm * pr.ntile, cap = (size_t)pr.region_cap * rb::EV_SHARDS;
@@ -1528,11 +1794,18 @@ static int query_plane(RibbitHandle *h, int32_t shift, int64_t start, int64_t en
 
 int ribbit_hip_plane_bits(RibbitHandle *h, int32_t shift, int64_t start, int64_t end, uint8_t *out) {
     if (!h || (!out && end > start)) return fail(RIBBIT_E_ARG, "null argument");
-    if (h->loaded && h->anchored_calls_valid && h->host.has_xa(shift)) {
-        // composed plane (fasta_utils.cpp:159): written by the anchored kernel, already on the host
+    if (h->loaded && h->xa_on_device && shift >= h->params.min_motif && shift <= h->params.max_motif) {
+        // composed plane (fasta_utils.cpp:159): written by the anchored kernel, resident in HBM
         if (start < 0 || end > h->length || start > end) return fail(RIBBIT_E_ARG, "range [%lld,%lld) outside the record", (long long)start, (long long)end);
-        const uint32_t *w = h->host.xa_words() + (int64_t)(shift - h->host.xa_m_lo) * h->host.xa_stride;
-        for (int64_t p = start; p < end; ++p) out[p - start] = (w[p >> 5] >> (p & 31)) & 1u;
+        if (end == start) return RIBBIT_OK;
+        int rcx;
+        if ((rcx = bind_device(h))) return rcx;
+        const int64_t w0 = start / 32, nw = (end + 31) / 32 - w0;
+        if ((rcx = h->h_query.ensure((size_t)nw + 16))) return rcx;
+        HIP_TRY(hipMemcpyAsync(h->h_query.p, h->d_xa.p + (int64_t)(shift - h->params.min_motif) * h->xa_stride + w0, (size_t)nw * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int64_t p = start; p < end; ++p) out[p - start] = (h->h_query.p[p / 32 - w0] >> (p & 31)) & 1u;
         return RIBBIT_OK;
     }
     int rc = query_plane(h, shift, start, end, true, nullptr);
@@ -1569,7 +1842,8 @@ int ribbit_hip_packed_plane(RibbitHandle *h, int which, uint32_t *out_words) {
 int ribbit_hip_last_timing_ms(const RibbitHandle *h, int what, double *ms) {
     if (!h || !ms) return fail(RIBBIT_E_ARG, "null argument");
     if (what == 3) { *ms = h->host_ms; return RIBBIT_OK; }
-    if (what < 0 || what > 3) return fail(RIBBIT_E_ARG, "what must be 0..3");
+    if (what == 4) { *ms = h->merge_ms; return RIBBIT_OK; }
+    if (what < 0 || what > 4) return fail(RIBBIT_E_ARG, "what must be 0..4");
     if (!h->have_timing[what]) return fail(RIBBIT_E_STATE, "no timing recorded yet");
     float f = 0.f;
     HIP_TRY(hipEventSynchronize(h->ev[2 * what + 1]));

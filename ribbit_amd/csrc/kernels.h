@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "device_planes.h"
+#include "ribbit_hip.h"
 
 namespace rb {
 
@@ -47,7 +48,8 @@ void launch_compact_events(const uint64_t *events, uint32_t ev_cap, uint32_t *co
 // status: PAIR_STATUS_WORDS words (all device scratch, initialised here).  runs holds run_cap records.
 struct PairLaunch {
     uint32_t m_lo, nm;        // first motif, number of motifs
-    uint32_t ntile;           // tiles of TILE_BASES positions covering 0..L
+    uint32_t ntile;           // tiles of tile_bases positions covering 0..L
+    uint32_t tile_bases;      // positions per scan-kernel tile: TILE_BASES, or the anchored kernel's narrower tile
     uint32_t region_cap;      // events per region
     // chunk of a longer record: only runs whose START lies in [own_lo, own_hi) (positions of the loaded piece) are
     // reported, with pos_offset added; a whole record is own_lo = 0, own_hi = INT64_MAX, pos_offset = 0
@@ -65,6 +67,49 @@ void launch_pair_publish(const uint32_t *counters, const uint32_t *status, uint3
 // of that (motif, tile) chunk of `dense` (both 0: no chunk); *status != 0: malformed stream.
 void launch_chunk_table(const uint64_t *dense, const uint32_t *counters, uint32_t m_lo, uint32_t nm, uint32_t ntile,
                         uint32_t tile_bases, void *table, uint32_t *status, hipStream_t stream);
+
+// ---- window stages on the device (window_stage.hip): streaks -> addSeed calls -------------------------------
+// counters of launch_window_calls (WS_WORDS words, zeroed by the caller)
+enum : uint32_t { WS_N_MAIN = 0, WS_N_EDGE = 1, WS_FLAGS = 2, WS_MAX_END = 3 /* largest end + 1 of an in-loop call */, WS_WORDS = 8 };
+enum : uint32_t {
+    WS_TWO_FLUSH = 1,    // two end-of-sequence calls for one motif
+    WS_BAD_MOTIF = 2,    // streak with a motif outside the launch
+    WS_NOT_PROMPT = 4,   // an ordinary call whose end is not its position - 8 (would break the bound argument)
+    WS_EDGE_LOST = 8,    // a kept edge call is missing from the main list
+};
+// E plane (bit q: window [q, q+7] is evaluated) and, reversed, the first word >= w that has an evaluated window;
+// n_words = L/32 + 1 words each (brk must be readable one word further); word_tmp: n_words words of scratch
+hipError_t launch_eval_planes(const uint32_t *brk, uint32_t n_words, uint32_t *eval, uint32_t *first_rev, uint32_t *word_tmp,
+                              void *scratch, size_t scratch_bytes, hipStream_t stream);
+// group[i] = (motif index << 32) | (start of the group streak i belongs to) + 1, streaks = the run records the
+// pairing kernels made of a window scan's events (motif-major, by start)
+hipError_t launch_group_starts(const RibbitRun *runs, uint32_t n, uint32_t m_lo, uint64_t *group, void *scratch,
+                               size_t scratch_bytes, hipStream_t stream);
+struct WindowCallsLaunch {
+    const RibbitRun *runs; uint32_t n_streaks;
+    const uint64_t *group;
+    const uint32_t *eval, *first_rev, *brk; uint32_t n_words;
+    int64_t length;
+    uint32_t m_lo, nm;
+    const int32_t *min_span;           // device, [nm]
+    int full;                          // 1: all calls, unfiltered; 0: compact (filtered + bounds)
+    uint64_t *keys, *vals; uint32_t cap;              // main list: key = pos << 10 | motif, val = start << 32 | end
+    uint64_t *edge_keys, *edge_vals; uint32_t edge_cap;   // compact mode; val bit 63 = passes the filter
+    RibbitCall *flush;                 // [nm], zeroed by the caller: the end-of-sequence call of each motif
+    uint32_t *bitmap;                  // [n_words + 1], zeroed by the caller
+    uint32_t *counters;                // [WS_WORDS], zeroed by the caller
+};
+void launch_window_calls(const WindowCallsLaunch &w, hipStream_t stream);
+hipError_t launch_sort_calls(uint64_t *keys_in, uint64_t *vals_in, uint64_t *keys_out, uint64_t *vals_out, uint32_t n, int key_bits,
+                             void *scratch, size_t scratch_bytes, hipStream_t stream);
+// bounds of the kept edge calls (edge list sorted by key) -> pend[index in the sorted main list]
+hipError_t launch_edge_bounds(const uint64_t *edge_keys, const uint64_t *edge_vals, uint32_t n_edge, uint32_t *edge_tmp, uint32_t *edge_end1,
+                              const uint32_t *bitmap, uint32_t *word_tmp, uint32_t *last_word1, uint32_t n_words, const uint64_t *main_keys,
+                              uint32_t n_main, int32_t *pend, uint32_t *counters, void *scratch, size_t scratch_bytes,
+                              hipStream_t stream);
+void launch_assemble_calls(const uint64_t *keys, const uint64_t *vals, uint32_t n, RibbitCall *out, hipStream_t stream);
+// bytes of scratch the rocPRIM scans / sorts above need for these sizes
+size_t window_stage_scratch_bytes(size_t n_streaks, size_t n_words, size_t n_calls, size_t n_edge, int key_bits);
 
 // X_shift words [w0, w0+nw) -> out_words (device); if count != nullptr also adds the popcount of
 // bits in [p0, p1) to *count.

@@ -929,7 +929,7 @@ struct ChunkEntry { uint32_t begin1, end1; };    // global event index + 1; 0 = 
 
 __device__ __forceinline__ bool chunk_key_of(uint64_t e, const PairLaunch &pl, uint32_t &key) {
     const uint32_t mi = ev_mlen(e) - pl.m_lo;
-    const uint32_t tile = ev_pos(e) / (uint32_t)TILE_BASES;
+    const uint32_t tile = ev_pos(e) / pl.tile_bases;
     key = mi * pl.ntile + tile;
     return mi < pl.nm && tile < pl.ntile;
 }
