@@ -202,6 +202,13 @@ int ribbit_hip_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n,
  * for every dispatched seed at once, on the GPU: out[i] belongs to dispatch seed i. */
 int ribbit_hip_seed_longest_runs(RibbitHandle *h, const int32_t **out, size_t *n);
 
+/* Host-only twin (no GPU): the same scan over seeds[0..n) of a record given by its packed planes (LSB-first words as
+ * ribbit_hip_packed_plane returns them, zero-padded by max_motif/32 + 4 words past word L/32).  The composed planes
+ * XA_m (fasta_utils.cpp:143-161; generateAnchoredShiftXORs, parse_anchored_shiftxor.cpp:20-56) are not needed: the slice
+ * a seed covers is recomputed from the packed planes, as the host merges of the GPU path do. */
+int ribbit_host_longest_runs(const RibbitScanParams *params, int64_t length, const uint32_t *hi, const uint32_t *lo,
+                             const uint32_t *brk, size_t nwords, const RibbitSeed *seeds, size_t n, int32_t *out);
+
 /*
  * The refinement scans between dispatch and alignment for every dispatched seed: seed validity,
  * possibleMotifs / calculateRepeatClass / calculateAtomicity (parse_smallmotif_seed.cpp:76-188,
@@ -213,8 +220,8 @@ int ribbit_hip_seed_longest_runs(RibbitHandle *h, const int32_t **out, size_t *n
 int ribbit_hip_refine_jobs(RibbitHandle *h, const RibbitRefineParams *prm, const RibbitAlignJob **jobs, size_t *n,
                            const char **motif_pool);
 
-/* Host-only variant (no GPU): same jobs from a dispatch list and host planes; *jobs and *motif_pool are
- * malloc'ed, release with ribbit_refine_jobs_free(). */
+/* Host-only variant (no GPU): same jobs from a dispatch list and host planes (xa may be NULL: recomputed); *jobs and
+ * *motif_pool are malloc'ed, release with ribbit_refine_jobs_free(). */
 int ribbit_host_refine_jobs(const RibbitScanParams *params, const RibbitRefineParams *prm, int64_t length,
                             const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
                             const uint32_t *xa, size_t xa_stride, const RibbitSeed *dispatch, size_t n_dispatch,
@@ -248,7 +255,7 @@ int ribbit_ssw_align(const char *query, int32_t query_len, const char *ref, int3
 int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const char *sequence_id,
                           const char **text, size_t *len);
 
-/* Host-only variant (no GPU); *text is malloc'ed, release with ribbit_text_free(). */
+/* Host-only variant (no GPU; xa may be NULL: recomputed); *text is malloc'ed, release with ribbit_text_free(). */
 int ribbit_host_refine_bed(const RibbitScanParams *params, const RibbitRefineParams *prm, const char *sequence, int64_t length,
                            const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
                            const uint32_t *xa, size_t xa_stride, const RibbitSeed *dispatch, size_t n_dispatch,
@@ -291,8 +298,9 @@ typedef struct RibbitSeedLists {
     RibbitSeed *dispatch; size_t n_dispatch;   /* fasta_utils.cpp:187-224 order */
     int64_t guard_hits;   /* defined-divergence guards that fired */
 } RibbitSeedLists;
-/* xa: composed planes XA_m for m = min_motif..max_motif, xa_stride words each (may be NULL when
- * there are no anchored calls). */
+/* xa: composed planes XA_m for m = min_motif..max_motif, xa_stride words each; may be NULL: the slices the merges
+ * read are then recomputed from the packed planes (as in the GPU path, where the composed planes stay in HBM).
+ * anchored_calls == NULL and xa == NULL: the anchored stage is not run (no dispatch list). */
 int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
                              const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
                              const uint32_t *xa, size_t xa_stride,
@@ -413,7 +421,8 @@ void ribbit_runs_free(RibbitRun *runs);
 /* Timing of the last call, milliseconds.  what: 0 pack kernel, 1 last scan kernel, 2 GPU side of
  * the last scan (kernel + pairing + state machine + sort + read-back), all by HIP events on the launch stream;
  * 3 everything after the pairing of the last window stage (device state machine, sort, read-back; wall clock);
- * 4 the sequential host merge of the last window stage (wall clock). */
+ * 4 the sequential host merge of the last window stage (wall clock); 5 that of the substitution stage when
+ * ribbit_hip_seeds_anchored ran both stages. */
 int ribbit_hip_last_timing_ms(const RibbitHandle *h, int what, double *ms);
 /* Profiling aid (no effect on results): streams `nbytes` of the loaded record's ASCII buffer /
  * planes through calib_stream_read_kernel so that a PMC pass contains a launch with a known byte

@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_range_popcount", "ribbit_hip_plane_words", "ribbit_hip_packed_plane",
     "ribbit_hip_last_timing_ms", "ribbit_hip_last_event_count",
     "ribbit_hip_subst_calls", "ribbit_hip_seeds_substitutions",
-    "ribbit_host_replay_calls", "ribbit_seed_lists_free",
+    "ribbit_host_replay_calls", "ribbit_seed_lists_free", "ribbit_host_longest_runs",
     "ribbit_hip_anchored_calls", "ribbit_hip_seeds_anchored", "ribbit_hip_dispatch_seeds", "ribbit_hip_guard_hits",
     "ribbit_hip_debug_stream_read",
     "ribbit_refine_params_default", "ribbit_hip_seed_longest_runs", "ribbit_hip_refine_jobs",
@@ -121,6 +121,7 @@ def load_library():
                                            vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(SeedLists)]
     L.ribbit_seed_lists_free.restype = None
     L.ribbit_seed_lists_free.argtypes = [C.POINTER(SeedLists)]
+    L.ribbit_host_longest_runs.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp]
     L.ribbit_hip_plane_bits.argtypes = [vp, i32, i64, i64, vp]
     L.ribbit_hip_range_popcount.argtypes = [vp, i32, i64, i64, C.POINTER(i32)]
     L.ribbit_hip_plane_words.restype = i64
@@ -223,7 +224,8 @@ def host_replay_calls(min_motif: int, max_motif: int, sequence: bytes, perfect_c
     out = SeedLists()
     rc = L.ribbit_host_replay_calls(C.byref(params), len(sequence), hi.ctypes.data, lo.ctypes.data, brk.ctypes.data, len(hi),
                                     xa.ctypes.data if xa is not None else None, xa_stride,
-                                    pc.ctypes.data, len(pc), sc.ctypes.data, len(sc), ac.ctypes.data, len(ac), C.byref(out))
+                                    pc.ctypes.data, len(pc), sc.ctypes.data, len(sc),
+                                    ac.ctypes.data if anchored_calls is not None else None, len(ac), C.byref(out))
     if rc != 0:
         raise RibbitHipError(f"ribbit_host_replay_calls error {rc}: {L.ribbit_hip_last_error().decode()}")
     try:
@@ -251,6 +253,21 @@ def _jobs_with_motifs(jobs, pool: bytes):
     return [(j, pool[int(j["motif_offset"]):int(j["motif_offset"]) + int(j["atomicity"])].decode()) for j in jobs]
 
 
+def host_longest_runs(min_motif: int, max_motif: int, sequence: bytes, seeds):
+    """ribbit_host_longest_runs: longestContinuousMatches of seeds on the composed planes, recomputed on the host. No GPU."""
+    L = load_library()
+    params = ScanParams()
+    L.ribbit_scan_params_default(C.byref(params), min_motif, max_motif)
+    hi, lo, brk = pack_planes(sequence, max_motif)
+    s = np.ascontiguousarray(seeds, dtype=SEED_DT)
+    out = np.zeros(len(s), dtype="<i4")
+    rc = L.ribbit_host_longest_runs(C.byref(params), len(sequence), hi.ctypes.data, lo.ctypes.data, brk.ctypes.data, len(hi),
+                                    s.ctypes.data, len(s), out.ctypes.data)
+    if rc != 0:
+        raise RibbitHipError(f"ribbit_host_longest_runs error {rc}: {L.ribbit_hip_last_error().decode()}")
+    return out
+
+
 def host_refine_jobs(min_motif: int, max_motif: int, sequence: bytes, xa, xa_stride: int, dispatch, refine_params=None):
     """ribbit_host_refine_jobs: dispatch seeds + planes -> (jobs array, motif pool bytes). No GPU needed."""
     L = load_library()
@@ -264,7 +281,7 @@ def host_refine_jobs(min_motif: int, max_motif: int, sequence: bytes, xa, xa_str
     d = np.ascontiguousarray(dispatch, dtype=SEED_DT)
     jobs, nj, pool, npool = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
     rc = L.ribbit_host_refine_jobs(C.byref(params), C.byref(rp), len(sequence), hi.ctypes.data, lo.ctypes.data, brk.ctypes.data,
-                                   len(hi), xa.ctypes.data, xa_stride, d.ctypes.data, len(d),
+                                   len(hi), xa.ctypes.data if xa is not None else None, xa_stride, d.ctypes.data, len(d),
                                    C.byref(jobs), C.byref(nj), C.byref(pool), C.byref(npool))
     if rc != 0:
         raise RibbitHipError(f"ribbit_host_refine_jobs error {rc}: {L.ribbit_hip_last_error().decode()}")
@@ -288,7 +305,7 @@ def host_refine_bed(min_motif: int, max_motif: int, sequence: bytes, xa, xa_stri
     d = np.ascontiguousarray(dispatch, dtype=SEED_DT)
     text, n = C.c_void_p(), C.c_size_t()
     rc = L.ribbit_host_refine_bed(C.byref(params), C.byref(rp), sequence, len(sequence), hi.ctypes.data, lo.ctypes.data,
-                                  brk.ctypes.data, len(hi), xa.ctypes.data, xa_stride, d.ctypes.data, len(d),
+                                  brk.ctypes.data, len(hi), xa.ctypes.data if xa is not None else None, xa_stride, d.ctypes.data, len(d),
                                   sequence_id.encode(), C.byref(text), C.byref(n))
     if rc != 0:
         raise RibbitHipError(f"ribbit_host_refine_bed error {rc}: {L.ribbit_hip_last_error().decode()}")

@@ -99,6 +99,7 @@ struct RibbitHandle {
     bool timing = true;           // record the HIP events behind ribbit_hip_last_timing_ms (each costs a barrier packet on the stream)
     double host_ms = 0.0;         // post-processing of the last scan after its pairing (device state machine, sort, read-back), wall clock
     double merge_ms = 0.0;        // sequential host merge of the last window stage, wall clock
+    double subst_merge_ms = 0.0;  // ... of the substitution stage when ribbit_hip_seeds_anchored ran both
     bool xa_on_device = false;    // the anchored kernel has written the composed planes of the loaded record
     unsigned host_threads = 0;    // worker threads of the host stages (0 = RIBBIT_THREADS or min(cores, 16))
 
@@ -115,7 +116,6 @@ struct RibbitHandle {
     PinnedBuf<uint64_t> h_events;
     PinnedBuf<uint32_t> h_counters;
     PinnedBuf<uint32_t> h_query;
-    PinnedBuf<uint32_t> h_xa;          // host copy of the composed planes (rb::HostPlanes::xa_view points here)
 
     // host copy of the packed planes: answers the sparse, latency-bound range reads of the
     // sequential merges (retainNestedSeed & co) without a GPU round trip per query
@@ -150,9 +150,13 @@ struct RibbitHandle {
     DevBuf<int32_t> d_min_span, d_pend;
     DevBuf<RibbitCall> d_flush;
     DevBuf<uint8_t> d_scratch;
-    PinnedBuf<RibbitCall> h_calls, h_flush;
-    PinnedBuf<int32_t> h_pend;
-    PinnedBuf<uint32_t> h_ws;
+    // results of the substitution [0] and anchored [1] stage, page-locked: both stages' kernels run before either merge
+    PinnedBuf<RibbitCall> h_calls_[2], h_flush_[2];
+    PinnedBuf<int32_t> h_pend_[2];
+    PinnedBuf<uint32_t> h_ws_[2];
+    PinnedBuf<uint32_t> h_xa;          // host copy of the composed planes (rb::HostPlanes::xa_view points here)
+    hipEvent_t ev_xa = nullptr;        // the copy of the composed planes has landed
+    bool xa_copy_pending = false;
     int64_t last_streaks = 0, last_calls = 0, last_edge_calls = 0;
     rb::CallVec perfect_calls;
     bool subst_calls_valid = false;
@@ -216,6 +220,7 @@ int pack_loaded_ascii(RibbitHandle *h, const uint8_t *dev_ascii, int64_t length)
     h->host_planes_valid = false;
     h->eval_valid = false;
     h->xa_on_device = false;
+    if (h->xa_copy_pending) { (void)hipEventSynchronize(h->ev_xa); h->xa_copy_pending = false; }
     h->stage_done = STAGE_NONE;
     h->length = length;
     const int64_t nwords = length / 32 + 1;   // word holding position L is included
@@ -617,6 +622,9 @@ struct DeviceCalls {
 int window_stage_device(RibbitHandle *h, int which, bool full, int (*min_span)(int), DeviceCalls *out) {
     int rc;
     uint32_t n = 0;
+    PinnedBuf<RibbitCall> &h_calls = h->h_calls_[which - 1], &h_flush = h->h_flush_[which - 1];
+    PinnedBuf<int32_t> &h_pend = h->h_pend_[which - 1];
+    PinnedBuf<uint32_t> &h_ws = h->h_ws_[which - 1];
     static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
     const double t_scan = now_ms();
     if ((rc = scan_and_pair_streaks(h, which, &n))) return rc;
@@ -647,8 +655,8 @@ int window_stage_device(RibbitHandle *h, int which, bool full, int (*min_span)(i
     if ((rc = h->d_flush.ensure(nm))) return rc;
     if ((rc = h->d_ws_counters.ensure(rb::WS_WORDS))) return rc;
     if ((rc = h->d_bitmap.ensure(n_words + 1))) return rc;
-    if ((rc = h->h_ws.ensure(rb::WS_WORDS))) return rc;
-    if ((rc = h->h_flush.ensure(nm))) return rc;
+    if ((rc = h_ws.ensure(rb::WS_WORDS))) return rc;
+    if ((rc = h_flush.ensure(nm))) return rc;
     size_t edge_cap = std::max<size_t>(h->d_edge_keys.cap, std::max<size_t>((size_t)1 << 16, n / 16));
     // the events are spent: their buffer (2 x 8 bytes per streak at least) receives the unsorted calls
     uint64_t *keys = h->d_events.p, *vals = h->d_events.p + h->d_events.cap / 2;
@@ -669,17 +677,17 @@ int window_stage_device(RibbitHandle *h, int which, bool full, int (*min_span)(i
         w.flush = h->d_flush.p; w.bitmap = h->d_bitmap.p; w.counters = h->d_ws_counters.p;
         rb::launch_window_calls(w, h->stream);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h->h_ws.p, h->d_ws_counters.p, rb::WS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->h_flush.p, h->d_flush.p, nm * sizeof(RibbitCall), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h_ws.p, h->d_ws_counters.p, rb::WS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h_flush.p, h->d_flush.p, nm * sizeof(RibbitCall), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        n_main = h->h_ws.p[rb::WS_N_MAIN];
-        n_edge = h->h_ws.p[rb::WS_N_EDGE];
+        n_main = h_ws.p[rb::WS_N_MAIN];
+        n_edge = h_ws.p[rb::WS_N_EDGE];
         if (n_edge <= edge_cap || full) break;
         if (attempt == 1) return fail(RIBBIT_E_INTERNAL, "edge-call list overflow");
         edge_cap = (size_t)n_edge + 1024;
     }
     const double t_calls = now_ms();
-    uint32_t wflags = h->h_ws.p[rb::WS_FLAGS];
+    uint32_t wflags = h_ws.p[rb::WS_FLAGS];
     if (wflags) return fail(RIBBIT_E_INTERNAL, "window state machine on the device failed (flags 0x%x)", wflags);
     if (n_main > h->d_events.cap / 2) return fail(RIBBIT_E_INTERNAL, "more calls than streaks");
     // call order: scan position major, motif minor
@@ -704,27 +712,27 @@ int window_stage_device(RibbitHandle *h, int which, bool full, int (*min_span)(i
     RibbitCall *d_calls = reinterpret_cast<RibbitCall *>(h->d_dense.p);
     rb::launch_assemble_calls(h->d_sort_keys.p, h->d_sort_vals.p, n_main, d_calls, h->stream);
     HIP_TRY(hipGetLastError());
-    if ((rc = h->h_calls.ensure(std::max<size_t>(n_main, 1)))) return rc;
-    if (n_main) HIP_TRY(hipMemcpyAsync(h->h_calls.p, d_calls, (size_t)n_main * sizeof(RibbitCall), hipMemcpyDeviceToHost, h->stream));
+    if ((rc = h_calls.ensure(std::max<size_t>(n_main, 1)))) return rc;
+    if (n_main) HIP_TRY(hipMemcpyAsync(h_calls.p, d_calls, (size_t)n_main * sizeof(RibbitCall), hipMemcpyDeviceToHost, h->stream));
     if (bounds) {
-        if ((rc = h->h_pend.ensure(n_main))) return rc;
-        HIP_TRY(hipMemcpyAsync(h->h_pend.p, h->d_pend.p, (size_t)n_main * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->h_ws.p, h->d_ws_counters.p, rb::WS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        if ((rc = h_pend.ensure(n_main))) return rc;
+        HIP_TRY(hipMemcpyAsync(h_pend.p, h->d_pend.p, (size_t)n_main * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h_ws.p, h->d_ws_counters.p, rb::WS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     }
     HIP_TRY(hipEventRecord(h->ev[5], h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->have_timing[2] = true;
-    wflags = h->h_ws.p[rb::WS_FLAGS];
+    wflags = h_ws.p[rb::WS_FLAGS];
     if (wflags) return fail(RIBBIT_E_INTERNAL, "cursor bounds of the edge calls failed (flags 0x%x)", wflags);
     // end-of-sequence calls: at most one per motif, already in motif order; close the gaps
     size_t nf = 0;
     for (uint32_t mi = 0; mi < nm; ++mi)
-        if (h->h_flush.p[mi].mlen != 0) h->h_flush.p[nf++] = h->h_flush.p[mi];
-    out->calls = h->h_calls.p;
+        if (h_flush.p[mi].mlen != 0) h_flush.p[nf++] = h_flush.p[mi];
+    out->calls = h_calls.p;
     out->n = n_main;
-    out->pend = bounds ? h->h_pend.p : nullptr;
-    out->tail_pend = (int32_t)h->h_ws.p[rb::WS_MAX_END] - 1;
-    out->flush = h->h_flush.p;
+    out->pend = bounds ? h_pend.p : nullptr;
+    out->tail_pend = (int32_t)h_ws.p[rb::WS_MAX_END] - 1;
+    out->flush = h_flush.p;
     out->n_flush = nf;
     h->last_calls = n_main;
     h->last_edge_calls = n_edge;
@@ -785,29 +793,36 @@ void replay_subst_compact(rb::SeedLists &lists, const DeviceCalls &dc) {
     }
 }
 
+// host half of the substitution stage: the merges of parse_substitute_shiftxor.cpp:18-388 over the stage's calls
+void subst_merge(RibbitHandle *h, const DeviceCalls *dc) {
+    const rb::HostPlanes *hp = &h->host;
+    h->lists.range_count = [hp](int shift, int start, int end) { return hp->range_count(shift, start, end); };
+    h->lists.subst.clear();
+    const double t0 = now_ms();
+    if (dc) replay_subst_compact(h->lists, *dc);
+    else replay_subst_calls(h->lists, h->subst_calls.data(), h->subst_calls.size());
+    h->merge_ms = now_ms() - t0;
+    h->stage_done = STAGE_SUBST;
+}
+
 int advance_to_subst(RibbitHandle *h) {
     if (h->stage_done >= STAGE_SUBST) return RIBBIT_OK;
     int rc = advance_to_perfect(h);
     if (rc) return rc;
     if ((rc = ensure_host_planes(h))) return rc;
-    const rb::HostPlanes *hp = &h->host;
-    h->lists.range_count = [hp](int shift, int start, int end) { return hp->range_count(shift, start, end); };
-    h->lists.subst.clear();
-    if (h->subst_calls_valid) {
-        replay_subst_calls(h->lists, h->subst_calls.data(), h->subst_calls.size());
-    } else {
-        DeviceCalls dc;
-        if ((rc = window_stage_device(h, 1, false, rb::subst_seedlen_cutoff, &dc))) return rc;
-        const double t0 = now_ms();
-        replay_subst_compact(h->lists, dc);
-        h->merge_ms = now_ms() - t0;
-    }
-    h->stage_done = STAGE_SUBST;
+    DeviceCalls dc;
+    const bool full = h->subst_calls_valid;      // the full call list has been asked for (ribbit_hip_subst_calls): replay that
+    if (!full && (rc = window_stage_device(h, 1, false, rb::subst_seedlen_cutoff, &dc))) return rc;
+    subst_merge(h, full ? nullptr : &dc);
     return RIBBIT_OK;
 }
 
-// The anchored stage's kernel needs room for the composed planes XA_m (they stay in HBM: the device-side refinement
-// scans read them; the host merges recompute the few bits they need from the packed planes).
+// The anchored stage's kernel writes the composed planes XA_m (fasta_utils.cpp:143-161) to HBM: the device-side
+// refinement scans read them there, and the host merges' range reads (retainNestedSeedAnchored,
+// parse_anchored_shiftxor.cpp:59-84: ~200 K per Mbp, each steering the next decision) read a host copy.  Recomputing
+// the slice of a query from the packed planes instead (HostPlanes::xa_slice, what the host-only entry points do when
+// they are not given the planes) costs ~0.6 us per query -- 1.4 s per 20 Mbp against 5 ms for the copy, which
+// moreover runs behind the substitution stage's merge.
 int prepare_anchored(RibbitHandle *h) {
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
     if (h->params.max_motif > rb::ANCHORED_MAX_MOTIF)
@@ -817,18 +832,30 @@ int prepare_anchored(RibbitHandle *h) {
     return h->d_xa.ensure(nm * (size_t)h->xa_stride);
 }
 
-// composed planes -> host (the sequential merges read a few bits at a time, far too often for a GPU round trip each)
-int fetch_xa_host(RibbitHandle *h) {
+// enqueue the copy of the composed planes on the handle's copy stream (behind everything enqueued on the compute
+// stream so far); xa_wait_host() makes them readable
+int xa_copy_begin(RibbitHandle *h) {
     int rc;
     const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
     if ((rc = h->h_xa.ensure(nm * (size_t)h->xa_stride))) return rc;      // page-locked: the copy runs at link speed
+    HIP_TRY(hipEventRecord(h->ev_xa, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->ev_xa, 0));
+    HIP_TRY(hipMemcpyAsync(h->h_xa.p, h->d_xa.p, nm * (size_t)h->xa_stride * sizeof(uint32_t), hipMemcpyDeviceToHost, h->copy_stream));
+    HIP_TRY(hipEventRecord(h->ev_xa, h->copy_stream));
+    h->xa_copy_pending = true;
+    return RIBBIT_OK;
+}
+
+int xa_wait_host(RibbitHandle *h) {
+    if (h->xa_copy_pending) {
+        HIP_TRY(hipEventSynchronize(h->ev_xa));
+        h->xa_copy_pending = false;
+    }
     h->host.xa.clear();
     h->host.xa_view = h->h_xa.p;
     h->host.xa_stride = h->xa_stride;
     h->host.xa_m_lo = h->params.min_motif;
     h->host.xa_m_hi = h->params.max_motif;
-    HIP_TRY(hipMemcpyAsync(h->h_xa.p, h->d_xa.p, nm * (size_t)h->xa_stride * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
     return RIBBIT_OK;
 }
 
@@ -897,31 +924,42 @@ void replay_anchored_device(rb::SeedLists &lists, const DeviceCalls &dc, int64_t
     r.run(dc.flush, dc.n_flush, length);
 }
 
+// processShiftXORswithSubstitutions + processShiftXORsAnchored.  All GPU work of both stages is enqueued before
+// either host merge starts, so the copies (kept calls, composed planes) travel while the host merges.
 int advance_to_anchored(RibbitHandle *h) {
     if (h->stage_done >= STAGE_ANCHORED) return RIBBIT_OK;
-    int rc = advance_to_subst(h);
+    int rc = advance_to_perfect(h);
     if (rc) return rc;
-    // the full call list only when it has been asked for (ribbit_hip_anchored_calls); otherwise the compact form:
-    // nine calls in ten fail the length filter and never leave the device
-    DeviceCalls dc;
+    if ((rc = ensure_host_planes(h))) return rc;
+    DeviceCalls dcs, dca;
+    const bool subst_todo = h->stage_done < STAGE_SUBST;
+    const bool subst_full = h->subst_calls_valid;
+    // the full call lists only when they have been asked for (ribbit_hip_*_calls); otherwise the compact form:
+    // nine anchored calls in ten fail the length filter and never leave the device
+    if (subst_todo && !subst_full && (rc = window_stage_device(h, 1, false, rb::subst_seedlen_cutoff, &dcs))) return rc;
     const bool full = h->anchored_calls_valid;
     if (!full) {
         if ((rc = prepare_anchored(h))) return rc;
-        if ((rc = window_stage_device(h, 2, false, rb::anchored_seedlen_cutoff, &dc))) return rc;
+        if ((rc = window_stage_device(h, 2, false, rb::anchored_seedlen_cutoff, &dca))) return rc;
         h->xa_on_device = true;
     }
-    if ((rc = fetch_xa_host(h))) return rc;
-    const rb::HostPlanes *hp = &h->host;
+    if ((rc = bind_device(h))) return rc;
+    if ((rc = xa_copy_begin(h))) return rc;
+    if (subst_todo) subst_merge(h, subst_full ? nullptr : &dcs);
+    const double merge_s = h->merge_ms;
+    if ((rc = xa_wait_host(h))) return rc;
     // from here on "plane m" means the composed plane XA_m (fasta_utils.cpp:159)
+    const rb::HostPlanes *hp = &h->host;
     h->lists.range_count = [hp](int shift, int start, int end) {
         return hp->has_xa(shift) ? hp->range_count_xa(shift, start, end) : hp->range_count(shift, start, end);
     };
     h->lists.anchored.clear();
     const double t0 = now_ms();
     if (full) replay_anchored_calls(h->lists, h->anchored_calls, h->length);
-    else replay_anchored_device(h->lists, dc, h->length);
+    else replay_anchored_device(h->lists, dca, h->length);
     rb::dispatch_order(h->lists, h->dispatch);
     h->merge_ms = now_ms() - t0;
+    h->subst_merge_ms = subst_todo ? merge_s : 0.0;
     h->stage_done = STAGE_ANCHORED;
     return RIBBIT_OK;
 }
@@ -1054,6 +1092,7 @@ int ribbit_hip_open(const RibbitScanParams *params, int device, RibbitHandle **o
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&h->ev_xa, hipEventDisableTiming);
     for (int i = 0; i < 6 && err == hipSuccess; ++i) err = hipEventCreate(&h->ev[i]);
     if (err != hipSuccess) {
         delete h;
@@ -1072,14 +1111,16 @@ int ribbit_hip_close(RibbitHandle *h) {
     h->d_ascii.release(); h->d_hi.release(); h->d_lo.release(); h->d_brk.release();
     h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release(); h->d_slices.release();
     h->d_ssw_jobs.release(); h->d_ssw_order.release(); h->d_ssw_out.release(); h->d_ssw_pool.release();
-    h->h_events.release(); h->h_counters.release(); h->h_query.release(); h->h_xa.release();
+    h->h_events.release(); h->h_counters.release(); h->h_query.release();
     h->d_pair_table.release(); h->d_run_base.release(); h->d_pair_partial.release(); h->d_pair_status.release();
     h->h_pub.release(); h->h_runs.release(); h->h_halves.release(); h->d_halves.release();
     h->d_eval.release(); h->d_first_rev.release(); h->d_word_tmp.release(); h->d_last_word.release(); h->d_bitmap.release();
     h->d_edge_tmp.release(); h->d_edge_end1.release(); h->d_ws_counters.release(); h->d_group.release(); h->d_sort_keys.release();
     h->d_sort_vals.release(); h->d_edge_keys.release(); h->d_edge_vals.release(); h->d_edge_keys2.release(); h->d_edge_vals2.release();
     h->d_min_span.release(); h->d_pend.release(); h->d_flush.release(); h->d_scratch.release();
-    h->h_calls.release(); h->h_flush.release(); h->h_pend.release(); h->h_ws.release();
+    for (int k = 0; k < 2; ++k) { h->h_calls_[k].release(); h->h_flush_[k].release(); h->h_pend_[k].release(); h->h_ws_[k].release(); }
+    h->h_xa.release();
+    if (h->ev_xa) (void)hipEventDestroy(h->ev_xa);
     for (int i = 0; i < 6; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -1295,8 +1336,10 @@ int ribbit_host_refine_jobs(const RibbitScanParams *params, const RibbitRefinePa
                             const uint32_t *xa, size_t xa_stride, const RibbitSeed *dispatch, size_t n_dispatch,
                             RibbitAlignJob **jobs, size_t *n_jobs, char **motif_pool, size_t *pool_len) {
     if (!params || !prm || !jobs || !n_jobs || !motif_pool || !pool_len || (n_dispatch && !dispatch)) return fail(RIBBIT_E_ARG, "null argument");
-    if (length > 0 && (!hi || !lo || !brk || !xa)) return fail(RIBBIT_E_ARG, "null plane");
-    if (nwords < (size_t)(length / 32 + 1) || xa_stride < (size_t)(length / 32 + 1)) return fail(RIBBIT_E_ARG, "planes too short");
+    if (length > 0 && (!hi || !lo || !brk)) return fail(RIBBIT_E_ARG, "null plane");
+    if (nwords < (size_t)(length / 32 + 1) || (xa && xa_stride < (size_t)(length / 32 + 1))) return fail(RIBBIT_E_ARG, "planes too short");
+    if (!xa && nwords < (size_t)(length / 32 + 1) + (size_t)(params->max_motif + 2) / 32 + 2)
+        return fail(RIBBIT_E_ARG, "planes too short to recompute the composed planes (zero padding past the record)");
     rb::HostPlanes hp;
     hp.resize(length, nwords);
     if (nwords) {
@@ -1305,8 +1348,8 @@ int ribbit_host_refine_jobs(const RibbitScanParams *params, const RibbitRefinePa
         std::memcpy(hp.brk.data(), brk, nwords * sizeof(uint32_t));
     }
     const size_t nm = (size_t)(params->max_motif - params->min_motif + 1);
-    if (xa) hp.xa.assign(xa, xa + nm * xa_stride);
-    hp.xa_stride = (int64_t)xa_stride;
+    if (xa) hp.xa.assign(xa, xa + nm * xa_stride);        // else: recomputed slice by slice from the packed planes
+    hp.xa_stride = xa ? (int64_t)xa_stride : 0;
     hp.xa_m_lo = params->min_motif;
     hp.xa_m_hi = params->max_motif;
     std::vector<RibbitSeed> seeds(dispatch, dispatch + n_dispatch);
@@ -1322,6 +1365,26 @@ int ribbit_host_refine_jobs(const RibbitScanParams *params, const RibbitRefinePa
     if (!*jobs || !*motif_pool) { std::free(*jobs); std::free(*motif_pool); return fail(RIBBIT_E_NOMEM, "out of host memory"); }
     if (!out.empty()) std::memcpy(*jobs, out.data(), out.size() * sizeof(RibbitAlignJob));
     std::memcpy(*motif_pool, pool.c_str(), pool.size() + 1);
+    return RIBBIT_OK;
+}
+
+int ribbit_host_longest_runs(const RibbitScanParams *params, int64_t length, const uint32_t *hi, const uint32_t *lo,
+                             const uint32_t *brk, size_t nwords, const RibbitSeed *seeds, size_t n, int32_t *out) {
+    if (!params || (n && (!seeds || !out)) || (length > 0 && (!hi || !lo || !brk))) return fail(RIBBIT_E_ARG, "null argument");
+    if (nwords < (size_t)(length / 32 + 1) + (size_t)(params->max_motif + 2) / 32 + 2)
+        return fail(RIBBIT_E_ARG, "planes too short (zero padding past the record)");
+    rb::HostPlanes hp;
+    hp.resize(length, nwords);
+    std::memcpy(hp.hi.data(), hi, nwords * sizeof(uint32_t));
+    std::memcpy(hp.lo.data(), lo, nwords * sizeof(uint32_t));
+    std::memcpy(hp.brk.data(), brk, nwords * sizeof(uint32_t));
+    hp.xa_m_lo = params->min_motif;
+    hp.xa_m_hi = params->max_motif;
+    for (size_t i = 0; i < n; ++i) {
+        if (seeds[i].start < 0 || seeds[i].end > length || seeds[i].start > seeds[i].end || seeds[i].mlen < 1 || seeds[i].mlen > params->max_motif + 2)
+            return fail(RIBBIT_E_ARG, "seed %zu outside the record or the shift range", i);
+        out[i] = rb::longest_run_host(hp, seeds[i].mlen, seeds[i].start, seeds[i].end);
+    }
     return RIBBIT_OK;
 }
 
@@ -1380,8 +1443,10 @@ int ribbit_host_refine_bed(const RibbitScanParams *params, const RibbitRefinePar
                            const uint32_t *xa, size_t xa_stride, const RibbitSeed *dispatch, size_t n_dispatch,
                            const char *sequence_id, char **text, size_t *len) {
     if (!params || !prm || !text || !len || !sequence_id || (n_dispatch && !dispatch)) return fail(RIBBIT_E_ARG, "null argument");
-    if (length > 0 && (!sequence || !hi || !lo || !brk || !xa)) return fail(RIBBIT_E_ARG, "null plane");
-    if (nwords < (size_t)(length / 32 + 1) || xa_stride < (size_t)(length / 32 + 1)) return fail(RIBBIT_E_ARG, "planes too short");
+    if (length > 0 && (!sequence || !hi || !lo || !brk)) return fail(RIBBIT_E_ARG, "null plane");
+    if (nwords < (size_t)(length / 32 + 1) || (xa && xa_stride < (size_t)(length / 32 + 1))) return fail(RIBBIT_E_ARG, "planes too short");
+    if (!xa && nwords < (size_t)(length / 32 + 1) + (size_t)(params->max_motif + 2) / 32 + 2)
+        return fail(RIBBIT_E_ARG, "planes too short to recompute the composed planes (zero padding past the record)");
     rb::HostPlanes hp;
     hp.resize(length, nwords);
     if (nwords) {
@@ -1390,8 +1455,8 @@ int ribbit_host_refine_bed(const RibbitScanParams *params, const RibbitRefinePar
         std::memcpy(hp.brk.data(), brk, nwords * sizeof(uint32_t));
     }
     const size_t nm = (size_t)(params->max_motif - params->min_motif + 1);
-    if (xa) hp.xa.assign(xa, xa + nm * xa_stride);
-    hp.xa_stride = (int64_t)xa_stride;
+    if (xa) hp.xa.assign(xa, xa + nm * xa_stride);        // else: recomputed slice by slice from the packed planes
+    hp.xa_stride = xa ? (int64_t)xa_stride : 0;
     hp.xa_m_lo = params->min_motif;
     hp.xa_m_hi = params->max_motif;
     std::vector<RibbitSeed> seeds(dispatch, dispatch + n_dispatch);
@@ -1619,7 +1684,7 @@ int ribbit_host_scan_from_events(const RibbitScanParams *params, int64_t length,
     if (!params || !out || !cnt_perfect || !cnt_subst || (length > 0 && (!hi || !lo || !brk))) return fail(RIBBIT_E_ARG, "null argument");
     const size_t need = (size_t)(length / 32 + 1) + (size_t)(params->max_motif + 2) / 32 + 2;
     if (nwords < need) return fail(RIBBIT_E_ARG, "planes too short: %zu words, need %zu", nwords, need);
-    if (cnt_anchored && (!xa || xa_stride < (size_t)(length / 32 + 1))) return fail(RIBBIT_E_ARG, "anchored events need the composed planes (xa)");
+    if (cnt_anchored && xa && xa_stride < (size_t)(length / 32 + 1)) return fail(RIBBIT_E_ARG, "composed planes (xa) too short");
     std::memset(out, 0, sizeof *out);
     const size_t nm = (size_t)(params->max_motif - params->min_motif + 1);
     rb::HostPlanes hp;
@@ -1658,8 +1723,8 @@ int ribbit_host_scan_from_events(const RibbitScanParams *params, int64_t length,
     replay_subst_calls(sl, calls.data(), calls.size());
     std::vector<RibbitSeed> dispatch;
     if (cnt_anchored) {
-        hp.xa.assign(xa, xa + nm * xa_stride);
-        hp.xa_stride = (int64_t)xa_stride;
+        if (xa) hp.xa.assign(xa, xa + nm * xa_stride);        // else: recomputed slice by slice from the packed planes
+        hp.xa_stride = xa ? (int64_t)xa_stride : 0;
         hp.xa_m_lo = params->min_motif;
         hp.xa_m_hi = params->max_motif;
         sl.range_count = [&hp](int shift, int start, int end) {
@@ -1718,7 +1783,7 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
         return fail(RIBBIT_E_ARG, "null call list");
     const size_t need = (size_t)(length / 32 + 1) + (size_t)(params->max_motif + 2) / 32 + 2;
     if (nwords < need) return fail(RIBBIT_E_ARG, "planes too short: %zu words, need %zu (zero padding past the record)", nwords, need);
-    if (n_anchored_calls && (!xa || xa_stride < (size_t)(length / 32 + 1))) return fail(RIBBIT_E_ARG, "anchored calls need the composed planes (xa)");
+    if (xa && xa_stride < (size_t)(length / 32 + 1)) return fail(RIBBIT_E_ARG, "composed planes (xa) too short");
     std::memset(out, 0, sizeof *out);
     rb::HostPlanes hp;
     hp.resize(length, nwords);
@@ -1733,10 +1798,13 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
     sl.range_count = [&hp](int shift, int start, int end) { return hp.range_count(shift, start, end); };
     for (size_t i = 0; i < n_perfect_calls; ++i) rb::perfect_add(sl, perfect_calls[i].start, perfect_calls[i].end, perfect_calls[i].mlen);
     replay_subst_calls(sl, subst_calls, n_subst_calls);
-    if (xa) {
+    // the anchored stage runs when there are anchored calls or composed planes are given; anchored_calls non-null with
+    // n == 0 also asks for it (a record whose anchored scan made no call still gets its dispatch list)
+    const bool anchored_stage = n_anchored_calls || xa || anchored_calls;
+    if (anchored_stage) {
         const size_t nm = (size_t)(params->max_motif - params->min_motif + 1);
-        hp.xa.assign(xa, xa + nm * xa_stride);
-        hp.xa_stride = (int64_t)xa_stride;
+        if (xa) hp.xa.assign(xa, xa + nm * xa_stride);        // else: recomputed slice by slice from the packed planes
+        hp.xa_stride = xa ? (int64_t)xa_stride : 0;
         hp.xa_m_lo = params->min_motif;
         hp.xa_m_hi = params->max_motif;
         sl.range_count = [&hp](int shift, int start, int end) {
@@ -1744,7 +1812,7 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
         };
     }
     std::vector<RibbitSeed> dispatch;
-    if (n_anchored_calls || xa) {
+    if (anchored_stage) {
         rb::CallVec ac(anchored_calls, anchored_calls + n_anchored_calls);
         replay_anchored_calls(sl, ac, length);
         rb::dispatch_order(sl, dispatch);
@@ -1843,7 +1911,8 @@ int ribbit_hip_last_timing_ms(const RibbitHandle *h, int what, double *ms) {
     if (!h || !ms) return fail(RIBBIT_E_ARG, "null argument");
     if (what == 3) { *ms = h->host_ms; return RIBBIT_OK; }
     if (what == 4) { *ms = h->merge_ms; return RIBBIT_OK; }
-    if (what < 0 || what > 4) return fail(RIBBIT_E_ARG, "what must be 0..4");
+    if (what == 5) { *ms = h->subst_merge_ms; return RIBBIT_OK; }
+    if (what < 0 || what > 5) return fail(RIBBIT_E_ARG, "what must be 0..5");
     if (!h->have_timing[what]) return fail(RIBBIT_E_STATE, "no timing recorded yet");
     float f = 0.f;
     HIP_TRY(hipEventSynchronize(h->ev[2 * what + 1]));

@@ -22,13 +22,23 @@ struct HostPlanes {
     // because an N lies in [q, q+7] (`valid_position < window_length`, parse_substitute_shiftxor.cpp:469)
     std::vector<std::pair<int64_t, int64_t>> blocked;
 
-    // composed planes XA_m of the anchored stage (fasta_utils.cpp:143-161), motif-major, xa_stride
-    // words per motif; written by the anchored kernel and copied back once
+    // Composed planes XA_m of the anchored stage (fasta_utils.cpp:143-161) for m = xa_m_lo..xa_m_hi:
+    // XA_m = X_m | anchor_{m-2} | anchor_{m-1} | anchor_{m+1} | anchor_{m+2}, anchor_s = the runs of X_s ones with
+    // 3 <= length < 2s that a zero closes at a position <= L-1-s (parse_anchored_shiftxor.cpp:20-56).  The GPU keeps
+    // them in HBM for its own refinement scans; the host merges read a few dozen bits at a time, so the slice a
+    // query needs is recomputed here from the packed planes (a run of length < 2s is visible within 2s bases of
+    // the slice).  Callers of the host-only entry points may instead supply the planes (xa / xa_view, motif-major,
+    // xa_stride words per motif).
     std::vector<uint32_t> xa;
-    const uint32_t *xa_view = nullptr;     // when set: the planes live in memory the caller owns (page-locked D2H target)
+    const uint32_t *xa_view = nullptr;     // when set: the planes live in memory the caller owns
     const uint32_t *xa_words() const { return xa_view ? xa_view : xa.data(); }
+    bool xa_stored() const { return xa_stride > 0 && (xa_view != nullptr || !xa.empty()); }
     int64_t xa_stride = 0;
     int xa_m_lo = 0, xa_m_hi = -1;
+    // words of XA_mlen covering [start, end): out[0] holds positions (start & ~31) .. +31; bits outside [start, end) are 0
+    void xa_slice(int mlen, int start, int end, std::vector<uint32_t> &out) const;
+    // adds the bits of anchor_shift over [start, end) to out (same layout)
+    void anchor_slice(int shift, int start, int end, std::vector<uint32_t> &out) const;
 
     void resize(int64_t len, size_t nwords) {
         length = len;

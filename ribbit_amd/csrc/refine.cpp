@@ -207,10 +207,12 @@ int consensus_row(const Bases &b, int seed_start, int seq_len, int m) {
 }  // namespace
 
 int longest_run_host(const HostPlanes &hp, int mlen, int start, int end) {
-    const uint32_t *w = hp.xa_words() + (int64_t)(mlen - hp.xa_m_lo) * hp.xa_stride;
+    static thread_local std::vector<uint32_t> w;
+    hp.xa_slice(mlen, start, end, w);
+    const int base = (start >> 5) << 5;
     int best = 0, run = 0;
     for (int p = start; p < end; ++p) {
-        if ((w[p >> 5] >> (p & 31)) & 1u) { ++run; best = std::max(best, run); }
+        if ((w[(size_t)((p - base) >> 5)] >> (p & 31)) & 1u) { ++run; best = std::max(best, run); }
         else run = 0;
     }
     return best;

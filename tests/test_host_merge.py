@@ -52,6 +52,40 @@ def test_replay_of_oracle_calls_reproduces_oracle_lists(name, seq, m_lo, m_hi):
         assert np.array_equal(r["anchored"].view("<i4"), o.seeds(LIST_ANCHORED).view("<i4"))
         assert np.array_equal(r["dispatch"].view("<i4"), o.dispatch().view("<i4"))
         assert r["guard_hits"] == o.guard_hits()
+        # the same without being given the composed planes: the merges' range reads recompute the slice of XA_m they
+        # need from the packed planes (what the GPU path does: the planes the kernel composed never leave HBM)
+        r2 = ribbit_amd.host_replay_calls(m_lo, m_hi, seq, pcalls, scalls, o.calls(LIST_ANCHORED))
+        for k in ("perfect", "subst", "anchored", "dispatch"):
+            assert np.array_equal(r2[k].view("<i4"), r[k].view("<i4")), k
+        assert r2["guard_hits"] == r["guard_hits"]
+
+
+@pytest.mark.parametrize("name,seq,m_lo,m_hi", ALL, ids=[c[0] for c in ALL])
+def test_recomputed_composed_plane_slices_equal_the_oracles_planes(name, seq, m_lo, m_hi):
+    """HostPlanes::xa_slice against the oracle's composed planes (fasta_utils.cpp:143-161), through the longest-run scan of
+    ribbit_host_refine_jobs' set-up: random intervals of every motif, with and without the planes supplied."""
+    if len(seq) < 8:
+        pytest.skip("too short for an interval")
+    rs = np.random.RandomState(len(seq) + m_hi)
+    with Oracle(seq, m_lo, m_hi) as o:
+        o.run_perfect(); o.run_subst(); o.run_anchor_planes()
+        planes = {m: o.plane(m) for m in range(m_lo, m_hi + 1)}
+    L = len(seq)
+    ms = list(range(m_lo, m_hi + 1)) if m_hi - m_lo < 24 else sorted(set(int(x) for x in rs.randint(m_lo, m_hi + 1, 24)) | {m_lo, m_hi})
+    seeds = []
+    for m in ms:
+        for _ in range(12):
+            a = int(rs.randint(0, L - 1))
+            b = int(min(L, a + 1 + rs.randint(0, min(L, 40 * m + 64))))
+            seeds.append((a, b, m, 0))
+        seeds.append((0, L, m, 0))
+        seeds.append((max(0, L - 3 * m - 5), L, m, 0))
+    got = ribbit_amd.host_longest_runs(m_lo, m_hi, seq, np.array(seeds, dtype=ribbit_amd.SEED_DT))
+    for (a, b, m, _), g in zip(seeds, got):
+        bits = planes[m][a:b].astype(np.int8)
+        d = np.diff(np.concatenate(([0], bits, [0])))
+        runs = np.flatnonzero(d == -1) - np.flatnonzero(d == 1)
+        assert g == (int(runs.max()) if len(runs) else 0), (m, a, b)
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=lambda p: os.path.basename(p)[:-4])

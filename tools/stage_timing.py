@@ -20,14 +20,12 @@ with ribbit_amd.Scanner(2, m_hi) as sc:
         t = time.perf_counter(); runs = sc.scan_perfect_runs(); dt = time.perf_counter() - t
         print(f"perfect: wall {1e3*dt:.1f} ms  kernel {sc.timing_ms(1):.3f} ms  gpu {sc.timing_ms(2):.3f} ms  events {sc.last_event_count()}  runs {len(runs)}")
         t = time.perf_counter(); seeds = sc.processShiftXORsPerfect(); print(f"perfect seeds {len(seeds)}  wall {1e3*(time.perf_counter()-t):.1f} ms")
-        t = time.perf_counter(); p, s = sc.processShiftXORswithSubstitutions(); dt = time.perf_counter() - t
-        print(f"subst stage: wall {1e3*dt:.1f} ms  kernel {sc.timing_ms(1):.3f} ms  device state machine + sort + read-back {sc.timing_ms(3):.1f} ms  "
-              f"host merge {sc.timing_ms(4):.1f} ms  events {sc.last_event_count()}  seeds {len(s)}")
-        if m_hi <= 990:
-            t = time.perf_counter(); p, s, a = sc.processShiftXORsAnchored(); dt = time.perf_counter() - t
-            d = sc.dispatch_seeds()
-            print(f"anchored stage: wall {1e3*dt:.1f} ms  kernel {sc.timing_ms(1):.3f} ms  device state machine + sort + read-back {sc.timing_ms(3):.1f} ms  "
-                  f"host merge {sc.timing_ms(4):.1f} ms  events {sc.last_event_count()}  seeds {len(a)} dispatch {len(d)} guards {sc.guard_hits()}")
+        if m_hi > 990:
+            continue
+        t = time.perf_counter(); p, s, a = sc.processShiftXORsAnchored(); dt = time.perf_counter() - t
+        d = sc.dispatch_seeds()
+        print(f"substitution + anchored stages: wall {1e3*dt:.1f} ms  anchored kernel {sc.timing_ms(1):.3f} ms  host merges {sc.timing_ms(5):.1f} + {sc.timing_ms(4):.1f} ms  "
+              f"seeds {len(s)} + {len(a)}  dispatch {len(d)}  guards {sc.guard_hits()}")
     # the full call lists (the parity entry points), warm
     sc.load_record(seq)
     t = time.perf_counter(); calls = sc.subst_calls(); print(f"subst_calls (full list): wall {1e3*(time.perf_counter()-t):.1f} ms  calls {len(calls)}")
