@@ -381,6 +381,13 @@ int ribbit_hip_debug_pair_events(RibbitHandle *h, const uint64_t *events, size_t
  * makes a scan overflow its regions, after which it is sized for the fullest region and run again. */
 int ribbit_hip_debug_set_event_capacity(RibbitHandle *h, size_t events);
 
+/* Test hook: the window stages' merges run as independent position ranges on host threads (RIBBIT_THREADS, default
+ * min(cores, 16)) wherever the call sequence can be cut; this sets the smallest number of calls per range (default 4096). */
+void ribbit_debug_set_merge_min_range(size_t calls);
+/* Test hook: what the last merge of a stage (0 substitution, 1 anchored) on the calling thread did: out = {ranges, ranges
+ * merged again after validation, whole stage redone in order (0/1), list-head writes that forced it, first range empty (0/1)}. */
+void ribbit_debug_last_merge(int stage, int32_t out[5]);
+
 /* HIP events behind ribbit_hip_last_timing_ms are recorded by default; every record is a barrier packet between two
  * kernels of the stream (~6 us each on MI355X).  A caller that streams many records can switch them off per handle
  * (ribbit_hip_last_timing_ms then fails with RIBBIT_E_STATE for the pack / scan / GPU-side intervals). */

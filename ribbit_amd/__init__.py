@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_range_popcount", "ribbit_hip_plane_words", "ribbit_hip_packed_plane",
     "ribbit_hip_last_timing_ms", "ribbit_hip_last_event_count",
     "ribbit_hip_subst_calls", "ribbit_hip_seeds_substitutions",
-    "ribbit_host_replay_calls", "ribbit_seed_lists_free", "ribbit_host_longest_runs",
+    "ribbit_host_replay_calls", "ribbit_seed_lists_free", "ribbit_host_longest_runs", "ribbit_debug_set_merge_min_range", "ribbit_debug_last_merge",
     "ribbit_hip_anchored_calls", "ribbit_hip_seeds_anchored", "ribbit_hip_dispatch_seeds", "ribbit_hip_guard_hits",
     "ribbit_hip_debug_stream_read",
     "ribbit_refine_params_default", "ribbit_hip_seed_longest_runs", "ribbit_hip_refine_jobs",
@@ -121,6 +121,10 @@ def load_library():
                                            vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(SeedLists)]
     L.ribbit_seed_lists_free.restype = None
     L.ribbit_seed_lists_free.argtypes = [C.POINTER(SeedLists)]
+    L.ribbit_debug_last_merge.restype = None
+    L.ribbit_debug_last_merge.argtypes = [C.c_int, C.POINTER(C.c_int32 * 5)]
+    L.ribbit_debug_set_merge_min_range.restype = None
+    L.ribbit_debug_set_merge_min_range.argtypes = [C.c_size_t]
     L.ribbit_host_longest_runs.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp]
     L.ribbit_hip_plane_bits.argtypes = [vp, i32, i64, i64, vp]
     L.ribbit_hip_range_popcount.argtypes = [vp, i32, i64, i64, C.POINTER(i32)]

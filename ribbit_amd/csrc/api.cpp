@@ -19,6 +19,7 @@
 #include "event_stream.h"
 #include "host_planes.h"
 #include "kernels.h"
+#include "parallel_merge.h"
 #include "refine.h"
 #include "ssw_exact.h"
 #include "ribbit_hip.h"
@@ -607,15 +608,7 @@ int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks) {
     return RIBBIT_OK;
 }
 
-// What a window stage hands the host merges (see rb::CompactCalls): views of handle-owned pinned memory.
-struct DeviceCalls {
-    const RibbitCall *calls = nullptr;   // in call order; compact mode: only those that pass the length filter
-    size_t n = 0;
-    const int32_t *pend = nullptr;       // compact mode: per call, largest end of any earlier call that matters (-1: none); null = all -1
-    int32_t tail_pend = -1;              // largest end of any in-loop call
-    const RibbitCall *flush = nullptr;   // end-of-sequence calls, motif order
-    size_t n_flush = 0;
-};
+using DeviceCalls = rb::KeptCalls;      // views of handle-owned page-locked memory
 
 // The whole window stage on the device (window_stage.hip).  full: every call, unfiltered (the call-list entry points
 // and the parity tests); otherwise only the calls that pass min_span, with their cursor bounds.
@@ -762,47 +755,22 @@ int build_subst_calls(RibbitHandle *h) {
     return RIBBIT_OK;
 }
 
-// Calls that fail the length filter only move the perfect-list cursor (parse_substitute_shiftxor.cpp:34-44);
-// their effect is folded into one advance with the running maximum of their ends (see advance_cursor).
-void replay_subst_calls(rb::SeedLists &lists, const RibbitCall *calls, size_t n) {
-    int from_index = 0;
-    int pending_end = -1;
-    for (size_t i = 0; i < n; ++i) {
-        const RibbitCall &c = calls[i];
-        if (c.end - c.start < rb::subst_seedlen_cutoff(c.mlen)) { pending_end = std::max(pending_end, c.end); continue; }
-        if (pending_end >= 0) { from_index = rb::advance_cursor(lists.perfect, from_index, pending_end); pending_end = -1; }
-        from_index = rb::subst_add(lists, c.start, c.end, c.mlen, from_index, RIBBIT_RANK_S);
-    }
-}
-
-// the same from what the device stage kept: calls that pass the filter, each with the largest end of any earlier call
-// that can matter to its cursor; the end-of-sequence calls come unfiltered
-void replay_subst_compact(rb::SeedLists &lists, const DeviceCalls &dc) {
-    int from_index = 0;
-    for (size_t i = 0; i < dc.n; ++i) {
-        const RibbitCall &c = dc.calls[i];
-        if (dc.pend && dc.pend[i] >= 0) from_index = rb::advance_cursor(lists.perfect, from_index, dc.pend[i]);
-        from_index = rb::subst_add(lists, c.start, c.end, c.mlen, from_index, RIBBIT_RANK_S);
-    }
-    int pending_end = dc.tail_pend;
-    for (size_t i = 0; i < dc.n_flush; ++i) {
-        const RibbitCall &c = dc.flush[i];
-        if (c.end - c.start < rb::subst_seedlen_cutoff(c.mlen)) { pending_end = std::max(pending_end, c.end); continue; }
-        if (pending_end >= 0) { from_index = rb::advance_cursor(lists.perfect, from_index, pending_end); pending_end = -1; }
-        from_index = rb::subst_add(lists, c.start, c.end, c.mlen, from_index, RIBBIT_RANK_S);
-    }
-}
-
 // host half of the substitution stage: the merges of parse_substitute_shiftxor.cpp:18-388 over the stage's calls
 void subst_merge(RibbitHandle *h, const DeviceCalls *dc) {
     const rb::HostPlanes *hp = &h->host;
     h->lists.range_count = [hp](int shift, int start, int end) { return hp->range_count(shift, start, end); };
     h->lists.subst.clear();
     const double t0 = now_ms();
-    if (dc) replay_subst_compact(h->lists, *dc);
-    else replay_subst_calls(h->lists, h->subst_calls.data(), h->subst_calls.size());
+    const unsigned threads = rb::merge_threads(h->host_threads);
+    rb::MergeStats st;
+    if (dc) rb::merge_subst_stage(h->lists, *dc, threads, &st);
+    else rb::merge_subst_stage_full(h->lists, h->subst_calls.data(), h->subst_calls.size(), threads, &st);
     h->merge_ms = now_ms() - t0;
     h->stage_done = STAGE_SUBST;
+    static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
+    if (profile)
+        std::fprintf(stderr, "[subst merge] %zu seeds: %u ranges on %u threads%s, preparation %.1f ms, merges %.1f ms\n", h->lists.subst.size(), st.ranges,
+                     st.threads, st.redone_in_order ? " (REDONE IN ORDER)" : "", st.prepare_ms, st.merge_ms);
 }
 
 int advance_to_subst(RibbitHandle *h) {
@@ -873,57 +841,6 @@ int build_anchored_calls(RibbitHandle *h) {
     return RIBBIT_OK;
 }
 
-// Replay of the anchored call list.  In the reference every in-loop call updates the cursor pair,
-// but the end-of-sequence flush keeps the returned cursors only for the first of the two calls it
-// makes when a motif has both a pending group and an unmerged open streak
-// (parse_anchored_shiftxor.cpp:713 vs :688,:697,:706,:717).
-struct AnchoredReplay {
-    rb::SeedLists &lists;
-    rb::Cursor2 cur;
-    int pending_end = -1;   // largest seed_end among in-loop calls that only moved the cursors (:133-153)
-    void catch_up() {
-        if (pending_end < 0) return;
-        cur.perfect = rb::advance_cursor(lists.perfect, cur.perfect, pending_end);
-        cur.subst = rb::advance_cursor(lists.subst, cur.subst, pending_end);
-        pending_end = -1;
-    }
-    void call(const RibbitCall &c, bool keeps_cursor) {
-        if (c.end - c.start < rb::anchored_seedlen_cutoff(c.mlen)) {
-            if (keeps_cursor) pending_end = std::max(pending_end, c.end);
-            return;
-        }
-        catch_up();
-        const rb::Cursor2 next = rb::anchored_add(lists, c.start, c.end, c.mlen, cur, RIBBIT_RANK_A);
-        if (keeps_cursor) cur = next;
-    }
-    // calls[first, n): the tail of a call list that may hold the end-of-sequence flush
-    void run(const RibbitCall *calls, size_t n, int64_t length) {
-        for (size_t i = 0; i < n; ++i) {
-            const RibbitCall &c = calls[i];
-            const bool flush = c.pos == (int32_t)length;
-            const bool first_of_two = flush && i + 1 < n && calls[i + 1].pos == c.pos && calls[i + 1].mlen == c.mlen;
-            call(c, !flush || first_of_two);
-        }
-    }
-};
-
-void replay_anchored_calls(rb::SeedLists &lists, const rb::CallVec &calls, int64_t length) {
-    AnchoredReplay r{lists, rb::Cursor2{}};
-    r.run(calls.data(), calls.size(), length);
-}
-
-// and from what the device stage kept (DeviceCalls): the bound of a call covers every earlier call, which by
-// advance_cursor's monotonicity is the same as covering those since the previous kept call
-void replay_anchored_device(rb::SeedLists &lists, const DeviceCalls &dc, int64_t length) {
-    AnchoredReplay r{lists, rb::Cursor2{}};
-    for (size_t i = 0; i < dc.n; ++i) {
-        if (dc.pend) r.pending_end = std::max(r.pending_end, dc.pend[i]);
-        r.call(dc.calls[i], true);
-    }
-    r.pending_end = std::max(r.pending_end, dc.tail_pend);
-    r.run(dc.flush, dc.n_flush, length);
-}
-
 // processShiftXORswithSubstitutions + processShiftXORsAnchored.  All GPU work of both stages is enqueued before
 // either host merge starts, so the copies (kept calls, composed planes) travel while the host merges.
 int advance_to_anchored(RibbitHandle *h) {
@@ -955,10 +872,17 @@ int advance_to_anchored(RibbitHandle *h) {
     };
     h->lists.anchored.clear();
     const double t0 = now_ms();
-    if (full) replay_anchored_calls(h->lists, h->anchored_calls, h->length);
-    else replay_anchored_device(h->lists, dca, h->length);
+    const unsigned threads = rb::merge_threads(h->host_threads);
+    rb::MergeStats st;
+    if (full) rb::merge_anchored_stage_full(h->lists, h->anchored_calls.data(), h->anchored_calls.size(), threads, &st);
+    else rb::merge_anchored_stage(h->lists, dca, threads, &st);
+    const double t1 = now_ms();
     rb::dispatch_order(h->lists, h->dispatch);
     h->merge_ms = now_ms() - t0;
+    static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
+    if (profile)
+        std::fprintf(stderr, "[anchored merge] %zu seeds: %u ranges on %u threads%s, preparation %.1f ms, merges %.1f ms, dispatch order %.1f ms\n",
+                     h->lists.anchored.size(), st.ranges, st.threads, st.redone_in_order ? (st.head_writes ? " (REDONE IN ORDER: list-head writes)" : " (REDONE IN ORDER: first range empty)") : "", st.prepare_ms, st.merge_ms, now_ms() - t1);
     h->subst_merge_ms = subst_todo ? merge_s : 0.0;
     h->stage_done = STAGE_ANCHORED;
     return RIBBIT_OK;
@@ -1634,6 +1558,14 @@ int ribbit_hip_debug_set_event_capacity(RibbitHandle *h, size_t events) {
     return RIBBIT_OK;
 }
 
+void ribbit_debug_set_merge_min_range(size_t calls) { rb::set_merge_min_range(calls); }
+
+void ribbit_debug_last_merge(int stage, int32_t out[5]) {
+    const rb::MergeStats st = rb::last_merge_stats(stage);
+    out[0] = (int32_t)st.ranges; out[1] = (int32_t)st.ranges_redone; out[2] = st.redone_in_order ? 1 : 0;
+    out[3] = (int32_t)std::min<long long>(st.head_writes, INT32_MAX); out[4] = st.first_range_empty ? 1 : 0;
+}
+
 int ribbit_hip_set_timing(RibbitHandle *h, int32_t enabled) {
     if (!h) return fail(RIBBIT_E_ARG, "null argument");
     h->timing = enabled != 0;
@@ -1720,7 +1652,7 @@ int ribbit_host_scan_from_events(const RibbitScanParams *params, int64_t length,
     rb::perfect_calls_from_runs(runs.data(), runs.size(), length, sl.min_shift, calls);
     for (const RibbitCall &c : calls) rb::perfect_add(sl, c.start, c.end, c.mlen);
     if (!rb::replay_window_events(source(ev_subst, cnt_subst, segs), hp, calls, &why)) return fail(RIBBIT_E_INTERNAL, "substitution events: %s", why.c_str());
-    replay_subst_calls(sl, calls.data(), calls.size());
+    rb::merge_subst_stage_full(sl, calls.data(), calls.size(), rb::merge_threads(0));
     std::vector<RibbitSeed> dispatch;
     if (cnt_anchored) {
         if (xa) hp.xa.assign(xa, xa + nm * xa_stride);        // else: recomputed slice by slice from the packed planes
@@ -1731,7 +1663,7 @@ int ribbit_host_scan_from_events(const RibbitScanParams *params, int64_t length,
             return hp.has_xa(shift) ? hp.range_count_xa(shift, start, end) : hp.range_count(shift, start, end);
         };
         if (!rb::replay_window_events(source(ev_anchored, cnt_anchored, segs), hp, calls, &why)) return fail(RIBBIT_E_INTERNAL, "anchored events: %s", why.c_str());
-        replay_anchored_calls(sl, calls, length);
+        rb::merge_anchored_stage_full(sl, calls.data(), calls.size(), rb::merge_threads(0));
         rb::dispatch_order(sl, dispatch);
     }
     auto give = [](const std::vector<RibbitSeed> &v, RibbitSeed **p, size_t *n) {
@@ -1797,7 +1729,7 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
     sl.min_shift = (params->min_motif > 2) ? params->min_motif - 2 : 1;
     sl.range_count = [&hp](int shift, int start, int end) { return hp.range_count(shift, start, end); };
     for (size_t i = 0; i < n_perfect_calls; ++i) rb::perfect_add(sl, perfect_calls[i].start, perfect_calls[i].end, perfect_calls[i].mlen);
-    replay_subst_calls(sl, subst_calls, n_subst_calls);
+    rb::merge_subst_stage_full(sl, subst_calls, n_subst_calls, rb::merge_threads(0));
     // the anchored stage runs when there are anchored calls or composed planes are given; anchored_calls non-null with
     // n == 0 also asks for it (a record whose anchored scan made no call still gets its dispatch list)
     const bool anchored_stage = n_anchored_calls || xa || anchored_calls;
@@ -1813,8 +1745,7 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
     }
     std::vector<RibbitSeed> dispatch;
     if (anchored_stage) {
-        rb::CallVec ac(anchored_calls, anchored_calls + n_anchored_calls);
-        replay_anchored_calls(sl, ac, length);
+        rb::merge_anchored_stage_full(sl, anchored_calls, n_anchored_calls, rb::merge_threads(0));
         rb::dispatch_order(sl, dispatch);
     }
     auto give = [](const std::vector<RibbitSeed> &v, RibbitSeed **p, size_t *n) {

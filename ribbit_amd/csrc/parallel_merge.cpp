@@ -1,0 +1,448 @@
+// parallel_merge.cpp -- see parallel_merge.h.
+#include "parallel_merge.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <climits>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+namespace rb {
+
+namespace {
+
+std::atomic<size_t> g_min_range{4096};
+thread_local MergeStats tl_last_stats[2];      // [0] substitution, [1] anchored stage: last merge on this thread
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------------------------- in call order
+// Replay of anchored calls.  In the reference every in-loop call updates the cursor pair, but the end-of-sequence
+// flush keeps the returned cursors only for the first of the two calls it makes when a motif has both a pending
+// group and an unmerged open streak (parse_anchored_shiftxor.cpp:713 vs :688,:697,:706,:717).
+template <class Lists>
+struct AnchoredReplay {
+    Lists &lists;
+    Cursor2 cur;
+    int pending_end = -1;   // largest seed_end among in-loop calls that only moved the cursors (:133-153)
+    void catch_up() {
+        if (pending_end < 0) return;
+        cur.perfect = advance_cursor(lists.perfect, cur.perfect, pending_end);
+        cur.subst = advance_cursor(lists.subst, cur.subst, pending_end);
+        pending_end = -1;
+    }
+    void call(const RibbitCall &c, bool keeps_cursor) {
+        if (c.end - c.start < anchored_seedlen_cutoff(c.mlen)) {
+            if (keeps_cursor) pending_end = std::max(pending_end, c.end);
+            return;
+        }
+        catch_up();
+        const Cursor2 next = anchored_add(lists, c.start, c.end, c.mlen, cur, RIBBIT_RANK_A);
+        if (keeps_cursor) cur = next;
+    }
+    // a call list (or its tail) that may hold the end-of-sequence flush
+    void run(const RibbitCall *calls, size_t n, int64_t length) {
+        for (size_t i = 0; i < n; ++i) {
+            const RibbitCall &c = calls[i];
+            const bool flush = c.pos == (int32_t)length;
+            const bool first_of_two = flush && i + 1 < n && calls[i + 1].pos == c.pos && calls[i + 1].mlen == c.mlen;
+            call(c, !flush || first_of_two);
+        }
+    }
+};
+
+// Calls that fail the length filter only move the perfect-list cursor (parse_substitute_shiftxor.cpp:34-44); their
+// effect is folded into one advance with the running maximum of their ends (seed_lists.h: advance_cursor).
+template <class Lists>
+struct SubstReplay {
+    Lists &lists;
+    int from_index = 0;
+    int pending_end = -1;
+    void call(const RibbitCall &c) {
+        if (c.end - c.start < subst_seedlen_cutoff(c.mlen)) { pending_end = std::max(pending_end, c.end); return; }
+        if (pending_end >= 0) { from_index = advance_cursor(lists.perfect, from_index, pending_end); pending_end = -1; }
+        from_index = subst_add(lists, c.start, c.end, c.mlen, from_index, RIBBIT_RANK_S);
+    }
+};
+
+// ------------------------------------------------------------------------------------ where to cut
+// positions covered by some interval [start, end] (closed: seeds that share a position interact)
+struct Coverage {
+    std::vector<uint64_t> w;
+    int64_t top;      // largest position
+    explicit Coverage(int64_t length) : w((size_t)(length / 64 + 2), 0), top(length) {}
+    void mark(int64_t a, int64_t b) {
+        a = std::max<int64_t>(a, 0);
+        b = std::min<int64_t>(b, top);
+        if (b < a) return;
+        const int64_t wa = a >> 6, wb = b >> 6;
+        const uint64_t lo = ~0ull << (a & 63), hi = ~0ull >> (63 - (b & 63));
+        if (wa == wb) { w[(size_t)wa] |= lo & hi; return; }
+        w[(size_t)wa] |= lo;
+        for (int64_t k = wa + 1; k < wb; ++k) w[(size_t)k] = ~0ull;
+        w[(size_t)wb] |= hi;
+    }
+    // first uncovered position in [from, to], -1 if none
+    int64_t first_clear(int64_t from, int64_t to) const {
+        from = std::max<int64_t>(from, 0);
+        to = std::min<int64_t>(to, top);
+        for (int64_t p = from; p <= to;) {
+            const uint64_t free_bits = ~w[(size_t)(p >> 6)] & (~0ull << (p & 63));
+            if (free_bits) {
+                const int64_t q = ((p >> 6) << 6) + __builtin_ctzll(free_bits);
+                return q <= to ? q : -1;
+            }
+            p = ((p >> 6) + 1) << 6;
+        }
+        return -1;
+    }
+};
+
+// first call of every range; a range boundary before call i is valid iff some position p, covered by no call and no
+// seed of the static lists, has every earlier call's interval to its left and every later call's to its right
+std::vector<size_t> cut_ranges(const KeptCalls &kc, std::initializer_list<const std::vector<RibbitSeed> *> statics, int64_t length,
+                               size_t want_ranges, std::vector<int> &cut_pos) {
+    const size_t n = kc.n;
+    std::vector<size_t> first{0};
+    cut_pos.assign(1, INT32_MIN);
+    const size_t min_range = std::max<size_t>(g_min_range.load(), 1);
+    const size_t per = std::max(min_range, (n + want_ranges - 1) / std::max<size_t>(want_ranges, 1));
+    if (n < 2 * per) return first;
+    Coverage cov(length);
+    for (const std::vector<RibbitSeed> *list : statics)
+        for (const RibbitSeed &s : *list) cov.mark(s.start, s.end);
+    for (size_t i = 0; i < n; ++i) cov.mark(kc.calls[i].start, kc.calls[i].end);
+    std::vector<int32_t> later_start(n + 1);
+    later_start[n] = INT32_MAX;
+    for (size_t i = n; i-- > 0;) later_start[i] = std::min(later_start[i + 1], kc.calls[i].start);
+    int32_t earlier_end = -1;
+    size_t next = per;
+    for (size_t i = 0; i < n; ++i) {
+        if (i >= next && n - i >= min_range && (int64_t)earlier_end + 1 <= (int64_t)later_start[i] - 1) {
+            const int64_t p = cov.first_clear((int64_t)earlier_end + 1, (int64_t)later_start[i] - 1);
+            if (p >= 0) {
+                first.push_back(i);
+                cut_pos.push_back((int)p);
+                next = i + per;
+            }
+        }
+        earlier_end = std::max(earlier_end, kc.calls[i].end);
+    }
+    return first;
+}
+
+unsigned resolve_threads(unsigned threads) { return std::max(1u, std::min(threads ? threads : std::thread::hardware_concurrency(), 256u)); }
+
+template <class Work>
+void run_ranges(size_t n_ranges, unsigned threads, Work work) {
+    std::atomic<size_t> next{0};
+    const bool reverse = std::getenv("RIBBIT_MERGE_REVERSE_RANGES") != nullptr;     // debugging aid
+    auto loop = [&]() { for (size_t k; (k = next.fetch_add(1)) < n_ranges;) work(reverse ? n_ranges - 1 - k : k); };
+    std::vector<std::thread> pool;
+    const unsigned nt = std::getenv("RIBBIT_MERGE_SERIAL_RANGES") ? 1u : (unsigned)std::min<size_t>(threads, n_ranges);   // debugging aid: ranges one after the other
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(loop);
+    loop();
+    for (std::thread &t : pool) t.join();
+}
+
+const RibbitSeed SENTINEL{-1, -1, 0, RIBBIT_RANK_N};   // stands for everything earlier ranges appended: ends before any interval of this range
+
+std::vector<int32_t> types_of(const std::vector<RibbitSeed> &list) {
+    std::vector<int32_t> t(list.size());
+    for (size_t i = 0; i < list.size(); ++i) t[i] = list[i].type;
+    return t;
+}
+void restore_types(std::vector<RibbitSeed> &list, const std::vector<int32_t> &t) {
+    for (size_t i = 0; i < list.size(); ++i) list[i].type = t[i];
+}
+
+// ---- the stages in call order (also the fallback of the parallel versions)
+void subst_in_order(SeedLists &lists, const KeptCalls &kc) {
+    lists.subst.clear();
+    SubstReplay<SeedLists> r{lists};
+    for (size_t i = 0; i < kc.n; ++i) {
+        if (kc.pend) r.pending_end = std::max(r.pending_end, kc.pend[i]);
+        r.call(kc.calls[i]);
+    }
+    r.pending_end = std::max(r.pending_end, kc.tail_pend);
+    for (size_t i = 0; i < kc.n_flush; ++i) r.call(kc.flush[i]);
+}
+
+void anchored_in_order(SeedLists &lists, const KeptCalls &kc) {
+    lists.anchored.clear();
+    AnchoredReplay<SeedLists> r{lists, Cursor2{}};
+    for (size_t i = 0; i < kc.n; ++i) {
+        if (kc.pend) r.pending_end = std::max(r.pending_end, kc.pend[i]);
+        r.call(kc.calls[i], true);
+    }
+    r.pending_end = std::max(r.pending_end, kc.tail_pend);
+    r.run(kc.flush, kc.n_flush, lists.length);
+}
+
+}  // namespace
+
+void set_merge_min_range(size_t calls) { g_min_range = std::max<size_t>(calls, 1); }
+MergeStats last_merge_stats(int stage) { return tl_last_stats[stage ? 1 : 0]; }
+
+unsigned merge_threads(unsigned asked) {
+    if (asked) return asked;
+    if (const char *env = std::getenv("RIBBIT_THREADS")) return (unsigned)std::max(1, std::atoi(env));
+    return std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+}
+
+namespace {
+// full call list -> the kept calls with cumulative bounds (the largest end of ANY earlier call), the flush apart
+struct Compacted {
+    std::vector<RibbitCall> calls, flush;
+    std::vector<int32_t> pend;
+    KeptCalls view;
+};
+void compact_full(const RibbitCall *calls, size_t n, int64_t length, int (*min_span)(int), Compacted &out) {
+    int32_t seen = -1;
+    size_t i = 0;
+    for (; i < n && calls[i].pos != (int32_t)length; ++i) {
+        const RibbitCall &c = calls[i];
+        if (c.end - c.start >= min_span(c.mlen)) { out.calls.push_back(c); out.pend.push_back(seen); }
+        seen = std::max(seen, c.end);
+    }
+    out.flush.assign(calls + i, calls + n);
+    out.view.calls = out.calls.data();
+    out.view.n = out.calls.size();
+    out.view.pend = out.pend.data();
+    out.view.tail_pend = seen;
+    out.view.flush = out.flush.data();
+    out.view.n_flush = out.flush.size();
+}
+}  // namespace
+
+void merge_subst_stage_full(SeedLists &lists, const RibbitCall *calls, size_t n, unsigned threads, MergeStats *stats) {
+    Compacted c;
+    compact_full(calls, n, lists.length, subst_seedlen_cutoff, c);
+    merge_subst_stage(lists, c.view, threads, stats);
+}
+
+void merge_anchored_stage_full(SeedLists &lists, const RibbitCall *calls, size_t n, unsigned threads, MergeStats *stats) {
+    Compacted c;
+    compact_full(calls, n, lists.length, anchored_seedlen_cutoff, c);
+    merge_anchored_stage(lists, c.view, threads, stats);
+}
+
+void replay_anchored_calls(SeedLists &lists, const RibbitCall *calls, size_t n, int64_t length) {
+    AnchoredReplay<SeedLists> r{lists, Cursor2{}};
+    r.run(calls, n, length);
+}
+
+void replay_subst_calls(SeedLists &lists, const RibbitCall *calls, size_t n) {
+    SubstReplay<SeedLists> r{lists};
+    for (size_t i = 0; i < n; ++i) r.call(calls[i]);
+}
+
+// One range's private state: the list it appends to and the logs that let it be validated and redone.
+struct RangeState {
+    std::vector<RibbitSeed> own;                    // the stage's list, this range's part (own[0] = SENTINEL for ranges > 0)
+    std::vector<ListRefs::TypeWrite> undo;
+    std::vector<ListRefs::TypeRead> foreign_reads;
+    std::vector<ListRefs::HeadWrite> head_writes;
+    int64_t guard_hits = 0;
+    Cursor2 cursor;
+    void reset(bool sentinel, size_t expect) {
+        for (size_t i = undo.size(); i-- > 0;) undo[i].seed->type = undo[i].old_type;
+        undo.clear();
+        foreign_reads.clear();
+        own.clear();
+        own.reserve(expect + 1);
+        if (sentinel) own.push_back(SENTINEL);
+        guard_hits = 0;
+        head_writes.clear();
+    }
+    // every seed of an earlier range whose type steered a decision here still has that type (types only ever go to
+    // "retired", and earlier ranges are final when this is asked)
+    bool reads_still_valid() const {
+        for (const ListRefs::TypeRead &r : foreign_reads)
+            if ((r.seed->type != RIBBIT_RANK_N) != r.live) return false;
+        return true;
+    }
+};
+
+// Runs body(k, state) for every range on `threads` threads, then walks the ranges in order and redoes those that read
+// the type of an earlier range's seed before that range retired it.  Returns the number of ranges redone.
+template <class Body>
+unsigned run_and_validate(size_t nr, unsigned threads, const std::vector<size_t> &first, std::vector<RangeState> &state, Body body) {
+    run_ranges(nr, threads, [&](size_t k) {
+        state[k].reset(k > 0, first[k + 1] - first[k]);
+        body(k, state[k]);
+    });
+    unsigned redone = 0;
+    for (size_t k = 1; k < nr; ++k) {
+        if (state[k].reads_still_valid()) continue;
+        state[k].reset(true, first[k + 1] - first[k]);
+        body(k, state[k]);
+        ++redone;
+    }
+    return redone;
+}
+
+void merge_subst_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, MergeStats *stats) {
+    MergeStats st;
+    threads = resolve_threads(threads);
+    st.threads = threads;
+    const double t0 = now_ms();
+    std::vector<size_t> first{0};
+    std::vector<int> cut_pos;
+    if (threads > 1) first = cut_ranges(kc, {&lists.perfect}, lists.length, (size_t)threads * 8, cut_pos);
+    const size_t nr = first.size();
+    st.ranges = (unsigned)nr;
+    if (nr == 1) {
+        subst_in_order(lists, kc);
+        st.merge_ms = now_ms() - t0;
+        tl_last_stats[0] = st;
+        if (stats) *stats = st;
+        return;
+    }
+    first.push_back(kc.n);
+    // the cursor every range starts from: a function of the largest end among the earlier calls (advance_cursor)
+    std::vector<int> start_cursor(nr, 0);
+    {
+        int cur = 0, seen = -1;
+        for (size_t k = 0, i = 0; k < nr; ++k) {
+            for (; i < first[k]; ++i) seen = std::max(seen, std::max(kc.calls[i].end, kc.pend ? kc.pend[i] : -1));
+            if (seen >= 0) cur = advance_cursor(lists.perfect, cur, seen);
+            start_cursor[k] = cur;
+        }
+    }
+    const std::vector<int32_t> perfect_types = types_of(lists.perfect);
+    std::vector<RangeState> state(nr);
+    st.prepare_ms = now_ms() - t0;
+    const double t1 = now_ms();
+    std::vector<RibbitSeed> no_anchored;
+    st.ranges_redone = run_and_validate(nr, threads, first, state, [&](size_t k, RangeState &me) {
+        ListRefs l(lists.perfect, me.own, no_anchored, lists.range_count, lists.length, lists.max_motif);
+        l.undo = &me.undo;
+        l.foreign_reads = &me.foreign_reads;
+        l.range_lo = cut_pos[k];
+        l.range_hi = k + 1 < nr ? cut_pos[k + 1] : INT32_MAX;
+        l.initial_types_perfect = perfect_types.data();
+        SubstReplay<ListRefs> r{l, start_cursor[k]};
+        for (size_t i = first[k]; i < first[k + 1]; ++i) {
+            if (kc.pend) r.pending_end = std::max(r.pending_end, kc.pend[i]);
+            r.call(kc.calls[i]);
+        }
+        me.guard_hits = l.guard_hits;
+        me.cursor.perfect = r.from_index;
+    });
+    const bool force_redo = std::getenv("RIBBIT_MERGE_FORCE_REDO") != nullptr;      // test hook: exercise the fallback
+    if (state[0].own.empty() || force_redo) {      // later ranges assumed a non-empty list
+        restore_types(lists.perfect, perfect_types);
+        subst_in_order(lists, kc);
+        st.redone_in_order = true;
+    } else {
+        size_t total = 0;
+        for (const RangeState &r : state) total += r.own.size();
+        lists.subst.clear();
+        lists.subst.reserve(total);
+        for (size_t k = 0; k < nr; ++k) {
+            lists.subst.insert(lists.subst.end(), state[k].own.begin() + (k > 0 ? 1 : 0), state[k].own.end());
+            lists.guard_hits += state[k].guard_hits;
+        }
+        SubstReplay<SeedLists> r{lists, state[nr - 1].cursor.perfect};
+        r.pending_end = kc.tail_pend;
+        for (size_t i = 0; i < kc.n_flush; ++i) r.call(kc.flush[i]);
+    }
+    st.merge_ms = now_ms() - t1;
+    tl_last_stats[0] = st;
+    if (stats) *stats = st;
+}
+
+void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, MergeStats *stats) {
+    MergeStats st;
+    threads = resolve_threads(threads);
+    st.threads = threads;
+    const double t0 = now_ms();
+    std::vector<size_t> first{0};
+    std::vector<int> cut_pos;
+    if (threads > 1) first = cut_ranges(kc, {&lists.perfect, &lists.subst}, lists.length, (size_t)threads * 8, cut_pos);
+    const size_t nr = first.size();
+    st.ranges = (unsigned)nr;
+    if (nr == 1) {
+        anchored_in_order(lists, kc);
+        st.merge_ms = now_ms() - t0;
+        tl_last_stats[1] = st;
+        if (stats) *stats = st;
+        return;
+    }
+    first.push_back(kc.n);
+    std::vector<Cursor2> start_cursor(nr);
+    {
+        Cursor2 cur;
+        int seen = -1;
+        for (size_t k = 0, i = 0; k < nr; ++k) {
+            for (; i < first[k]; ++i) seen = std::max(seen, std::max(kc.calls[i].end, kc.pend ? kc.pend[i] : -1));
+            if (seen >= 0) {
+                cur.perfect = advance_cursor(lists.perfect, cur.perfect, seen);
+                cur.subst = advance_cursor(lists.subst, cur.subst, seen);
+            }
+            start_cursor[k] = cur;
+        }
+    }
+    const std::vector<int32_t> perfect_types = types_of(lists.perfect), subst_types = types_of(lists.subst);
+    const int64_t guard_before = lists.guard_hits;
+    std::vector<RangeState> state(nr);
+    st.prepare_ms = now_ms() - t0;
+    const double t1 = now_ms();
+    st.ranges_redone = run_and_validate(nr, threads, first, state, [&](size_t k, RangeState &me) {
+        ListRefs l(lists.perfect, lists.subst, me.own, lists.range_count, lists.length, lists.max_motif);
+        l.head_write_log = &me.head_writes;
+        l.undo = &me.undo;
+        l.foreign_reads = &me.foreign_reads;
+        l.range_lo = cut_pos[k];
+        l.range_hi = k + 1 < nr ? cut_pos[k + 1] : INT32_MAX;
+        l.initial_types_perfect = perfect_types.data();
+        l.initial_types_subst = subst_types.data();
+        AnchoredReplay<ListRefs> r{l, start_cursor[k]};
+        for (size_t i = first[k]; i < first[k + 1]; ++i) {
+            if (kc.pend) r.pending_end = std::max(r.pending_end, kc.pend[i]);
+            r.call(kc.calls[i], true);
+        }
+        me.guard_hits = l.guard_hits;
+        me.cursor = r.cur;
+    });
+    // Q8 writes to list heads the ranges logged: harmless iff each leaves its target as it is now (every range is final
+    // here, and nothing but such a write changes a head entry after the range that holds it)
+    int64_t head_writes = 0;
+    for (const RangeState &r : state)
+        for (const ListRefs::HeadWrite &w : r.head_writes) {
+            const RibbitSeed &t = *w.target;
+            head_writes += !(t.start == w.value.start && t.end == w.value.end && t.mlen == w.value.mlen && t.type == w.value.type);
+        }
+    st.head_writes = head_writes;
+    st.first_range_empty = state[0].own.empty();
+    if (head_writes || state[0].own.empty() || std::getenv("RIBBIT_MERGE_FORCE_REDO")) {      // (the variable: test hook)
+        restore_types(lists.perfect, perfect_types);
+        restore_types(lists.subst, subst_types);
+        lists.guard_hits = guard_before;
+        anchored_in_order(lists, kc);
+        st.redone_in_order = true;
+    } else {
+        size_t total = 0;
+        for (const RangeState &r : state) total += r.own.size();
+        lists.anchored.clear();
+        lists.anchored.reserve(total);
+        for (size_t k = 0; k < nr; ++k) {
+            lists.anchored.insert(lists.anchored.end(), state[k].own.begin() + (k > 0 ? 1 : 0), state[k].own.end());
+            lists.guard_hits += state[k].guard_hits;
+        }
+        AnchoredReplay<SeedLists> r{lists, state[nr - 1].cursor};
+        r.pending_end = kc.tail_pend;
+        r.run(kc.flush, kc.n_flush, lists.length);
+    }
+    st.merge_ms = now_ms() - t1;
+    tl_last_stats[1] = st;
+    if (stats) *stats = st;
+}
+
+}  // namespace rb

@@ -1,0 +1,77 @@
+// parallel_merge.h -- the window stages' seed-list merges (addSeedToSeedPositionsSubstitutions / ...Anchored,
+// SURVEY.md 8a rows a7 / a11) over the calls a stage kept, run as independent position ranges on host threads.
+//
+// The reference makes the calls one by one; a call only ever reads or writes seeds whose interval intersects its
+// own (or the union it grows into by merging with such seeds), plus the cursors, which are a function of the largest
+// end seen so far.  Wherever the call sequence can be cut so that every interval before the cut lies left of some
+// position p and every interval after it right of p -- p covered by no call and no seed of the earlier stages --
+// the two halves do not interact: the right half sees the left half only as list entries that end before anything it
+// looks for, which a single sentinel entry stands for.  The halves are merged in parallel into lists of their own and
+// concatenated in call order, which is the order the reference appends in.
+// One dependency crosses a cut: the candidate walk pushes the nearest earlier-stage seed to the LEFT of a call unless
+// that seed is retired (merge_types.cpp:64-93), and it may lie in the range before.  Reads of such seeds' types are
+// logged; after the parallel pass the ranges are checked in order and one that saw a type its left neighbour changed
+// afterwards is merged again (its own retirements undone first).
+// Two things a cut cannot localise at all are detected, and the whole stage is then redone in order (neither happened
+// in any test or benchmark record, but correctness does not rest on that):
+//   * Q8: the anchored merge's coverage code writes entries at the HEAD of the perfect / substitution lists from
+//     anywhere in the record (parse_anchored_shiftxor.cpp:511-522).  Workers log these writes; one that would change
+//     its target (most give a retired entry its own coordinates) forces the redo;
+//   * the first range appending nothing: later ranges assumed a non-empty list (merge_types.cpp:103 and
+//     parse_substitute_shiftxor.cpp:48-116 take different paths for an empty list).
+// Product code: must never include anything from oracle/.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ribbit_hip.h"
+#include "seed_lists.h"
+
+namespace rb {
+
+// What a window stage hands its merge: the calls that pass the stage's length filter, in call order, each with
+// the largest end among the earlier calls that can matter to its cursors (-1: none; pend == null: all -1), the
+// largest end of any in-loop call, and the end-of-sequence calls (unfiltered, motif order).
+struct KeptCalls {
+    const RibbitCall *calls = nullptr;
+    size_t n = 0;
+    const int32_t *pend = nullptr;
+    int32_t tail_pend = -1;
+    const RibbitCall *flush = nullptr;
+    size_t n_flush = 0;
+};
+
+struct MergeStats {
+    unsigned ranges = 1;       // independent ranges the calls were cut into
+    unsigned threads = 1;
+    unsigned ranges_redone = 0;    // ranges that read a seed type an earlier range changed afterwards, merged again
+    bool redone_in_order = false;
+    long long head_writes = 0;     // Q8 writes to list heads that would change an entry (any: the stage is redone in order)
+    bool first_range_empty = false;
+    double prepare_ms = 0.0, merge_ms = 0.0;
+};
+
+// lists.subst is rebuilt from kc (lists.perfect as the perfect stage left it)
+void merge_subst_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, MergeStats *stats = nullptr);
+// lists.anchored is rebuilt from kc (lists.perfect / lists.subst as the substitution stage left them)
+void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, MergeStats *stats = nullptr);
+
+// Replay of a full anchored call list (ribbit_hip_anchored_calls order: in-loop calls, then the end-of-sequence flush)
+void replay_anchored_calls(SeedLists &lists, const RibbitCall *calls, size_t n, int64_t length);
+// ... and of a full substitution call list
+void replay_subst_calls(SeedLists &lists, const RibbitCall *calls, size_t n);
+
+// The same two stages from a FULL call list in the scanner's call order (in-loop calls, then the end-of-sequence
+// flush with pos == length): filtered and bounded here, then merged as above.
+void merge_subst_stage_full(SeedLists &lists, const RibbitCall *calls, size_t n, unsigned threads, MergeStats *stats = nullptr);
+void merge_anchored_stage_full(SeedLists &lists, const RibbitCall *calls, size_t n, unsigned threads, MergeStats *stats = nullptr);
+
+// threads the merges may use: `asked` if non-zero, else environment RIBBIT_THREADS, else min(cores, 16)
+unsigned merge_threads(unsigned asked);
+
+// test hook: smallest number of calls per range (default 4096); small values cut wherever a cut is valid
+void set_merge_min_range(size_t calls);
+// test hook: what the last merge of a stage (0 substitution, 1 anchored) on the calling thread did
+MergeStats last_merge_stats(int stage);
+
+}  // namespace rb

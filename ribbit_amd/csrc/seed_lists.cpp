@@ -2,6 +2,8 @@
 #include "seed_lists.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace rb {
 
@@ -84,19 +86,36 @@ struct Cand { bool from_perfect; int idx; };
 
 inline void retire(RibbitSeed &s) { s.type = RIBBIT_RANK_N; }
 
+// a seed of a list that parallel workers share: retirement and the "is it retired" test (see ListRefs)
+inline void retire_shared(ListRefs &sl, RibbitSeed &s) {
+    if (sl.undo && s.type != RIBBIT_RANK_N) sl.undo->push_back({&s, s.type});
+    __atomic_store_n(&s.type, (int32_t)RIBBIT_RANK_N, __ATOMIC_RELAXED);
+}
+inline bool live_shared(const ListRefs &sl, const RibbitSeed &s) {
+    if (s.start > sl.range_hi) {
+        const size_t ip = (size_t)(&s - sl.perfect.data());
+        if (sl.initial_types_perfect && ip < sl.perfect.size()) return sl.initial_types_perfect[ip] != RIBBIT_RANK_N;
+        const size_t is = (size_t)(&s - sl.subst.data());
+        if (sl.initial_types_subst && is < sl.subst.size()) return sl.initial_types_subst[is] != RIBBIT_RANK_N;
+    }
+    const bool live = __atomic_load_n(&s.type, __ATOMIC_RELAXED) != RIBBIT_RANK_N;
+    if (s.end < sl.range_lo && sl.foreign_reads) sl.foreign_reads->push_back({&s, live});
+    return live;
+}
+
 // retainNestedSeed (parse_perfect_shiftxor.cpp:18-29): keep the nested seed unless the parent plane
 // has strictly more matches over [start, end)
-inline bool keep_nested(const SeedLists &sl, int start, int end, int nested_mlen, int parent_mlen) {
+inline bool keep_nested(const ListRefs &sl, int start, int end, int nested_mlen, int parent_mlen) {
     return !(sl.range_count(nested_mlen, start, end) < sl.range_count(parent_mlen, start, end));
 }
 // retainIdenticalSeeds (parse_perfect_shiftxor.cpp:31-43): ties go to the smaller plane index
-inline bool keep_identical(const SeedLists &sl, int start, int end, int nested_mlen, int parent_mlen) {
+inline bool keep_identical(const ListRefs &sl, int start, int end, int nested_mlen, int parent_mlen) {
     const int a = sl.range_count(nested_mlen, start, end), b = sl.range_count(parent_mlen, start, end);
     return a != b ? a > b : nested_mlen < parent_mlen;
 }
 
 // :48-116 -- perfect and substitution seeds that may touch [seed_start, ...), larger end first
-void gather_candidates(const SeedLists &sl, int from_index, int seed_start, std::vector<Cand> &out) {
+void gather_candidates(const ListRefs &sl, int from_index, int seed_start, std::vector<Cand> &out) {
     const std::vector<RibbitSeed> &P = sl.perfect, &S = sl.subst;
     out.clear();
     bool more_p = !P.empty(), more_s = !S.empty();
@@ -107,13 +126,13 @@ void gather_candidates(const SeedLists &sl, int from_index, int seed_start, std:
             // both lists live: the larger end goes first, and BOTH cursors are re-tested against
             // the ends read in this step (:92-115)
             const int p_end = P[pi].end, s_end = S[si].end;
-            if (take_p) { if (P[pi].type != RIBBIT_RANK_N) out.push_back({true, (int)pi}); --pi; }
+            if (take_p) { if (live_shared(sl, P[pi])) out.push_back({true, (int)pi}); --pi; }
             else        { if (S[si].type != RIBBIT_RANK_N) out.push_back({false, (int)si}); --si; }
             if (pi < 0 || p_end < seed_start) more_p = false;
             if (si < 0 || s_end < seed_start) more_s = false;
         } else if (take_p) {                                  // :60-73
             const int p_end = P[pi].end;
-            if (p_end >= seed_start) { if (P[pi].type != RIBBIT_RANK_N) out.push_back({true, (int)pi}); --pi; }
+            if (p_end >= seed_start) { if (live_shared(sl, P[pi])) out.push_back({true, (int)pi}); --pi; }
             if (pi < 0 || p_end < seed_start) more_p = false;
         } else {                                              // :76-89
             const int s_end = S[si].end;
@@ -125,7 +144,7 @@ void gather_candidates(const SeedLists &sl, int from_index, int seed_start, std:
 
 }  // namespace
 
-int subst_add(SeedLists &sl, int seed_start, int seed_end, int mlen, int from_index, int seed_type) {
+int subst_add(ListRefs &sl, int seed_start, int seed_end, int mlen, int from_index, int seed_type) {
     std::vector<RibbitSeed> &P = sl.perfect, &S = sl.subst;
     std::vector<Cand> cands;
     constexpr int RP = RIBBIT_RANK_P, RQ = RIBBIT_RANK_Q, RS = RIBBIT_RANK_S;
@@ -181,7 +200,7 @@ int subst_add(SeedLists &sl, int seed_start, int seed_end, int mlen, int from_in
             } else if (seed_start <= o_start && o_end <= seed_end) {                        // :235 old inside new
                 if (new_is_lower) {
                     if (o_mlen % mlen == 0) {                                               // :239
-                        retire(old);
+                        if (c.from_perfect) retire_shared(sl, old); else retire(old);
                         again(seed_start, seed_end, mlen, RQ); break;
                     }
                     if (mlen % o_mlen == 0 || o_mlen < mlen) {                              // :249
@@ -226,7 +245,7 @@ int subst_add(SeedLists &sl, int seed_start, int seed_end, int mlen, int from_in
                     const bool many = o_len / o_mlen > 3;
                     if ((many && overlap >= 3 * o_mlen - 1) ||
                         (!many && (overlap >= o_mlen - 1 || overlap >= o_len - 1))) {
-                        retire(old);
+                        if (c.from_perfect) retire_shared(sl, old); else retire(old);
                         again(ms, me, mlen, RQ); break;
                     }
                 } else if (mlen % o_mlen == 0 || mlen > o_mlen) {                           // :362
@@ -255,7 +274,7 @@ namespace {
 enum Src : uint8_t { FROM_P, FROM_S, FROM_A };
 struct Cand3 { Src src; int idx; };
 
-inline const RibbitSeed &seed_of(const SeedLists &sl, Src src, int idx) {
+inline const RibbitSeed &seed_of(const ListRefs &sl, Src src, int idx) {
     return src == FROM_P ? sl.perfect[idx] : src == FROM_S ? sl.subst[idx] : sl.anchored[idx];
 }
 
@@ -275,15 +294,15 @@ void walk_back(const std::vector<RibbitSeed> &list, long &i, int seed_start, Pus
 // descending end (starting at the two cursors); phase 2 interleaves that candidate list -- walked
 // from its LAST element, i.e. by ascending end -- with the anchored list walked from its end.
 // Divergence D1: an empty substitution list is treated as exhausted (the reference reads it: UB).
-void merge_all_lists(SeedLists &sl, Cursor2 from, int seed_start, std::vector<Cand3> &out) {
+void merge_all_lists(ListRefs &sl, Cursor2 from, int seed_start, std::vector<Cand3> &out) {
     const std::vector<RibbitSeed> &P = sl.perfect, &S = sl.subst, &A = sl.anchored;
     static thread_local std::vector<Cand3> ps;       // scratch, reused across the millions of calls of a record
     ps.clear();
     bool p_done = P.empty(), s_done = false;
     if (S.empty()) { s_done = true; ++sl.guard_hits; }
     long pi = from.perfect, si = from.subst;
-    auto push_p = [&](long i) { if (P[i].type != RIBBIT_RANK_N) ps.push_back({FROM_P, (int)i}); };
-    auto push_s = [&](long i) { if (S[i].type != RIBBIT_RANK_N) ps.push_back({FROM_S, (int)i}); };
+    auto push_p = [&](long i) { if (live_shared(sl, P[i])) ps.push_back({FROM_P, (int)i}); };
+    auto push_s = [&](long i) { if (live_shared(sl, S[i])) ps.push_back({FROM_S, (int)i}); };
     while (!(p_done && s_done)) {
         if (s_done) { walk_back(P, pi, seed_start, push_p); p_done = true; }            // :30-45
         else if (p_done) { walk_back(S, si, seed_start, push_s); s_done = true; }        // :47-62
@@ -327,7 +346,7 @@ void merge_all_lists(SeedLists &sl, Cursor2 from, int seed_start, std::vector<Ca
 
 }  // namespace
 
-Cursor2 anchored_add(SeedLists &sl, int seed_start, int seed_end, int mlen, const Cursor2 from, int seed_type) {
+Cursor2 anchored_add(ListRefs &sl, int seed_start, int seed_end, int mlen, const Cursor2 from, int seed_type) {
     std::vector<RibbitSeed> &P = sl.perfect, &S = sl.subst, &A = sl.anchored;
     constexpr int RA = RIBBIT_RANK_A, RC = RIBBIT_RANK_C, RP = RIBBIT_RANK_P, RS = RIBBIT_RANK_S, RQ = RIBBIT_RANK_Q;
     struct Child { int idx, mlen, type; };
@@ -354,8 +373,8 @@ Cursor2 anchored_add(SeedLists &sl, int seed_start, int seed_end, int mlen, cons
         bool restart = false;
         auto again = [&](int s, int e, int m, int t) { seed_start = s; seed_end = e; mlen = m; seed_type = t; restart = true; };
         auto retire_by_type = [&](int type, int idx) {                                       // :270-271 and twins
-            if (type == RP) P[idx].type = RIBBIT_RANK_N;
-            else if (type == RS || type == RQ) S[idx].type = RIBBIT_RANK_N;
+            if (type == RP) retire_shared(sl, P[idx]);
+            else if (type == RS || type == RQ) retire_shared(sl, S[idx]);
         };
 
         for (const Cand3 &c : cands) {
@@ -502,7 +521,11 @@ Cursor2 anchored_add(SeedLists &sl, int seed_start, int seed_end, int mlen, cons
                     if (!dst) continue;
                     if (j >= dst->size()) { ++sl.guard_hits; continue; }
                     o_mlen = (*dst)[j].mlen;
-                    if (o_mlen == f) (*dst)[j] = RibbitSeed{o_start, o_end, o_mlen, RIBBIT_RANK_N};
+                    if (o_mlen == f) {
+                        const RibbitSeed value{o_start, o_end, o_mlen, RIBBIT_RANK_N};
+                        if (sl.head_write_log) sl.head_write_log->push_back({&(*dst)[j], value});     // parallel worker: decided later
+                        else (*dst)[j] = value;
+                    }
                 }
                 break;
             }

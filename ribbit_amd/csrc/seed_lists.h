@@ -23,6 +23,41 @@ struct SeedLists {
     int64_t guard_hits = 0;   // defined-divergence guards
 };
 
+// The same lists by reference, for the window stages' merges: when a record's calls are merged as independent
+// position ranges in parallel (parallel_merge.h), a worker appends to a list of its own while the lists of the
+// earlier stages are shared.  Member names follow SeedLists.
+struct ListRefs {
+    std::vector<RibbitSeed> &perfect, &subst, &anchored;
+    const RangeCount &range_count;
+    int64_t length;
+    int max_motif;
+    int64_t guard_hits = 0;
+    // Q8 (parse_anchored_shiftxor.cpp:511-522): the coverage code writes list entries it indexes with a loop counter,
+    // i.e. entries at the HEAD of the perfect / substitution list, wherever in the record the seed lies.
+    // Parallel workers log the write instead of performing it; the merge then checks that it changes nothing (the
+    // usual case: the entry is retired already and is given its own coordinates) or redoes the stage in order.
+    struct HeadWrite { RibbitSeed *target; RibbitSeed value; };
+    std::vector<HeadWrite> *head_write_log = nullptr;
+    // Parallel workers (parallel_merge.h) share the lists of the earlier stages.  The only field that changes there is
+    // `type` (a seed is retired), and the only place where the type of a seed OUTSIDE the worker's range steers a
+    // decision is the candidate walk, which pushes the nearest seed to the left unless it is retired
+    // (merge_types.cpp:64-93, parse_substitute_shiftxor.cpp:92-115).  Those reads and all retirements are logged so
+    // that a range that saw a stale type can be redone.
+    struct TypeWrite { RibbitSeed *seed; int32_t old_type; };
+    struct TypeRead { const RibbitSeed *seed; bool live; };
+    std::vector<TypeWrite> *undo = nullptr;
+    std::vector<TypeRead> *foreign_reads = nullptr;
+    int range_lo = INT32_MIN;         // seeds that end before this position belong to an earlier range
+    // Seeds that start beyond range_hi belong to a LATER range; in call order nothing has touched them yet when this
+    // range's calls are made, so their type is read from the snapshot taken before the stage (the walk meets the
+    // nearest such seed at its cursor, and whether it is pushed decides which candidate the loop sees last: Q8).
+    int range_hi = INT32_MAX;
+    const int32_t *initial_types_perfect = nullptr, *initial_types_subst = nullptr;
+    ListRefs(std::vector<RibbitSeed> &p, std::vector<RibbitSeed> &s, std::vector<RibbitSeed> &a, const RangeCount &rc, int64_t len, int mm)
+        : perfect(p), subst(s), anchored(a), range_count(rc), length(len), max_motif(mm) {}
+    explicit ListRefs(SeedLists &sl) : perfect(sl.perfect), subst(sl.subst), anchored(sl.anchored), range_count(sl.range_count), length(sl.length), max_motif(sl.max_motif) {}
+};
+
 // addSeedToSeedPositionsPerfect, parse_perfect_shiftxor.cpp:47-142
 void perfect_add(SeedLists &sl, int seed_start, int seed_end, int mlen);
 
@@ -42,7 +77,13 @@ inline int advance_cursor(const std::vector<RibbitSeed> &list, int from, int see
 }
 
 // addSeedToSeedPositionsSubstitutions, parse_substitute_shiftxor.cpp:18-388; returns the new cursor
-int subst_add(SeedLists &sl, int seed_start, int seed_end, int mlen, int from_index, int seed_type);
+int subst_add(ListRefs &sl, int seed_start, int seed_end, int mlen, int from_index, int seed_type);
+inline int subst_add(SeedLists &sl, int seed_start, int seed_end, int mlen, int from_index, int seed_type) {
+    ListRefs l(sl);
+    const int r = subst_add(l, seed_start, seed_end, mlen, from_index, seed_type);
+    sl.guard_hits += l.guard_hits;
+    return r;
+}
 
 
 // cursors into the perfect and substitution lists carried between addSeedToSeedPositionsAnchored calls
@@ -50,7 +91,13 @@ struct Cursor2 { int perfect = 0, subst = 0; };
 
 // addSeedToSeedPositionsAnchored (parse_anchored_shiftxor.cpp:113-534) incl. mergeAllLists
 // (merge_types.cpp:11-189); range_count must answer on the COMPOSED planes XA_m.
-Cursor2 anchored_add(SeedLists &sl, int seed_start, int seed_end, int mlen, Cursor2 from, int seed_type);
+Cursor2 anchored_add(ListRefs &sl, int seed_start, int seed_end, int mlen, Cursor2 from, int seed_type);
+inline Cursor2 anchored_add(SeedLists &sl, int seed_start, int seed_end, int mlen, Cursor2 from, int seed_type) {
+    ListRefs l(sl);
+    const Cursor2 r = anchored_add(l, seed_start, seed_end, mlen, from, seed_type);
+    sl.guard_hits += l.guard_hits;
+    return r;
+}
 
 // 3-way merge by start + filters of fasta_utils.cpp:187-224: the seeds that reach refinement, in order
 void dispatch_order(const SeedLists &sl, std::vector<RibbitSeed> &out);

@@ -1,0 +1,85 @@
+"""CPU tests of the range-parallel seed-list merges (ribbit_amd/csrc/parallel_merge.cpp): the window stages' calls are
+cut into independent position ranges, merged on host threads and concatenated.  With the smallest range forced down to
+a handful of calls (so that a record is cut wherever a cut is valid at all) the lists must still equal the oracle's,
+which makes its calls strictly one after the other."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import ribbit_amd
+from cases import edge_cases, large_motif_cases, simulated_cases, structured_cases
+from fuzz import fuzz_case
+from oracle_lib import LIST_ANCHORED, LIST_PERFECT, LIST_SUBST, Oracle
+
+CASES = edge_cases() + simulated_cases() + large_motif_cases() + [c for c in structured_cases() if "homopolymer" not in c[0]]
+
+
+@pytest.fixture(params=[1, 5, 64], ids=lambda v: f"min_range_{v}")
+def tiny_ranges(request):
+    lib = ribbit_amd.load_library()
+    old = os.environ.get("RIBBIT_THREADS")
+    os.environ["RIBBIT_THREADS"] = "4"
+    lib.ribbit_debug_set_merge_min_range(request.param)
+    yield request.param
+    lib.ribbit_debug_set_merge_min_range(4096)
+    if old is None:
+        del os.environ["RIBBIT_THREADS"]
+    else:
+        os.environ["RIBBIT_THREADS"] = old
+
+
+def _check(seq, m_lo, m_hi, tag):
+    with Oracle(seq, m_lo, m_hi) as o:
+        o.run_all()
+        r = ribbit_amd.host_replay_calls(m_lo, m_hi, seq, o.calls(LIST_PERFECT), o.calls(LIST_SUBST), o.calls(LIST_ANCHORED))
+        assert np.array_equal(r["perfect"].view("<i4"), o.seeds(LIST_PERFECT).view("<i4")), tag
+        assert np.array_equal(r["subst"].view("<i4"), o.seeds(LIST_SUBST).view("<i4")), tag
+        assert np.array_equal(r["anchored"].view("<i4"), o.seeds(LIST_ANCHORED).view("<i4")), tag
+        assert np.array_equal(r["dispatch"].view("<i4"), o.dispatch().view("<i4")), tag
+        assert r["guard_hits"] == o.guard_hits(), tag
+
+
+@pytest.mark.parametrize("name,seq,m_lo,m_hi", CASES, ids=[c[0] for c in CASES])
+def test_range_parallel_merges_equal_the_oracles_lists(tiny_ranges, name, seq, m_lo, m_hi):
+    _check(seq, m_lo, m_hi, name)
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_range_parallel_merges_on_fuzzed_records(tiny_ranges, block):
+    for seed in range(9000 + 40 * block, 9000 + 40 * (block + 1)):
+        seq, m_lo, m_hi = fuzz_case(seed)
+        _check(seq, m_lo, m_hi, f"seed {seed}: {len(seq)} bases, -m {m_lo} -M {m_hi}")
+
+
+def test_a_two_megabase_record_is_cut_into_many_ranges():
+    from ribbit_amd.simulate import simulate_sequence
+    seq, _ = simulate_sequence(400_000, 17, 2, 40, n_block_rate=0.3)
+    os.environ["RIBBIT_THREADS"] = "8"
+    try:
+        _check(seq, 2, 40, "400 kb, default range size")
+    finally:
+        del os.environ["RIBBIT_THREADS"]
+
+
+def test_redo_in_order_restores_what_the_ranges_changed(tiny_ranges):
+    """The fallback (a list-head write that changes an entry, or an empty first range): the parallel pass has retired
+    seeds of the earlier stages by then; they must be live again when the stage is redone in order."""
+    os.environ["RIBBIT_MERGE_FORCE_REDO"] = "1"
+    try:
+        for name, seq, m_lo, m_hi in [c for c in CASES if c[0] in ("sim_m4_50_60k", "n_runs", "M200_mixed")]:
+            _check(seq, m_lo, m_hi, name)
+        out = (C.c_int32 * 5)()
+        ribbit_amd.load_library().ribbit_debug_last_merge(1, C.byref(out))
+        assert out[2] == 1
+    finally:
+        del os.environ["RIBBIT_MERGE_FORCE_REDO"]
+
+
+def test_ranges_that_read_a_stale_type_are_merged_again(tiny_ranges):
+    """Seeds 20037 / 20171 (found by scanning): a range's candidate walk meets a seed of the range before that is retired
+    later in that range; run in parallel it may see it live, which the validation pass must catch."""
+    for seed in (20037, 20171):
+        seq, m_lo, m_hi = fuzz_case(seed)
+        _check(seq, m_lo, m_hi, f"seed {seed}")
