@@ -6,7 +6,20 @@ pack kernel (fasta_utils.cpp:78-115) + perfect shift-XOR scan kernel over m=2..1
 (fasta_utils.cpp:117-122 + parse_perfect_shiftxor.cpp:173-223) + event read-back + host pairing
 into runs.  Workload = BASELINE.json configs[1]: 100 Mbp synthetic FASTA, -m 2 -M 100, perfect scan.
 
-N > 1: one process per GPU (torch.distributed, backend nccl == RCCL).  ONE record of N x 100 Mbp is
+Next to that line's headline (configs[1]) rank 0 of an N = 1 run also reports, in the same JSON object:
+  verified          the GPU's perfect-stage calls on the first 20 Mbp equal the CPU oracle's (BASELINE: "BED diff==0")
+  pcie_inclusive    the same step with the bases starting in page-locked HOST memory (clock from the first H2D enqueue,
+                    uploads double-buffered against the previous batch's kernels): SURVEY.md 8(d)'s clock
+  pack_hbm          pack_kernel over a rotating working set larger than the 256 MiB Infinity Cache
+  full_path_sample  10 Mbp of the workload through the whole path, beside the CPU oracle on 1 Mbp
+  chr1_full_path    BASELINE.json configs[2]'s largest record: one chromosome-1-sized record (248,956,422 bp, generator
+                    seed 4, N blocks) through perfect + substitution + anchored scans, merges, dispatch, refinement
+                    and BED text, with per-kernel times and a roofline block for each scan kernel
+  cpu_baseline      the oracle's perfect stage on 20 Mbp, one core (CPU model and core count stated)
+
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL).  `python bench.py --gpus N` without a launcher
+starts `python -m torch.distributed.run --nproc-per-node N` itself (before anything touches a GPU) and exits with its
+code; under a launcher WORLD_SIZE must equal --gpus.  ONE record of N x 100 Mbp is
 chunk-sharded (option 2): every rank owns a 100-Mbp chunk (weak scaling), scans it
 together with halos of a few hundred bases taken from its neighbours, keeps the events it owns, and the
 chunk's events are paired locally; the sparse run records (candidate seed intervals) and the few runs
@@ -35,18 +48,182 @@ PLAIN_VALU_RATE = 930e9          # v_or / v_xor / v_bitop3, same probe
 CPU_FULL_PATH_BASES = 1_000_000  # whole-path CPU oracle sample (a few seconds)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 CPU_SAMPLE_BASES = 20_000_000
+CHR1_BASES = 248_956_422         # GRCh38 chromosome 1 (the largest record of configs[2])
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(seq: bytes):
-    """Oracle ("port") timed on this box's host cores, single thread, on a bounded sample."""
-    from oracle_lib import Oracle
+    """Oracle ("port") timed on this box's host cores, single thread, on a bounded sample.
+    -> (record, the oracle's perfect-stage call list and seed list of that sample, for the verification leg)"""
+    from oracle_lib import LIST_PERFECT, Oracle
     sample = seq[:CPU_SAMPLE_BASES]
     t0 = time.perf_counter()
     with Oracle(sample, M_LO, M_HI) as o:
         o.run_perfect()
+        dt = time.perf_counter() - t0
+        calls, seeds = o.calls(LIST_PERFECT), o.seeds(LIST_PERFECT)
+    rec = {"value": len(sample) / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
+           "host_cpu": cpu_model(), "host_cores_available": os.cpu_count(),
+           "sample": f"first {len(sample)} bases of the workload, encode + sweep + perfect scan + addSeed, m={M_LO}..{M_HI}, {dt:.1f} s"}
+    return rec, calls, seeds
+
+
+def verify_against_oracle(sc, seq: bytes, calls, seeds):
+    """BASELINE.json's metric carries "BED diff==0": the GPU path's perfect-stage output on the CPU baseline's sample must
+    be the oracle's, call for call and seed for seed (integer coordinates, bit-exact)."""
+    import numpy as np
+    sc.load_record(seq[:CPU_SAMPLE_BASES])
+    got_calls = sc.perfect_calls()
+    got_seeds = sc.processShiftXORsPerfect()
+    ok = bool(np.array_equal(got_calls.view("<i4"), calls.view("<i4")) and np.array_equal(got_seeds.view("<i4"), seeds.view("<i4")))
+    return ok, {"bases": min(len(seq), CPU_SAMPLE_BASES), "perfect_calls": int(len(got_calls)), "perfect_seeds": int(len(got_seeds)),
+                "what": "GPU perfect-stage call list and seed list == CPU oracle's on the cpu_baseline sample (bit-exact)"}
+
+
+def pcie_inclusive(ribbit_amd, seq: bytes, steps: int, depth: int, device: int):
+    """SURVEY.md 8(d)'s clock: the step with the bases starting in page-locked host memory.  Timed from the first H2D
+    enqueue to the last batch's run records on the host; every handle has its own streams, so batch k+1's upload
+    (1 B/base over PCIe) overlaps batch k's kernels and batch k-1's result copy."""
+    import numpy as np
+    n = len(seq)
+    bufs = [ribbit_amd.PinnedBuffer(n) for _ in range(depth)]
+    for b in bufs:
+        b.array[:] = np.frombuffer(seq, dtype=np.uint8)
+    scs = [ribbit_amd.Scanner(M_LO, M_HI, device=device) for _ in range(depth)]
+    for h in scs:
+        h.set_timing(False)
+
+    def issue(k):
+        h = scs[k % depth]
+        h.load_record_pinned(bufs[k % depth].ptr, n)
+        h.scan_perfect_begin(0, (1 << 63) - 1, 0)
+
+    def run(nsteps):
+        issued, runs = 0, 0
+        for k in range(min(depth - 1, nsteps)):
+            issue(issued); issued += 1
+        for k in range(nsteps):
+            if issued <= k:
+                issue(issued); issued += 1
+            h = scs[k % depth]
+            out = h.scan_perfect_end(wait=False)
+            if issued < nsteps:
+                issue(issued); issued += 1
+            h.scan_perfect_wait()
+            runs = len(out[0]) if isinstance(out, tuple) else len(out)
+        return runs
+
+    run(2)
+    t0 = time.perf_counter()
+    runs = run(steps)
     dt = time.perf_counter() - t0
-    return {"value": len(sample) / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
-            "sample": f"first {len(sample)} bases of the workload, encode + sweep + perfect scan + addSeed, m={M_LO}..{M_HI}, {dt:.1f} s"}
+    for h in scs:
+        h.close()
+    for b in bufs:
+        b.close()
+    return {"value": n * steps / dt / 1e9, "unit": "Gbases/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "batches_in_flight": depth,
+            "h2d_bytes_per_step": n, "h2d_gb_per_s_needed": n / (dt / steps) / 1e9, "runs_per_step": int(runs),
+            "what": "pack + perfect scan + pairing + D2H of the runs with the ASCII bases starting in page-locked host memory; clock from "
+                    "the first H2D enqueue (ribbit_hip_load_record_pinned: async upload on the handle's upload stream)"}
+
+
+def pack_hbm(ribbit_amd, torch, seq: bytes, dev, device: int):
+    """pack_kernel over a rotating working set that cannot sit in the 256 MiB Infinity Cache: 8 distinct 100-MB ASCII
+    buffers (plus 3 x 12.5 MB of planes written per launch), HIP-event time per launch."""
+    import numpy as np
+    copies = 8
+    base = torch.frombuffer(bytearray(seq), dtype=torch.uint8).to(dev)
+    bufs = [base] + [base.clone() for _ in range(copies - 1)]
+    torch.cuda.synchronize()
+    ms = []
+    with ribbit_amd.Scanner(M_LO, M_HI, device=device) as sc:
+        for rep in range(3 * copies):
+            sc.load_record_device(bufs[rep % copies].data_ptr(), len(seq))
+            if rep >= copies:
+                ms.append(sc.timing_ms(0))
+    t = float(np.median(ms))
+    nbytes = len(seq) * (1 + 3 / 8)
+    return {"kernel": "pack_kernel", "ms": t, "bytes_per_launch": nbytes, "achieved": nbytes / (t * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": nbytes / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, "working_set_bytes": copies * len(seq),
+            "what": f"1 B/base ASCII read + 0.375 B/base planes written, {copies} input buffers in rotation ({copies * len(seq) >> 20} MiB > Infinity Cache)"}
+
+
+def chr1_record(bases: int) -> bytes:
+    """SURVEY.md 8(d) cfg3 stand-in, largest record: generator seed 4, N blocks at both ends and one 3-Mbp
+    centromere-like N block"""
+    from ribbit_amd.simulate import simulate_sequence
+    seq, _ = simulate_sequence(bases, 4, M_LO, M_HI)
+    b = bytearray(seq)
+    edge = min(10_000, bases // 100)
+    b[:edge] = b"N" * edge
+    b[bases - edge:] = b"N" * edge
+    cen = min(3_000_000, bases // 50)
+    mid = bases // 2
+    b[mid:mid + cen] = b"N" * cen
+    return bytes(b)
+
+
+def chr1_full_path(ribbit_amd, bases: int, device: int, traffic: dict):
+    """BASELINE.json configs[2] on its largest record: perfect + substitution + anchored scans, merges, dispatch,
+    refinement, BED text.  Two passes over the scans and merges (the first includes every allocation), one refinement."""
+    t_gen = time.perf_counter()
+    seq = chr1_record(bases)
+    t_gen = time.perf_counter() - t_gen
+    out = {"bases": bases, "generator": "ribbit_amd.simulate seed 4 + N blocks (ends, 3 Mbp centre)", "generate_s": t_gen}
+    with ribbit_amd.PinnedBuffer(bases) as buf, ribbit_amd.Scanner(M_LO, M_HI, device=device) as sc:
+        import numpy as np
+        buf.array[:] = np.frombuffer(seq, dtype=np.uint8)
+        passes = []
+        for rep in range(2):
+            t0 = time.perf_counter()
+            sc.load_record_pinned(buf.ptr, bases)
+            perfect_seeds = sc.processShiftXORsPerfect()
+            t1 = time.perf_counter()
+            perfect, subst, anchored = sc.processShiftXORsAnchored()
+            dispatch = sc.dispatch_seeds()
+            t2 = time.perf_counter()
+            passes.append({"load_and_perfect_stage_s": t1 - t0, "substitution_and_anchored_stages_s": t2 - t1, "scans_and_merges_s": t2 - t0,
+                           "merge_ms": {"substitution": sc.timing_ms(5), "anchored": sc.timing_ms(4)}})
+        kern = {"pack_kernel": sc.timing_ms(0), "scan_window_kernel<1>": sc.timing_ms(6), "scan_anchored_kernel": sc.timing_ms(7)}
+        sc.scan_perfect_runs()
+        kern["scan_perfect_kernel"] = sc.timing_ms(1)
+        # refinement of the lists just made (the perfect re-scan above does not touch them)
+        t3 = time.perf_counter()
+        bed = sc.refine_bed("chr1")
+        t4 = time.perf_counter()
+    scans = passes[1]["scans_and_merges_s"]
+    out.update({
+        "passes": passes, "kernel_ms": kern, "scans_and_merges_s": scans, "refinement_and_bed_s": t4 - t3,
+        "seconds": scans + (t4 - t3), "value": bases / (scans + (t4 - t3)) / 1e9, "unit": "Gbases/s",
+        "scans_and_merges_gbases_per_s": bases / scans / 1e9,
+        "seeds": {"perfect": int(len(perfect)), "substitution": int(len(subst)), "anchored": int(len(anchored))},
+        "dispatched": int(len(dispatch)), "bed_rows": bed.count("\n"),
+        "what": "one chromosome-1-sized record, -m 2 -M 100: FASTA record in page-locked memory -> BED text (pass 2 of the scans and "
+                "merges; pass 1, with every allocation, is listed too)"})
+    roof = {}
+    for name, key in (("scan_window_kernel<1>", "scan_window_kernel"), ("scan_anchored_kernel", "scan_anchored_kernel"), ("scan_perfect_kernel", None)):
+        ms = kern[name]
+        achieved = bases * ALGO_BYTES_PER_BASE / (ms * 1e-3) / 1e9
+        r = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+             "kernel_ms": ms, "algorithmic_bytes_per_launch": bases * ALGO_BYTES_PER_BASE, "kernel_gbases_per_s": bases / (ms * 1e-3) / 1e9, "traffic": None}
+        if key and traffic and traffic.get(key + "_hbm_bytes_per_base") is not None:
+            # PMC passes were taken on a 100-Mbp record (profiles/): bytes per base carry over, the record is all that differs
+            r["traffic"] = traffic[key + "_hbm_bytes_per_base"] * bases
+            r["traffic_source"] = f"profiles/{traffic.get('tag', '?')} PMC passes (FETCH_SIZE x correction + WRITE_SIZE) per base x this record"
+            if traffic.get(key + "_SQ_INSTS_VALU_per_base") is not None:
+                r["valu_wave_instr_per_base"] = traffic[key + "_SQ_INSTS_VALU_per_base"]
+        roof[name] = r
+    out["roofline"] = roof
+    return out
 
 
 def full_path_sample(sc, seq: bytes, bases: int):
@@ -97,7 +274,27 @@ def main():
                     help="N > 1: rank 0 also scans the whole record on its own GPU and checks the sharded runs against it")
     ap.add_argument("--calibrate", action="store_true",
                     help="after the timed region, launch the known-byte-count stream-read kernel (for PMC passes)")
+    ap.add_argument("--chr1-bases", type=int, default=CHR1_BASES,
+                    help="size of the BASELINE configs[2] record of the chr1_full_path leg (0 = skip the leg)")
+    ap.add_argument("--stage-kernels", action="store_true",
+                    help="after the timed region, run the substitution and anchored scan kernels once on the workload record "
+                         "(so that a profiler pass over this command sees all three scan kernels at the same size)")
     args = ap.parse_args()
+
+    # --gpus N without a launcher: start one process per GPU ourselves -- as a CHILD, before this process has touched a
+    # GPU (an exec after HIP is initialised takes the machine down on this pool) -- and leave with its exit code.
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} processes")
 
     import numpy as np
     import torch
@@ -324,10 +521,25 @@ def main():
             out["roofline"]["valu"] = {"wave_instr_per_launch": n_valu, "alignbit_share": ALIGNBIT_SHARE,
                                        "issue_rate_wave_instr_per_s": {"v_alignbit_b32": ALIGNBIT_RATE, "other": PLAIN_VALU_RATE},
                                        "issue_bound_ms": roof_ms, "frac": roof_ms / kavg}
-        if world == 1 and not args.no_cpu_baseline and args.full_path_bases > 0:
-            out["full_path_sample"] = full_path_sample(sc, seq, min(args.full_path_bases, args.bases))
+        if args.stage_kernels:
+            sc.load_record_device(d_ascii.data_ptr(), d_ascii.numel())
+            sc.processShiftXORsAnchored()
+            out["stage_kernels_ms"] = {"scan_window_kernel<1>": sc.timing_ms(6), "scan_anchored_kernel": sc.timing_ms(7)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(seq)
+            prof = json.load(open(tpath)) if os.path.exists(tpath) else {}
+            cpu, oracle_calls, oracle_seeds = cpu_baseline(seq)
+            ok, what = verify_against_oracle(sc, seq, oracle_calls, oracle_seeds)
+            out["verified"] = ok
+            out["verification"] = what
+            out["pcie_inclusive"] = pcie_inclusive(ribbit_amd, seq, max(4, min(args.steps, 12)), depth, local_rank)
+            out["pack_hbm"] = pack_hbm(ribbit_amd, torch, seq, dev, local_rank)
+            if args.full_path_bases > 0:
+                out["full_path_sample"] = full_path_sample(sc, seq, min(args.full_path_bases, args.bases))
+            if args.chr1_bases > 0:
+                for h in scs[1:]:
+                    h.close()                     # their buffers are not needed any more; the chr1 record wants the room
+                out["chr1_full_path"] = chr1_full_path(ribbit_amd, args.chr1_bases, local_rank, prof)
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
 
     if ng is not None:

@@ -88,12 +88,24 @@ int ribbit_hip_set_stream(RibbitHandle *h, void *hip_stream);
 /*
  * Load one FASTA record (ASCII bases, no newlines).  Replaces the 2-bit encode of
  * fasta_utils.cpp:78-115: H2D copy + pack kernel -> device bit planes (left, right, N).
+ * Must not be called between ribbit_hip_scan_perfect_begin and _end on the same handle (RIBBIT_E_STATE).
  * The shift-XOR sweep of fasta_utils.cpp:117-122 is never materialised; each scan kernel
  * recomputes X_s words in registers.
  */
 int ribbit_hip_load_record(RibbitHandle *h, const char *ascii, int64_t length);
-/* Same, but the ASCII bases are already in device memory (length bytes at dev_ascii). */
+/* Same, but the ASCII bases are already in device memory (length bytes at dev_ascii).  dev_ascii stays the caller's and
+ * is READ AGAIN by later calls on this record (the refinement kernels and the fetch of the bases for alignment): it must
+ * stay valid and unchanged until the next load on this handle or ribbit_hip_close(). */
 int ribbit_hip_load_record_device(RibbitHandle *h, const void *dev_ascii, int64_t length);
+/* Same as ribbit_hip_load_record from page-locked host memory (ribbit_hip_host_alloc) that the caller keeps valid and
+ * unchanged until the next load on this handle or ribbit_hip_close(): the upload runs asynchronously at link speed on
+ * the handle's upload stream (the previous record's kernels keep running), and refinement reads the bases in place --
+ * no host copy of the record is made.  This is what a streaming FASTA reader hands over (ribbit.cpp:269-280 is the
+ * loop it replaces: getline + string += into one pageable std::string per record). */
+int ribbit_hip_load_record_pinned(RibbitHandle *h, const char *pinned_ascii, int64_t length);
+/* Page-locked host memory for ribbit_hip_load_record_pinned (hipHostMalloc / hipHostFree). */
+int ribbit_hip_host_alloc(size_t bytes, void **out);
+int ribbit_hip_host_free(void *p);
 
 /*
  * Device hot loop of processShiftXORsPerfect (parse_perfect_shiftxor.cpp:173-223) without the
@@ -428,8 +440,8 @@ void ribbit_runs_free(RibbitRun *runs);
 /* Timing of the last call, milliseconds.  what: 0 pack kernel, 1 last scan kernel, 2 GPU side of
  * the last scan (kernel + pairing + state machine + sort + read-back), all by HIP events on the launch stream;
  * 3 everything after the pairing of the last window stage (device state machine, sort, read-back; wall clock);
- * 4 the sequential host merge of the last window stage (wall clock); 5 that of the substitution stage when
- * ribbit_hip_seeds_anchored ran both stages. */
+ * 4 the host merge of the last window stage (wall clock); 5 that of the substitution stage when
+ * ribbit_hip_seeds_anchored ran both stages; 6 / 7 the scan kernel of the substitution / anchored stage (HIP events). */
 int ribbit_hip_last_timing_ms(const RibbitHandle *h, int what, double *ms);
 /* Profiling aid (no effect on results): streams `nbytes` of the loaded record's ASCII buffer /
  * planes through calib_stream_read_kernel so that a PMC pass contains a launch with a known byte

@@ -33,7 +33,7 @@ SEED_DT = np.dtype([("start", "<i4"), ("end", "<i4"), ("mlen", "<i4"), ("type", 
 ABI_SYMBOLS = [
     "ribbit_scan_params_default", "ribbit_hip_last_error", "ribbit_hip_abi_version",
     "ribbit_hip_device_count", "ribbit_hip_open", "ribbit_hip_close", "ribbit_hip_set_stream",
-    "ribbit_hip_load_record", "ribbit_hip_load_record_device", "ribbit_hip_scan_perfect_runs",
+    "ribbit_hip_load_record", "ribbit_hip_load_record_device", "ribbit_hip_load_record_pinned", "ribbit_hip_host_alloc", "ribbit_hip_host_free", "ribbit_hip_scan_perfect_runs",
     "ribbit_hip_perfect_calls", "ribbit_hip_seeds_perfect", "ribbit_hip_plane_bits",
     "ribbit_hip_range_popcount", "ribbit_hip_plane_words", "ribbit_hip_packed_plane",
     "ribbit_hip_last_timing_ms", "ribbit_hip_last_event_count",
@@ -110,6 +110,9 @@ def load_library():
     L.ribbit_hip_set_stream.argtypes = [vp, vp]
     L.ribbit_hip_load_record.argtypes = [vp, C.c_char_p, i64]
     L.ribbit_hip_load_record_device.argtypes = [vp, vp, i64]
+    L.ribbit_hip_load_record_pinned.argtypes = [vp, vp, i64]
+    L.ribbit_hip_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.ribbit_hip_host_free.argtypes = [vp]
     for f in ("ribbit_hip_scan_perfect_runs", "ribbit_hip_perfect_calls", "ribbit_hip_seeds_perfect", "ribbit_hip_subst_calls",
               "ribbit_hip_anchored_calls", "ribbit_hip_dispatch_seeds"):
         getattr(L, f).argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -413,6 +416,32 @@ def merge_chunk_runs(parts, halves) -> np.ndarray:
     return allr[np.lexsort((allr["start"], allr["mlen"]))]
 
 
+class PinnedBuffer:
+    """page-locked host memory (ribbit_hip_host_alloc) as a writable numpy uint8 view"""
+
+    def __init__(self, nbytes: int):
+        self._L = load_library()
+        p = C.c_void_p()
+        rc = self._L.ribbit_hip_host_alloc(max(int(nbytes), 1), C.byref(p))
+        if rc != 0:
+            raise RibbitHipError(f"ribbit_hip_host_alloc error {rc}: {self._L.ribbit_hip_last_error().decode()}")
+        self.ptr = p.value
+        self.nbytes = int(nbytes)
+        self.array = np.frombuffer((C.c_char * max(self.nbytes, 1)).from_address(self.ptr), dtype=np.uint8)[:self.nbytes]
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            self._L.ribbit_hip_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 class Scanner:
     """One GPU-resident FASTA record and the scans over it.
 
@@ -475,6 +504,11 @@ class Scanner:
         self._keep = bytes(sequence)
         self.length = len(self._keep)
         self._check(self._L.ribbit_hip_load_record(self._h, self._keep, self.length))
+
+    def load_record_pinned(self, host_ptr: int, length: int):
+        """bases in page-locked memory (PinnedBuffer) that stays valid until the next load: async upload, no host copy"""
+        self.length = int(length)
+        self._check(self._L.ribbit_hip_load_record_pinned(self._h, C.c_void_p(host_ptr), self.length))
 
     def load_record_device(self, dev_ptr: int, length: int):
         self.length = int(length)

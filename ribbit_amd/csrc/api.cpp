@@ -180,8 +180,13 @@ struct RibbitHandle {
     std::vector<RibbitAlignJob> jobs;
     std::string motif_pool;
     std::vector<uint64_t> export_events, export_counts;
-    std::string host_ascii;   // the record's bases on the host (refinement slices them for the aligner)
+    std::string host_ascii;   // the record's bases on the host when they had to be fetched back (refinement slices them for the aligner)
     bool host_ascii_valid = false;
+    const char *host_bases = nullptr;     // where refinement reads the bases: the caller's page-locked buffer (load_record_pinned) or host_ascii
+    hipStream_t up_stream = nullptr;      // uploads: the next record's bases travel while this record's kernels run
+    hipEvent_t ev_up = nullptr, ev_busy = nullptr;
+    hipEvent_t ev_stage[2][2] = {};       // scan kernel of the substitution [0] / anchored [1] stage
+    bool have_stage_timing[2] = {false, false};
     const uint8_t *dev_ascii_src = nullptr;
     std::string bed;
     int stage_done = STAGE_NONE;          // how far the seed lists have been advanced
@@ -212,7 +217,13 @@ int is_gfx950(int device) {
     return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
 }
 
+int perfect_wait(RibbitHandle *h);
+
 int pack_loaded_ascii(RibbitHandle *h, const uint8_t *dev_ascii, int64_t length) {
+    // a perfect scan enqueued with ribbit_hip_scan_perfect_begin still reads the planes and counters the pack kernel
+    // is about to rewrite
+    if (h->pair_pending) return fail(RIBBIT_E_STATE, "a perfect scan is in flight on this handle: call ribbit_hip_scan_perfect_end first");
+    if (h->copy_pending) { const int rcw = perfect_wait(h); if (rcw) return rcw; }
     h->loaded = false;
     h->dev_ascii_src = dev_ascii;
     h->runs_valid = h->calls_valid = h->subst_calls_valid = h->anchored_calls_valid = false;
@@ -574,10 +585,13 @@ int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks) {
         pp.ev_cap = (uint32_t)cap;
         pr.region_cap = pp.ev_cap / (uint32_t)rb::EV_SHARDS;
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+        HIP_TRY(hipEventRecord(h->ev_stage[which - 1][0], h->stream));
         if (which == 1) rb::launch_scan_window(pl, pp, 1, h->d_events.p, h->d_counters.p, h->stream);
         else rb::launch_scan_anchored(pl, pp, h->d_xa.p, h->xa_stride, h->d_events.p, h->d_counters.p, h->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+        HIP_TRY(hipEventRecord(h->ev_stage[which - 1][1], h->stream));
+        h->have_stage_timing[which - 1] = true;
         rb::launch_pair_runs(h->d_events.p, h->d_counters.p, pr, h->d_pair_table.p, h->d_run_base.p, h->d_pair_partial.p,
                              h->d_dense.p, (uint32_t)(cap / 2), h->d_halves.p, (uint32_t)(2 * (size_t)pr.nm), h->d_pair_status.p, h->stream);
         HIP_TRY(hipGetLastError());
@@ -1017,6 +1031,10 @@ int ribbit_hip_open(const RibbitScanParams *params, int device, RibbitHandle **o
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&h->ev_xa, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&h->ev_busy, hipEventDisableTiming);
+    for (int i = 0; i < 4 && err == hipSuccess; ++i) err = hipEventCreate(&h->ev_stage[i / 2][i % 2]);
     for (int i = 0; i < 6 && err == hipSuccess; ++i) err = hipEventCreate(&h->ev[i]);
     if (err != hipSuccess) {
         delete h;
@@ -1045,6 +1063,10 @@ int ribbit_hip_close(RibbitHandle *h) {
     for (int k = 0; k < 2; ++k) { h->h_calls_[k].release(); h->h_flush_[k].release(); h->h_pend_[k].release(); h->h_ws_[k].release(); }
     h->h_xa.release();
     if (h->ev_xa) (void)hipEventDestroy(h->ev_xa);
+    if (h->ev_up) (void)hipEventDestroy(h->ev_up);
+    if (h->ev_busy) (void)hipEventDestroy(h->ev_busy);
+    for (int i = 0; i < 4; ++i) if (h->ev_stage[i / 2][i % 2]) (void)hipEventDestroy(h->ev_stage[i / 2][i % 2]);
+    if (h->up_stream) { (void)hipStreamSynchronize(h->up_stream); (void)hipStreamDestroy(h->up_stream); }
     for (int i = 0; i < 6; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -1059,16 +1081,37 @@ int ribbit_hip_set_stream(RibbitHandle *h, void *hip_stream) {
     return RIBBIT_OK;
 }
 
-int ribbit_hip_load_record(RibbitHandle *h, const char *ascii, int64_t length) {
-    if (!h || (!ascii && length > 0)) return fail(RIBBIT_E_ARG, "null argument");
-    if (length < 0 || length >= ((int64_t)1 << 31) - 64) return fail(RIBBIT_E_ARG, "record length %lld not supported (positions are int32, fasta_utils.cpp:78)", (long long)length);
+// H2D of the bases on the upload stream (so that it overlaps kernels of other handles on a shared compute stream),
+// then the pack kernel on the compute stream
+static int upload_and_pack(RibbitHandle *h, const char *ascii, int64_t length) {
     int rc;
     if ((rc = bind_device(h))) return rc;
     if ((rc = h->d_ascii.ensure((size_t)std::max<int64_t>(length, 16)))) return rc;
-    if (length) HIP_TRY(hipMemcpyAsync(h->d_ascii.p, ascii, (size_t)length, hipMemcpyHostToDevice, h->stream));
-    rc = pack_loaded_ascii(h, h->d_ascii.p, length);
-    if (rc == RIBBIT_OK) { h->host_ascii.assign(ascii, (size_t)length); h->host_ascii_valid = true; }
-    return rc;
+    if (length) {
+        // the previous record's kernels may still read d_ascii
+        HIP_TRY(hipEventRecord(h->ev_busy, h->stream));
+        HIP_TRY(hipStreamWaitEvent(h->up_stream, h->ev_busy, 0));
+        HIP_TRY(hipMemcpyAsync(h->d_ascii.p, ascii, (size_t)length, hipMemcpyHostToDevice, h->up_stream));
+        HIP_TRY(hipEventRecord(h->ev_up, h->up_stream));
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_up, 0));
+    }
+    return pack_loaded_ascii(h, h->d_ascii.p, length);
+}
+
+int ribbit_hip_load_record(RibbitHandle *h, const char *ascii, int64_t length) {
+    if (!h || (!ascii && length > 0)) return fail(RIBBIT_E_ARG, "null argument");
+    if (length < 0 || length >= ((int64_t)1 << 31) - 64) return fail(RIBBIT_E_ARG, "record length %lld not supported (positions are int32, fasta_utils.cpp:78)", (long long)length);
+    h->host_ascii_valid = false;      // not duplicated: refinement fetches the bases back from the device if it runs
+    h->host_bases = nullptr;
+    return upload_and_pack(h, ascii, length);
+}
+
+int ribbit_hip_load_record_pinned(RibbitHandle *h, const char *pinned_ascii, int64_t length) {
+    if (!h || (!pinned_ascii && length > 0)) return fail(RIBBIT_E_ARG, "null argument");
+    if (length < 0 || length >= ((int64_t)1 << 31) - 64) return fail(RIBBIT_E_ARG, "record length %lld not supported", (long long)length);
+    h->host_ascii_valid = false;
+    h->host_bases = pinned_ascii;     // stays the caller's; read again by refinement
+    return upload_and_pack(h, pinned_ascii, length);
 }
 
 int ribbit_hip_load_record_device(RibbitHandle *h, const void *dev_ascii, int64_t length) {
@@ -1077,7 +1120,22 @@ int ribbit_hip_load_record_device(RibbitHandle *h, const void *dev_ascii, int64_
     int rc;
     if ((rc = bind_device(h))) return rc;
     h->host_ascii_valid = false;
+    h->host_bases = nullptr;
     return pack_loaded_ascii(h, (const uint8_t *)dev_ascii, length);
+}
+
+int ribbit_hip_host_alloc(size_t bytes, void **out) {
+    if (!out || !bytes) return fail(RIBBIT_E_ARG, "bad argument");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { *out = nullptr; return fail(RIBBIT_E_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_host_free(void *p) {
+    if (!p) return RIBBIT_OK;
+    HIP_TRY(hipHostFree(p));
+    return RIBBIT_OK;
 }
 
 int ribbit_hip_scan_perfect_runs(RibbitHandle *h, const RibbitRun **out, size_t *n) {
@@ -1324,7 +1382,7 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
     if (rc) return rc;
     t_rows += now_ms() - t0;
     t0 = now_ms();
-    if (!h->host_ascii_valid) {      // record was loaded from device memory: fetch the bases once
+    if (!h->host_bases && !h->host_ascii_valid) {      // bases not on the host in memory we may keep reading: fetch them once
         h->host_ascii.resize((size_t)h->length);
         if (h->length) {
             HIP_TRY(hipMemcpyAsync(&h->host_ascii[0], h->dev_ascii_src, (size_t)h->length, hipMemcpyDeviceToHost, h->stream));
@@ -1353,7 +1411,7 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
     }
     t_jobs += now_ms() - t0;
     t0 = now_ms();
-    rb::refine_to_bed(h->host, h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sequence_id, h->bed,
+    rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sequence_id, h->bed,
                       h->host_threads, jobs, jobs ? &h->ssw_ends : nullptr);
     t_text += now_ms() - t0;
     if (profile) std::fprintf(stderr, "[refine_bed] cumulative: GPU scans of the seeds %.1f ms, alignment set-up + GPU striped passes %.1f ms, host refinement + BED %.1f ms\n", t_rows, t_jobs, t_text);
@@ -1843,7 +1901,15 @@ int ribbit_hip_last_timing_ms(const RibbitHandle *h, int what, double *ms) {
     if (what == 3) { *ms = h->host_ms; return RIBBIT_OK; }
     if (what == 4) { *ms = h->merge_ms; return RIBBIT_OK; }
     if (what == 5) { *ms = h->subst_merge_ms; return RIBBIT_OK; }
-    if (what < 0 || what > 5) return fail(RIBBIT_E_ARG, "what must be 0..5");
+    if (what == 6 || what == 7) {
+        if (!h->have_stage_timing[what - 6]) return fail(RIBBIT_E_STATE, "that stage's kernel has not run on this handle");
+        float f = 0.f;
+        HIP_TRY(hipEventSynchronize(h->ev_stage[what - 6][1]));
+        HIP_TRY(hipEventElapsedTime(&f, h->ev_stage[what - 6][0], h->ev_stage[what - 6][1]));
+        *ms = f;
+        return RIBBIT_OK;
+    }
+    if (what < 0 || what > 7) return fail(RIBBIT_E_ARG, "what must be 0..7");
     if (!h->have_timing[what]) return fail(RIBBIT_E_STATE, "no timing recorded yet");
     float f = 0.f;
     HIP_TRY(hipEventSynchronize(h->ev[2 * what + 1]));

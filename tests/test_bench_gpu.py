@@ -19,7 +19,7 @@ def _line(out):
 
 
 def test_single_gpu_line_has_the_contracted_fields():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--bases", "3000000"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--bases", "3000000", "--chr1-bases", "4000000"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
@@ -36,8 +36,34 @@ def test_single_gpu_line_has_the_contracted_fields():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Gbases/s" and cb["value"] > 0 and cb["sample"]
     assert d["value"] > cb["value"]
+    assert cb["host_cpu"] and cb["host_cores_available"] >= 1
     fp = d["full_path_sample"]
     assert fp["bases"] == 3_000_000 and fp["bed_rows"] > 1000 and 0 < fp["value"] < d["value"] and fp["unit"] == "Gbases/s"
+    # self-check and the other legs of an N = 1 run
+    assert d["verified"] is True and d["verification"]["perfect_calls"] > 0
+    pi = d["pcie_inclusive"]
+    assert pi["unit"] == "Gbases/s" and 0 < pi["value"] < 60 and pi["h2d_bytes_per_step"] == 3_000_000     # 1 B/base over PCIe bounds it
+    ph = d["pack_hbm"]
+    assert ph["kernel"] == "pack_kernel" and 0 < ph["frac"] < 1 and ph["working_set_bytes"] == 8 * 3_000_000
+    c1 = d["chr1_full_path"]
+    assert c1["bases"] == 4_000_000 and c1["bed_rows"] > 1000 and c1["seeds"]["anchored"] > 0 and len(c1["passes"]) == 2
+    for k in ("scan_window_kernel<1>", "scan_anchored_kernel", "scan_perfect_kernel"):
+        rf2 = c1["roofline"][k]
+        assert rf2["bound"] == "hbm" and rf2["kernel_ms"] > 0 and abs(rf2["frac"] - rf2["achieved"] / 8000.0) < 1e-12
+        assert abs(rf2["achieved"] - 4e6 * 0.375 / (rf2["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * rf2["achieved"]
+
+
+def test_gpus_flag_without_a_launcher_starts_the_ranks_itself_or_fails():
+    """`python bench.py --gpus 2` must never quietly run one process: it launches two ranks (on this one-GPU box the second
+    rank has no device, so the run fails) -- and with a launcher whose WORLD_SIZE disagrees it refuses."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--bases", "1000000",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert (r.returncode == 0 and len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2) or r.returncode != 0
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=120, cwd=ROOT, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
 
 
 @pytest.mark.parametrize("exchange", ["shm", "rccl"])
