@@ -274,6 +274,25 @@ int ribbit_host_refine_bed(const RibbitScanParams *params, const RibbitRefinePar
                            const char *sequence_id, char **text, size_t *len);
 void ribbit_text_free(char *text);
 
+/*
+ * ---- streaming FASTA ingest ---------------------------------------------------------------------------------------
+ * Replaces the reader loop of ribbit.cpp:269-280 (getline + `sequence += line` into one pageable std::string per
+ * record).  The file is read in 16-MB blocks; line bodies are copied once, straight into a page-locked buffer
+ * (pinned != 0; plain malloc otherwise, for hosts without a GPU) that ribbit_hip_load_record_pinned uploads from
+ * asynchronously and refinement reads in place.  Record boundaries follow the reference loop exactly: a '>' line ends
+ * the previous record if it has any bases and names the next one (text up to the first space); other lines are appended
+ * without their '\n'; the last record is handed out even when it is empty (*is_last = 1: ribbit.cpp:280 processes it
+ * without the "Processing sequence" line).
+ * ribbit_fasta_next returns 1 with a record, 0 after the last one, < 0 on error; *bases stays valid until
+ * ribbit_fasta_release (any thread) or ribbit_fasta_close; released buffers are reused.
+ */
+typedef struct RibbitFastaReader RibbitFastaReader;
+int ribbit_fasta_open(const char *path, int pinned, RibbitFastaReader **out);
+int ribbit_fasta_next(RibbitFastaReader *r, const char **name, const char **bases, int64_t *length, int *is_last);
+int ribbit_fasta_release(RibbitFastaReader *r, const char *bases);
+int ribbit_fasta_close(RibbitFastaReader *r);
+const char *ribbit_fasta_last_error(void);
+
 /* How often the defined-divergence guards fired in the merges of this record (the
  * reference has undefined behaviour there; 0 on ordinary inputs). */
 int64_t ribbit_hip_guard_hits(const RibbitHandle *h);

@@ -33,7 +33,8 @@ SEED_DT = np.dtype([("start", "<i4"), ("end", "<i4"), ("mlen", "<i4"), ("type", 
 ABI_SYMBOLS = [
     "ribbit_scan_params_default", "ribbit_hip_last_error", "ribbit_hip_abi_version",
     "ribbit_hip_device_count", "ribbit_hip_open", "ribbit_hip_close", "ribbit_hip_set_stream",
-    "ribbit_hip_load_record", "ribbit_hip_load_record_device", "ribbit_hip_load_record_pinned", "ribbit_hip_host_alloc", "ribbit_hip_host_free", "ribbit_hip_scan_perfect_runs",
+    "ribbit_hip_load_record", "ribbit_hip_load_record_device", "ribbit_hip_load_record_pinned", "ribbit_hip_host_alloc", "ribbit_hip_host_free",
+    "ribbit_fasta_open", "ribbit_fasta_next", "ribbit_fasta_release", "ribbit_fasta_close", "ribbit_fasta_last_error", "ribbit_hip_scan_perfect_runs",
     "ribbit_hip_perfect_calls", "ribbit_hip_seeds_perfect", "ribbit_hip_plane_bits",
     "ribbit_hip_range_popcount", "ribbit_hip_plane_words", "ribbit_hip_packed_plane",
     "ribbit_hip_last_timing_ms", "ribbit_hip_last_event_count",
@@ -113,6 +114,11 @@ def load_library():
     L.ribbit_hip_load_record_pinned.argtypes = [vp, vp, i64]
     L.ribbit_hip_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.ribbit_hip_host_free.argtypes = [vp]
+    L.ribbit_fasta_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.ribbit_fasta_next.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(i64), C.POINTER(C.c_int)]
+    L.ribbit_fasta_release.argtypes = [vp, vp]
+    L.ribbit_fasta_close.argtypes = [vp]
+    L.ribbit_fasta_last_error.restype = C.c_char_p
     for f in ("ribbit_hip_scan_perfect_runs", "ribbit_hip_perfect_calls", "ribbit_hip_seeds_perfect", "ribbit_hip_subst_calls",
               "ribbit_hip_anchored_calls", "ribbit_hip_dispatch_seeds"):
         getattr(L, f).argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -414,6 +420,29 @@ def merge_chunk_runs(parts, halves) -> np.ndarray:
     allr = np.concatenate([np.asarray(p) for p in parts] + [join_run_halves(halves)])
     allr = allr[allr["term"] >= 0]
     return allr[np.lexsort((allr["start"], allr["mlen"]))]
+
+
+def read_fasta(path: str, pinned: bool = False):
+    """records of a FASTA file as ribbit_fasta_* delimits them (the reference's reader loop, ribbit.cpp:269-280):
+    [(name, bases bytes, is_last)]"""
+    L = load_library()
+    r = C.c_void_p()
+    if L.ribbit_fasta_open(path.encode(), int(pinned), C.byref(r)) != 0:
+        raise RibbitHipError(L.ribbit_fasta_last_error().decode())
+    out = []
+    try:
+        while True:
+            name, bases, n, last = C.c_char_p(), C.c_void_p(), C.c_int64(), C.c_int()
+            got = L.ribbit_fasta_next(r, C.byref(name), C.byref(bases), C.byref(n), C.byref(last))
+            if got < 0:
+                raise RibbitHipError(L.ribbit_fasta_last_error().decode())
+            if got == 0:
+                break
+            out.append((name.value.decode(), C.string_at(bases.value, n.value), bool(last.value)))
+            L.ribbit_fasta_release(r, bases)
+    finally:
+        L.ribbit_fasta_close(r)
+    return out
 
 
 class PinnedBuffer:

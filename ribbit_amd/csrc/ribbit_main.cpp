@@ -5,8 +5,10 @@
 //   ribbit-hip -i in.fa [-o out.bed] [-m 2] [-M 100] [-p 0.85] [-l N|file] [--min-units N|file] [--perfect-units N|file]
 //
 // Records are independent (ribbit.cpp:269-280 handles them one after the other); here up to --jobs of them are in
-// flight at once, each on its own handle / HIP stream, so that the GPU scans of one record overlap the sequential
-// host merges of the others (long-read inputs: thousands of 10-100 kb records).  Output order is the input order.
+// flight at once, each on its own handle / HIP streams, so that the upload and GPU scans of one record overlap the
+// host merges and refinement of the others (long-read inputs: thousands of 10-100 kb records).  Output order is the
+// input order.  The file is read by ribbit_fasta_* (block reads, line bodies copied once into page-locked buffers that
+// the GPU uploads from asynchronously and refinement reads in place) instead of getline + string +=.
 //
 // Reproduced quirks: -p is accepted and ignored (Q1); without -o the BED rows go to
 // stderr (Q2); --help exits with status 1 (Q3); the record name ends at the first space and the last
@@ -59,10 +61,14 @@ const char *kHelp =
     "  --jobs arg                    (ribbit-hip) FASTA records processed side by side. Default: automatic\n"
     "  --device arg                  (ribbit-hip) GPU ordinal. Default: 0\n";
 
-[[noreturn]] void die(const std::string &msg) {
+[[noreturn]] void die(const std::string &msg) {        // argument errors: main thread, before any worker exists
     std::cerr << "ribbit-hip: " << msg << "\n";
     std::exit(1);
 }
+
+// a failure of the GPU path inside the record pipeline: carried to main(), which lets the workers drain, closes the
+// handles and returns 1 (exiting from a worker would run static destructors under live threads)
+struct PathError { std::string what; };
 
 // returns 0 for --help (the caller exits 1, as the reference does), 1 on success
 int parse_arguments(int argc, char **argv, Options &o) {
@@ -152,7 +158,7 @@ void build_refine_params(const Options &o, RibbitRefineParams &prm) {
 }
 
 void check(int rc) {
-    if (rc != RIBBIT_OK) die(std::string("GPU path failed: ") + ribbit_hip_last_error());
+    if (rc != RIBBIT_OK) throw PathError{std::string("GPU path failed: ") + ribbit_hip_last_error()};
 }
 
 size_t count_failed(const RibbitSeed *s, size_t n) {
@@ -163,19 +169,24 @@ size_t count_failed(const RibbitSeed *s, size_t n) {
 
 // RIBBIT_PROFILE=1: wall time per stage, summed over the records, printed at exit
 double g_stage_ms[6] = {0, 0, 0, 0, 0, 0};
+std::mutex g_stage_mu;
 struct StageClock {
     int slot;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     explicit StageClock(int s) : slot(s) {}
-    ~StageClock() { g_stage_ms[slot] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+    ~StageClock() {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        g_stage_ms[slot] += ms;
+    }
 };
 
 // processSequence (fasta_utils.cpp:59-250) through the C ABI, with the reference's progress lines
-void process_sequence(RibbitHandle *h, const RibbitRefineParams &prm, const std::string &name, const std::string &sequence,
+void process_sequence(RibbitHandle *h, const RibbitRefineParams &prm, const std::string &name, const char *bases, int64_t length,
                       std::ostream &out, std::ostream &log) {
     const time_t t0 = time(0);
     auto secs = [&]() { return difftime(time(0), t0); };
-    { StageClock c(0); check(ribbit_hip_load_record(h, sequence.data(), (int64_t)sequence.size())); }
+    { StageClock c(0); check(ribbit_hip_load_record_pinned(h, bases, length)); }
     log << "Generated shift XORs!\t Time elapsed:" << secs() << "secs\n";
     const RibbitSeed *p, *s, *a;
     size_t np, ns, na;
@@ -217,7 +228,7 @@ int main(int argc, char **argv) {
     RibbitScanParams scan;
     ribbit_scan_params_default(&scan, opt.min_motif, opt.max_motif);
     RibbitHandle *h = nullptr;
-    check(ribbit_hip_open(&scan, opt.device, &h));
+    if (ribbit_hip_open(&scan, opt.device, &h) != RIBBIT_OK) die(std::string("GPU path failed: ") + ribbit_hip_last_error());
 
     // ---- record pipeline: the reader (this thread) parses records; `jobs` workers process them on their own
     // handles; results are written in input order.  A record weighs ceil(length / 4 Mbp) of the `jobs` tokens (at
@@ -228,7 +239,7 @@ int main(int argc, char **argv) {
     if (const char *env = std::getenv("RIBBIT_JOBS")) jobs = std::max(1, std::atoi(env));
     if (opt.jobs > 0) jobs = opt.jobs;
     jobs = std::min(jobs, 64);
-    struct Record { size_t index; std::string name, sequence; };
+    struct Record { size_t index; std::string name; const char *bases; int64_t length; };
     struct Result { std::string bed, log; };
     std::mutex mu;
     std::condition_variable cv;
@@ -236,7 +247,14 @@ int main(int argc, char **argv) {
     std::map<size_t, Result> done;
     size_t next_out = 0;
     bool reader_done = false;
+    bool failed = false;            // some record's GPU path failed: everybody drains
+    std::string failure;
     int tokens = jobs;
+    RibbitFastaReader *reader = nullptr;
+    if (ribbit_fasta_open(opt.fasta.c_str(), 1, &reader) != RIBBIT_OK) {
+        // the reference's ifstream on a missing file simply yields no lines: one empty, unnamed record (Q4)
+        std::cerr << "ribbit-hip: " << ribbit_fasta_last_error() << "\n";
+    }
 
     auto flush_ready = [&]() {                      // call with mu held
         for (auto it = done.find(next_out); it != done.end(); it = done.find(next_out)) {
@@ -254,7 +272,7 @@ int main(int argc, char **argv) {
                 std::unique_lock<std::mutex> lk(mu);
                 for (;;) {
                     if (!queue.empty()) {
-                        weight = (int)std::min<size_t>((size_t)jobs, queue.front().sequence.size() / 4000000 + 1);
+                        weight = (int)std::min<size_t>((size_t)jobs, (size_t)queue.front().length / 4000000 + 1);
                         if (tokens >= weight) break;
                     } else if (reader_done) {
                         return;
@@ -266,15 +284,27 @@ int main(int argc, char **argv) {
                 tokens -= weight;
             }
             cv.notify_all();
-            check(ribbit_hip_set_host_threads(wh, (int)std::max(1u, cores * (unsigned)weight / (unsigned)jobs)));
             std::ostringstream bed, log;
-            log << "Processing sequence " << rec.name << "\n";
-            process_sequence(wh, prm, rec.name, rec.sequence, bed, log);
+            bool ok = true;
+            std::string why;
+            {
+                bool skip;
+                { std::lock_guard<std::mutex> lk(mu); skip = failed; }
+                if (!skip) {
+                    try {
+                        check(ribbit_hip_set_host_threads(wh, (int)std::max(1u, cores * (unsigned)weight / (unsigned)jobs)));
+                        log << "Processing sequence " << rec.name << "\n";
+                        process_sequence(wh, prm, rec.name, rec.bases, rec.length, bed, log);
+                    } catch (const PathError &e) { ok = false; why = e.what; }
+                }
+            }
+            ribbit_fasta_release(reader, rec.bases);
             {
                 std::lock_guard<std::mutex> lk(mu);
+                if (!ok && !failed) { failed = true; failure = why; }
                 done[rec.index] = Result{bed.str(), log.str()};
                 tokens += weight;
-                flush_ready();
+                if (!failed) flush_ready();
             }
             cv.notify_all();
         }
@@ -282,49 +312,57 @@ int main(int argc, char **argv) {
     std::vector<RibbitHandle *> handles{h};
     for (int j = 1; j < jobs; ++j) {
         RibbitHandle *extra = nullptr;
-        check(ribbit_hip_open(&scan, opt.device, &extra));
+        if (ribbit_hip_open(&scan, opt.device, &extra) != RIBBIT_OK) { failed = true; failure = std::string("GPU path failed: ") + ribbit_hip_last_error(); break; }
         handles.push_back(extra);
     }
     std::vector<std::thread> pool;
     for (RibbitHandle *wh : handles) pool.emplace_back(worker, wh);
 
+    // ribbit.cpp:269-279 -- records as the reference's getline loop delimits them; :280 -- the last record is processed
+    // unconditionally and WITHOUT the "Processing sequence" line, also for an empty file (Q4): it bypasses the pipeline
+    // once the pipeline has drained
     size_t n_records = 0;
-    auto submit = [&](std::string &name, std::string &sequence) {
+    std::string last_name;
+    const char *last_bases = nullptr;
+    int64_t last_length = 0;
+    for (;;) {
+        const char *name = "", *bases = nullptr;
+        int64_t length = 0;
+        int is_last = 1;
+        const int got = reader ? ribbit_fasta_next(reader, &name, &bases, &length, &is_last) : 0;
+        if (got < 0) { std::lock_guard<std::mutex> lk(mu); failed = true; failure = ribbit_fasta_last_error(); break; }
+        if (got == 0) break;
+        if (is_last) { last_name = name; last_bases = bases; last_length = length; break; }
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return queue.size() < (size_t)(2 * jobs); });       // bounded look-ahead
-        queue.push_back(Record{n_records++, name, std::move(sequence)});
+        cv.wait(lk, [&] { return queue.size() < (size_t)(2 * jobs) || failed; });       // bounded look-ahead
+        if (failed) break;
+        queue.push_back(Record{n_records++, name, bases, length});
         cv.notify_all();
-    };
-    std::ifstream in(opt.fasta);
-    std::string line, name, sequence;
-    while (std::getline(in, line)) {                                          // ribbit.cpp:269-279
-        if (!line.empty() && line[0] == '>') {
-            if (!sequence.empty()) submit(name, sequence);
-            const size_t sp = line.find(' ');
-            name = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
-            sequence.clear();
-        } else {
-            sequence += line;
-        }
     }
-    // :280 -- the last record is processed unconditionally and WITHOUT the "Processing sequence" line, also for an
-    // empty file (Q4): it bypasses the pipeline once the pipeline has drained
     {
         std::unique_lock<std::mutex> lk(mu);
         reader_done = true;
         cv.notify_all();
     }
     for (std::thread &t : pool) t.join();
+    int status = 0;
     {
         std::lock_guard<std::mutex> lk(mu);
-        flush_ready();
+        if (!failed) flush_ready();
     }
-    check(ribbit_hip_set_host_threads(h, 0));
-    process_sequence(h, prm, name, sequence, out, std::cerr);
+    if (!failed) {
+        try {
+            check(ribbit_hip_set_host_threads(h, 0));
+            static const char kNoBases[1] = {0};
+            process_sequence(h, prm, last_name, last_bases ? last_bases : kNoBases, last_length, out, std::cerr);
+        } catch (const PathError &e) { failed = true; failure = e.what; }
+    }
+    if (failed) { std::cerr << "ribbit-hip: " << failure << "\n"; status = 1; }
     for (size_t j = 1; j < handles.size(); ++j) ribbit_hip_close(handles[j]);
     ribbit_hip_close(h);
+    if (reader) ribbit_fasta_close(reader);
     if (std::getenv("RIBBIT_PROFILE"))
         std::cerr << "[stages, ms over all records] load " << g_stage_ms[0] << "  perfect " << g_stage_ms[1] << "  substitutions "
                   << g_stage_ms[2] << "  anchored " << g_stage_ms[3] << "  dispatch " << g_stage_ms[4] << "  refine+BED " << g_stage_ms[5] << "\n";
-    return 0;
+    return status;
 }

@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # --depth 1: one batch at a time, so that a kernel's duration in the trace is its own (with several batches in flight the
 # result copies -- blit kernels on this stack -- share the CUs with the next batch's scan under the profiler)
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline --calibrate --depth 1"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --calibrate --depth 1 --stage-kernels"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/bench_write.err
@@ -19,6 +19,6 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write 
 # know just leaves its pass empty)
 for SET in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "VALUBusy" "SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
   D=$OUT/pmc_$(echo $SET | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $D -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --depth 1 > $D.json 2> $D.err || echo "pass [$SET] failed"
+  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $D -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --depth 1 --stage-kernels > $D.json 2> $D.err || echo "pass [$SET] failed"
 done
 find $OUT -name "*.csv" | head -40

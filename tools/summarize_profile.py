@@ -56,6 +56,22 @@ out = {
 for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "VALUBusy", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
     if c in scan:
         out["scan_perfect_kernel_" + c] = scan[c]["mean"]
+# the window-stage scan kernels (launched once per pass by --stage-kernels, on the same 100-Mbp record): per base, so
+# that bench.py can scale them to the chromosome-sized record of its configs[2] leg
+bases = bench["config"]["bases_per_gpu"]
+for key, needle in (("scan_window_kernel", "scan_window_kernel<1>"), ("scan_anchored_kernel", "scan_anchored_kernel")):
+    k = [name for name in pmc if needle in name]
+    if not k or "FETCH_SIZE" not in pmc[k[0]] or "WRITE_SIZE" not in pmc[k[0]]:
+        continue
+    m = pmc[k[0]]
+    rd, wr = m["FETCH_SIZE"]["mean_kb"] * 1024 * factor, m["WRITE_SIZE"]["mean_kb"] * 1024
+    out[key + "_hbm_read_bytes_per_base"] = rd / bases
+    out[key + "_hbm_write_bytes_per_base"] = wr / bases
+    out[key + "_hbm_bytes_per_base"] = (rd + wr) / bases
+    out[key + "_algorithmic_bytes_per_base"] = 0.375
+    for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "VALUBusy", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
+        if c in m:
+            out[key + "_" + c + ("" if c == "VALUBusy" else "_per_base")] = m[c]["mean"] / (1 if c == "VALUBusy" else bases)
 with open(os.path.join(dst, "traffic.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out, indent=1))
