@@ -6,8 +6,11 @@
 // tie-breaks, and those depend on the striped evaluation order: the lazy-F loop
 // stops early and never refreshes E, so scores are a function of the 16-/8-lane striping.  This
 // file therefore evaluates the recurrences in exactly the library's striped order -- vector j,
-// lane l  <->  query position j + l*segLen.  Written from the algorithm's description (host SSE2);
-// no library code is used.
+// lane l  <->  query position j + l*segLen -- and restates the library's banded path search with its
+// tie-breaks, band doubling and boundary handling (see banded_path).  The arithmetic is the library's by
+// necessity; the code is this repository's (host SSE2 passes, own cell encoding and walker for the path).
+// The library itself (MIT licence, Mengyao Zhao & Wan-Ping Lee) is not linked: oracle/_ref builds it from the
+// reference tree only to pin this file in the tests.
 // Pinned in tests/test_ssw.py against the reference library itself (oracle/_ref/libssw_ref.so).
 #include "ssw_exact.h"
 
@@ -216,63 +219,92 @@ Ends striped_pass_i16(const int8_t *ref, int dir, int ref_len, const int8_t *rea
 
 struct Op { char op; int len; };
 
-// Banded global-ish alignment with traceback between the located end points (ssw.c:590-775).  The band
-// doubles until the banded score reaches the striped score.  Returns false on a traceback error.
-bool banded_traceback(const int8_t *ref, const int8_t *read, int ref_len, int read_len, int score, int band, std::vector<Op> &out) {
-    const int len = std::max(ref_len, read_len);
-    std::vector<int32_t> h_b, e_b, h_c;
-    std::vector<int8_t> dir;
-    int best = 0, width = 0, width_d = 0;
-    auto col_u = [](int w, int i, int j) { const int x = std::max(i - w, 0); return j - x + 1; };
-    auto col_d = [](int w, int i, int j, int p) { const int x = std::max(i - w, 0); return (j - x) * 3 + p; };
-    do {
-        width = band * 2 + 3; width_d = band * 2 + 1;
-        h_b.assign((size_t)width + 1, 0); e_b.assign((size_t)width + 1, 0); h_c.assign((size_t)width + 1, 0);
-        dir.assign((size_t)width_d * read_len * 3 + 3, 0);
-        for (int i = 0; i < read_len; ++i) {
-            const int beg = std::max(0, i - band), end = std::min(ref_len - 1, i + band);
-            const int edge = std::min(end + 1, width - 1);
-            int f = 0, u = 0;
-            h_b[0] = e_b[0] = h_b[(size_t)edge] = e_b[(size_t)edge] = h_c[0] = 0;
-            int8_t *line = dir.data() + (size_t)width_d * i * 3;
-            for (int j = beg; j <= end; ++j) {
-                u = col_u(band, i, j);
-                const int e = col_u(band, i - 1, j), b = col_u(band, i, j - 1), d = col_u(band, i - 1, j - 1);
-                const int de = col_d(band, i, j, 0), df = col_d(band, i, j, 1), dh = col_d(band, i, j, 2);
-                int t1 = i == 0 ? -GAP_OPEN : h_b[(size_t)e] - GAP_OPEN;
-                int t2 = i == 0 ? -GAP_EXTEND : e_b[(size_t)e] - GAP_EXTEND;
-                e_b[(size_t)u] = std::max(t1, t2);
-                line[de] = t1 > t2 ? 3 : 2;
-                t1 = h_c[(size_t)b] - GAP_OPEN;
-                t2 = f - GAP_EXTEND;
-                f = std::max(t1, t2);
-                line[df] = t1 > t2 ? 5 : 4;
-                const int e1 = std::max(e_b[(size_t)u], 0), f1 = std::max(f, 0);
-                t1 = std::max(e1, f1);
-                t2 = h_b[(size_t)d] + score_of(ref[j], read[i]);
-                h_c[(size_t)u] = std::max(t1, t2);
-                best = std::max(best, h_c[(size_t)u]);
-                line[dh] = t1 <= t2 ? 1 : (e1 > f1 ? line[de] : line[df]);
-            }
-            for (int j = 1; j <= u; ++j) h_b[(size_t)j] = h_c[(size_t)j];
-        }
-        band *= 2;
-    } while (best < score && band <= len);
-    band /= 2;
+// ---- the path between the located end points ----------------------------------------------------------------
+// The library finds it with a banded dynamic programme over the rectangle between the end points (banded_sw,
+// ssw.c:590-775), rows = query positions, columns = reference positions, |column - row| <= band, three states per
+// cell (H: best score ending here; E: ... in a gap that consumes query = 'I'; F: ... in a gap that consumes
+// reference = 'D').  The CIGAR in the BED row is that path, so everything that decides it is the library's and is
+// kept as it is there: the recurrences and their tie-breaks (E/F open only when strictly better than extending; H
+// takes the diagonal on a tie, E before F only when strictly larger), the band that starts at |ref_len -
+// read_len| + 1 and doubles until the banded score reaches the striped score, the zero-valued out-of-band
+// neighbours -- including the library's habit of clearing slot `edge` of the previous row, which for the first
+// rows of a band that reaches past the reference is a live cell -- and the way the walk closes the path at
+// column 0.  What is this file's own: one byte per cell instead of three direction codes (bits 0-1: H came from
+// the diagonal / E / F; bit 2: E opened here; bit 3: F opened here), rows addressed relative to their first
+// in-band column, an explicit walker over (state, cell), and scratch that lives across calls.
+enum : uint8_t { FROM_DIAG = 0, FROM_E = 1, FROM_F = 2, SRC_MASK = 3, E_OPENS = 4, F_OPENS = 8, NO_CELL = 0xff };
 
-    std::vector<Op> rev;
-    int i = read_len - 1, j = ref_len - 1, count = 0, state = 2;
-    char op = 'M', prev = 'M';
-    const int8_t *line = dir.data() + (size_t)width_d * (read_len - 1) * 3;
-    while (i >= 0 && j > 0) {
-        switch (line[col_d(band, i, j, state)]) {
-            case 1: --i; --j; state = 2; line -= width_d * 3; op = 'M'; break;
-            case 2: --i; state = 0; line -= width_d * 3; op = 'I'; break;
-            case 3: --i; state = 2; line -= width_d * 3; op = 'I'; break;
-            case 4: --j; state = 1; op = 'D'; break;
-            case 5: --j; state = 2; op = 'D'; break;
-            default: return false;
+struct BandScratch {
+    std::vector<int32_t> h_above, e_above, h_row;     // slot u = column - first in-band column of the row + 1; slot 0 = out of band
+    std::vector<uint8_t> cell;                        // [row][column - first in-band column]
+};
+
+bool banded_path(const int8_t *ref, const int8_t *read, int ref_len, int read_len, int score, int band, std::vector<Op> &out) {
+    static thread_local BandScratch s;
+    const int longest = std::max(ref_len, read_len);
+    int best = 0, row_cells = 0;
+    for (;;) {
+        row_cells = 2 * band + 1;
+        const int slots = row_cells + 2;
+        s.h_above.assign((size_t)slots + 1, 0);
+        s.e_above.assign((size_t)slots + 1, 0);
+        s.h_row.assign((size_t)slots + 1, 0);
+        if (s.cell.size() < (size_t)row_cells * read_len) s.cell.resize((size_t)row_cells * read_len);
+        int32_t *h_above = s.h_above.data(), *e_above = s.e_above.data(), *h_row = s.h_row.data();
+        for (int i = 0; i < read_len; ++i) {
+            const int first = std::max(0, i - band), last = std::min(ref_len - 1, i + band);
+            const int first_above = std::max(0, i - 1 - band);
+            const int edge = std::min(last + 1, slots - 1);
+            h_above[0] = e_above[0] = h_above[edge] = e_above[edge] = h_row[0] = 0;
+            uint8_t *cells = s.cell.data() + (size_t)row_cells * i;
+            int f = 0, u = 0;
+            for (int j = first; j <= last; ++j) {
+                u = j - first + 1;
+                const int above = j - first_above + 1;            // same column, row above; above - 1: the diagonal
+                uint8_t code = 0;
+                // E: gap in the reference direction of the query ('I'), opened from H above or extended
+                const int e_open = i == 0 ? -GAP_OPEN : h_above[above] - GAP_OPEN;
+                const int e_ext = i == 0 ? -GAP_EXTEND : e_above[above] - GAP_EXTEND;
+                const int e = std::max(e_open, e_ext);
+                e_above[u] = e;
+                if (e_open > e_ext) code |= E_OPENS;
+                // F: gap that consumes reference ('D'), opened from H to the left or extended
+                const int f_open = h_row[u - 1] - GAP_OPEN, f_ext = f - GAP_EXTEND;
+                f = std::max(f_open, f_ext);
+                if (f_open > f_ext) code |= F_OPENS;
+                const int e0 = std::max(e, 0), f0 = std::max(f, 0);
+                const int gap = std::max(e0, f0);
+                const int diag = h_above[above - 1] + score_of(ref[j], read[i]);
+                const int h = std::max(gap, diag);
+                h_row[u] = h;
+                best = std::max(best, h);
+                code |= gap <= diag ? FROM_DIAG : (e0 > f0 ? FROM_E : FROM_F);
+                cells[j - first] = code;
+            }
+            for (int k = last - first + 1; k < row_cells; ++k) cells[k] = NO_CELL;      // columns past the reference
+            for (int k = 1; k <= u; ++k) h_above[k] = h_row[k];
         }
+        if (!(best < score && band * 2 <= longest)) break;
+        band *= 2;
+    }
+
+    // walk back from the end-point corner
+    enum State { IN_E, IN_F, IN_H };
+    const long n_cells = (long)row_cells * read_len;
+    std::vector<Op> rev;
+    int i = read_len - 1, j = ref_len - 1, count = 0;
+    State state = IN_H;
+    char op = 'M', prev = 'M';
+    while (i >= 0 && j > 0) {
+        // (a column outside the row's band addresses the neighbouring row's cell, as in the library's flat array)
+        const long at = (long)row_cells * i + (j - std::max(0, i - band));
+        if (at < 0 || at >= n_cells) return false;
+        const uint8_t code = s.cell[(size_t)at];
+        if (code == NO_CELL) return false;
+        const State via = state != IN_H ? state : (code & SRC_MASK) == FROM_DIAG ? IN_H : (code & SRC_MASK) == FROM_E ? IN_E : IN_F;
+        if (via == IN_H) { --i; --j; state = IN_H; op = 'M'; }
+        else if (via == IN_E) { --i; state = (code & E_OPENS) ? IN_H : IN_E; op = 'I'; }
+        else { --j; state = (code & F_OPENS) ? IN_H : IN_F; op = 'D'; }
         if (op == prev) ++count;
         else { rev.push_back({prev, count}); prev = op; count = 1; }
     }
@@ -328,7 +360,7 @@ void ssw_finish(const char *query, int query_len, const char *ref, int ref_len, 
     const bool too_far = out.ref_end - out.ref_begin > DISTANCE_FILTER || out.query_end - out.query_begin > DISTANCE_FILTER;
     if (!too_far) {
         const int rl = out.ref_end - out.ref_begin + 1, ql = out.query_end - out.query_begin + 1;
-        if (!banded_traceback(r.data() + out.ref_begin, q.data() + out.query_begin, rl, ql, out.score, std::abs(rl - ql) + 1, path)) {
+        if (!banded_path(r.data() + out.ref_begin, q.data() + out.query_begin, rl, ql, out.score, std::abs(rl - ql) + 1, path)) {
             out.flag = 1;
             path.clear();
         }
