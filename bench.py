@@ -354,26 +354,54 @@ def main():
     pos_offset = rank * args.bases - own_lo
     lo_hi = (own_lo, own_hi) if world > 1 else (0, (1 << 63) - 1)
 
-    # N > 1: every rank scans and pairs its chunk on its GPU; the run records (16 B each) are then gathered for the
-    # host-side merge on rank 0.  On one node every GPU copies its records down its own PCIe link into a page-locked
-    # segment all ranks map ("shm": N links in parallel, no second hop); otherwise gather-v over RCCL ("rccl").
-    exchange = args.exchange
-    if exchange == "auto":
-        exchange = "shm" if world > 1 and same_node() else "rccl"
-    ng = None
-    if world > 1 and exchange == "shm":
-        sc.load_record_device(d_ascii.data_ptr(), d_ascii.numel())
-        probe, _ = sc.scan_perfect_chunk(own_lo, own_hi, pos_offset)
-        cap = max(int(a[0]) for a in allgather_array(np.array([len(probe)], dtype=np.int64), xdev))
-        ng = open_node_gather(ribbit_amd.RUN_DT, 2 * cap + 4096, 2 * (M_HI - M_LO + 1), nslots=depth + 1)
-        if ng is None and rank == 0:
-            print("node-shared segment unavailable: gathering over RCCL instead", file=sys.stderr)
-        for addr, nbytes in (ng.my_cells() if ng is not None else []):
-            try:
-                sc.host_register(addr, nbytes)
-            except ribbit_amd.RibbitHipError as e:       # still correct, the copies are just staged by the runtime
-                print(f"rank {rank}: shared segment not page-locked ({e})", file=sys.stderr)
-                break
+    # N > 1: every rank scans and pairs its chunk on its GPU; the run records (16 B each: the candidate seed intervals)
+    # are then gathered for the host-side merge on rank 0.  Transports:
+    #   rccl  the records stay in HBM and travel GPU-to-GPU over xGMI (grouped send / recv through RCCL) to rank 0's
+    #         GPU, then down rank 0's PCIe link once (ribbit_amd.distributed.DeviceGather) -- what north_star names;
+    #         this is the headline;
+    #   shm   (one node) every GPU copies its records down its OWN PCIe link into a page-locked segment all ranks map:
+    #         N links in parallel, no second hop.  Timed as well and reported beside the headline.
+    transports = ["local"]
+    if world > 1:
+        first = "rccl" if args.exchange == "auto" else args.exchange
+        transports = [first] + (["shm"] if args.exchange == "auto" and same_node() else [])
+    device_gather = world > 1 and args.backend == "nccl"      # gloo rehearsals gather host arrays instead
+    T = {"name": transports[0], "ng": None, "dg": None}
+
+    def setup(name):
+        T["name"], T["ng"] = name, None
+        if name == "rccl" and device_gather and T["dg"] is None:
+            from ribbit_amd.distributed import DeviceGather
+            T["dg"] = DeviceGather(dev)
+        if name == "shm":
+            sc.load_record_device(d_ascii.data_ptr(), d_ascii.numel())
+            probe, _ = sc.scan_perfect_chunk(own_lo, own_hi, pos_offset)
+            cap = max(int(a[0]) for a in allgather_array(np.array([len(probe)], dtype=np.int64), xdev))
+            ng = open_node_gather(ribbit_amd.RUN_DT, 2 * cap + 4096, 2 * (M_HI - M_LO + 1), nslots=depth + 1)
+            if ng is None:
+                if rank == 0:
+                    print("node-shared segment unavailable: gathering over RCCL instead", file=sys.stderr)
+                T["name"] = "rccl"
+                return setup("rccl")
+            T["ng"] = ng
+            for addr, nbytes in ng.my_cells():
+                try:
+                    sc.host_register(addr, nbytes)
+                except ribbit_amd.RibbitHipError as e:       # still correct, the copies are just staged by the runtime
+                    print(f"rank {rank}: shared segment not page-locked ({e})", file=sys.stderr)
+                    break
+
+    def teardown():
+        ng = T["ng"]
+        if ng is not None:
+            dist.barrier()
+            for addr, _ in ng.my_cells():
+                try:
+                    sc.host_unregister(addr)
+                except ribbit_amd.RibbitHipError:
+                    pass
+            ng.close()
+            T["ng"] = None
 
     def issue(k):
         """enqueue batch k: pack + scan + pairing kernels on handle k % depth, no waiting"""
@@ -382,8 +410,11 @@ def main():
         h.scan_perfect_begin(lo_hi[0], lo_hi[1], pos_offset if world > 1 else 0)
 
     def collect(k):
-        """batch k's kernels are done: start copying its run records down (no waiting); -> what finish() needs"""
+        """batch k's kernels are done: start moving its run records (no waiting); -> what finish() needs"""
         h = scs[k % depth]
+        ng = T["ng"]
+        if world > 1 and T["name"] == "rccl" and device_gather:
+            return h.scan_perfect_end_device()            # nothing is copied: the records stay in HBM
         if world == 1 or ng is None:
             return h.scan_perfect_end(wait=False)
         if rank == 0 and k > 1:
@@ -396,6 +427,13 @@ def main():
     def finish(k, pending):
         """batch k's run records on the host (rank 0: of every rank)"""
         h = scs[k % depth]
+        ng = T["ng"]
+        if world > 1 and T["name"] == "rccl" and device_gather:
+            ptr, n, hptr, nh = pending
+            all_runs, all_halves = T["dg"].gather(ptr, n, hptr, nh, ribbit_amd.RUN_DT)
+            if rank == 0:
+                return all_runs + [ribbit_amd.join_run_halves(all_halves)]
+            return [np.zeros(n, ribbit_amd.RUN_DT)]       # (this rank's records went to rank 0; only their number is of use here)
         h.scan_perfect_wait()
         if world == 1:
             return pending[0]                             # view of the C ABI's own pinned result buffer
@@ -424,7 +462,7 @@ def main():
             issue(issued)
         for k in range(first, last + 1):
             pending = collect(k) if issued >= k else None
-            if issued < last:                             # next batch's kernels are enqueued while k's results cross PCIe
+            if issued < last:                             # next batch's kernels are enqueued while k's results travel
                 issued += 1
                 issue(issued)
             if pending is None:
@@ -435,36 +473,68 @@ def main():
         batch[0] = last
         return out
 
-    run_steps(args.warmup)
-
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    kernel_ms, pack_ms, gpu_ms, counts = [], [], [], [0, 0]
+    def timed_region(name):
+        """warm-up, then exactly args.steps timed steps of transport `name`: -> (seconds, max over ranks), last batch's runs, ..."""
+        setup(name)
+        batch[0] = 0
+        run_steps(args.warmup)
+        k_ms, p_ms, g_ms, cnt = [], [], [], [0, 0]
 
-    def on_step(h, out):
-        if h is timed_handle[0]:
-            kernel_ms.append(h.timing_ms(1))
-            pack_ms.append(h.timing_ms(0))
-            gpu_ms.append(h.timing_ms(2))
-        counts[0] = len(out) if world == 1 else sum(len(r) for r in out)
-        counts[1] = h.last_event_count()
+        def on_step(h, out):
+            if h is timed_handle[0]:
+                k_ms.append(h.timing_ms(1))
+                p_ms.append(h.timing_ms(0))
+                if not (world > 1 and T["name"] == "rccl" and device_gather):
+                    g_ms.append(h.timing_ms(2))
+            cnt[0] = len(out) if world == 1 else sum(len(r) for r in out)
+            cnt[1] = h.last_event_count()
 
-    timed_handle[0] = scs[(batch[0] + 1) % depth]        # the handle of the first timed batch, then of every depth-th
-    for h in scs:
-        h.set_timing(h is timed_handle[0])
-    fence()
-    t0 = time.perf_counter()
-    runs = run_steps(args.steps, on_step)
-    fence()
-    dt = time.perf_counter() - t0
+        timed_handle[0] = scs[(batch[0] + 1) % depth]    # the handle of the first timed batch, then of every depth-th
+        for h in scs:
+            h.set_timing(h is timed_handle[0])
+        fence()
+        t0 = time.perf_counter()
+        last_runs = run_steps(args.steps, on_step)
+        fence()
+        seconds = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([seconds], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            seconds = float(t.item())
+        used = T["name"]
+        return seconds, last_runs, k_ms, p_ms, g_ms, cnt, used
+
+    # The RCCL path cannot be rehearsed on the one-GPU development box (RCCL refuses two ranks on one device), so it is
+    # probed first: one step, and a vote over a gloo side channel.  If any rank failed, every rank falls back to the
+    # node-shared segment and the line says so.
+    rccl_error = None
+    if world > 1 and transports[0] == "rccl" and device_gather:
+        ctl = dist.new_group(backend="gloo")
+        ok = 1
+        try:
+            setup("rccl")
+            batch[0] = 0
+            run_steps(1)
+            torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001 -- whatever the collective layer raises
+            ok, rccl_error = 0, f"{type(e).__name__}: {e}"[:300]
+        votes = [None] * world
+        dist.all_gather_object(votes, (ok, rccl_error), group=ctl)
+        if not all(v[0] for v in votes):
+            rccl_error = next(v[1] for v in votes if not v[0])
+            if rank == 0:
+                print(f"RCCL gather of the device-resident records failed ({rccl_error}); using the node-shared segment", file=sys.stderr)
+            transports = ["shm"]
+            device_gather = False
+    dt, runs, kernel_ms, pack_ms, gpu_ms, counts, used_transport = timed_region(transports[0])
     nruns, nevents = counts
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    headline_ng = T["ng"] is not None
+    other = {}
 
     if args.calibrate:
         sc.debug_stream_read(256 << 20)
@@ -478,6 +548,11 @@ def main():
             want = sc.scan_perfect_runs()
             assert np.array_equal(got.view("<i4"), want.view("<i4")), "chunk-sharded runs differ from the single-GPU scan"
             print(f"verify: {len(want)} runs identical to the single-GPU scan of the whole record", file=sys.stderr)
+
+    for name in transports[1:]:
+        teardown()
+        sec, _r, _k, _p, _g, _c, used = timed_region(name)
+        other[used] = {"ms_per_step": sec / args.steps * 1e3, "value": args.bases * world * args.steps / sec / 1e9, "unit": "Gbases/s"}
 
     if rank == 0:
         traffic = n_valu = None
@@ -502,7 +577,8 @@ def main():
                        "kernel_timing": f"HIP events on every {depth}th launch of the timed region" if depth > 1 else "HIP events on every launch",
                        "bases_per_gpu": args.bases, "min_motif": M_LO, "max_motif": M_HI,
                        "parallelism": (f"one record chunk-sharded x{world} (halos), runs paired on each GPU, gathered for rank 0's host merge "
-                                       + ("through page-locked node-shared memory (one PCIe link per GPU)" if ng is not None else "by gather-v over RCCL"))
+                                       + ("through page-locked node-shared memory (one PCIe link per GPU)" if headline_ng else
+                                          ("by gather-v of the device-resident records over RCCL / xGMI (grouped send/recv)" if device_gather else "by gather-v over the collective backend")))
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "scan_perfect_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -511,8 +587,13 @@ def main():
                          "kernel_gbases_per_s": args.bases / (kavg * 1e-3) / 1e9,
                          "note": "integer-VALU bound by design (SURVEY.md 8d); HBM fraction reported as required"},
             "runs_per_step": nruns, "device_events_per_step": nevents,
-            "gpu_side_ms_per_step": float(np.mean(gpu_ms)),   # scan + pairing kernels + D2H of the runs (HIP events)
+            "gpu_side_ms_per_step": float(np.mean(gpu_ms)) if gpu_ms else None,   # scan + pairing kernels + D2H of the runs (HIP events)
         }
+        if world > 1:
+            out["exchange"] = {"headline": used_transport, used_transport: {"ms_per_step": dt / args.steps * 1e3, "value": total_bases / dt / 1e9, "unit": "Gbases/s"}}
+            out["exchange"].update(other)
+            if rccl_error:
+                out["exchange"]["rccl_error"] = rccl_error
         if n_valu:
             # the honest limiter: wave-instructions per launch from the committed SQ_INSTS_VALU pass,
             # ALIGNBIT_SHARE of them v_alignbit (ISA of the hot loop), against the issue rates measured on this part by
@@ -542,15 +623,8 @@ def main():
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
 
-    if ng is not None:
-        dist.barrier()
-        for addr, _ in ng.my_cells():
-            try:
-                sc.host_unregister(addr)
-            except ribbit_amd.RibbitHipError:
-                pass
-        runs = None
-        ng.close()
+    runs = None
+    teardown()
     for h in scs:
         h.close()
     if world > 1:

@@ -400,6 +400,11 @@ int ribbit_hip_scan_perfect_begin(RibbitHandle *h, int64_t own_lo, int64_t own_h
 int ribbit_hip_scan_perfect_end(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *half_dst, size_t half_dst_cap,
                                 int wait, const RibbitRun **out, size_t *n, const RibbitRun **halves, size_t *n_halves);
 int ribbit_hip_scan_perfect_wait(RibbitHandle *h);
+/* _end without the copy to the host: the records stay where the pairing kernels wrote them.  *dev_runs / *dev_halves
+ * are DEVICE pointers to *n / *n_halves RibbitRun records (complete: the call has waited for the kernels), valid until
+ * the next scan on this handle.  For callers that move them on over RCCL / xGMI (the chunks' candidate seed intervals
+ * of a chunk-sharded record, gathered to the rank that runs the host merge) instead of through host memory. */
+int ribbit_hip_scan_perfect_end_device(RibbitHandle *h, const void **dev_runs, size_t *n, const void **dev_halves, size_t *n_halves);
 
 /* Test hook: run the device-side pairing on a caller-made event stream of a record of `length` bases,
  * as if one scan had left it in one region.  *flags = 0 for a well-formed stream, otherwise the PAIR_* bits of

@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_stage_events", "ribbit_hip_xa_words", "ribbit_host_scan_from_events",
     "ribbit_host_perfect_runs_from_events", "ribbit_runs_free", "ribbit_hip_perfect_runs_partial",
     "ribbit_hip_scan_perfect_chunk", "ribbit_hip_host_register", "ribbit_hip_host_unregister",
-    "ribbit_hip_set_host_threads", "ribbit_hip_ssw_passes", "ribbit_hip_set_timing", "ribbit_hip_debug_set_event_capacity", "ribbit_hip_debug_pair_events", "ribbit_hip_scan_perfect_begin", "ribbit_hip_scan_perfect_end", "ribbit_hip_scan_perfect_wait",
+    "ribbit_hip_set_host_threads", "ribbit_hip_ssw_passes", "ribbit_hip_set_timing", "ribbit_hip_debug_set_event_capacity", "ribbit_hip_debug_pair_events", "ribbit_hip_scan_perfect_begin", "ribbit_hip_scan_perfect_end", "ribbit_hip_scan_perfect_wait", "ribbit_hip_scan_perfect_end_device",
 ]
 
 
@@ -171,6 +171,7 @@ def load_library():
     L.ribbit_hip_scan_perfect_end.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int,
                                               C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.ribbit_hip_scan_perfect_wait.argtypes = [vp]
+    L.ribbit_hip_scan_perfect_end_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.ribbit_host_scan_from_events.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t,
                                                vp, vp, vp, vp, vp, vp, C.POINTER(SeedLists)]
     L.ribbit_host_perfect_runs_from_events.argtypes = [C.POINTER(ScanParams), C.c_size_t, vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -660,6 +661,14 @@ class Scanner:
     def scan_perfect_begin(self, own_lo: int = 0, own_hi: int = (1 << 63) - 1, pos_offset: int = 0) -> None:
         """Enqueue the perfect scan of the loaded record (or of one chunk of it) and return without waiting."""
         self._check(self._L.ribbit_hip_scan_perfect_begin(self._h, own_lo, own_hi, pos_offset))
+
+    def scan_perfect_end_device(self):
+        """Finish the scan begun by scan_perfect_begin WITHOUT copying anything to the host:
+        -> (device pointer of the run records, their number, device pointer of the half records, their number).
+        The memory is the handle's and stays valid until its next scan (ribbit_hip_scan_perfect_end_device)."""
+        p, n, hp, nh = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        self._check(self._L.ribbit_hip_scan_perfect_end_device(self._h, C.byref(p), C.byref(n), C.byref(hp), C.byref(nh)))
+        return p.value or 0, n.value, hp.value or 0, nh.value
 
     def scan_perfect_wait(self) -> None:
         self._check(self._L.ribbit_hip_scan_perfect_wait(self._h))

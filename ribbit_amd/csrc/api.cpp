@@ -454,7 +454,9 @@ int perfect_begin(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_o
     return RIBBIT_OK;
 }
 
-int perfect_finish(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *half_dst, size_t half_dst_cap, bool wait = true) {
+// the scan in flight is complete on the device: counts known, overflow handled (the scan is run again with more room),
+// pairing checked.  The run records are in d_dense, the cut ones in d_halves.
+int perfect_collect(RibbitHandle *h) {
     if (!h->pair_pending) return fail(RIBBIT_E_STATE, "no perfect scan in flight on this handle");
     h->pair_pending = false;
     int rc;
@@ -488,6 +490,13 @@ int perfect_finish(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *h
     h->n_runs = h->h_pub.p[rb::EV_SHARDS + rb::PAIR_TOTAL];
     if (h->n_runs * 2 != produced) return fail(RIBBIT_E_INTERNAL, "%llu events but %zu runs", (unsigned long long)produced, h->n_runs);
     h->n_halves = h->h_pub.p[rb::EV_SHARDS + rb::PAIR_HALVES];
+    return RIBBIT_OK;
+}
+
+int perfect_finish(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *half_dst, size_t half_dst_cap, bool wait = true) {
+    int rc = perfect_collect(h);
+    if (rc) return rc;
+    const rb::PairLaunch &pr = h->pair;
     if (half_dst && h->n_halves > half_dst_cap) return fail(RIBBIT_E_OVERFLOW, "%zu half records do not fit the caller's buffer of %zu", h->n_halves, half_dst_cap);
     if (!half_dst) half_dst = h->h_halves.p;
     if (h->n_halves)
@@ -1550,6 +1559,20 @@ int ribbit_hip_scan_perfect_begin(RibbitHandle *h, int64_t own_lo, int64_t own_h
     if (!h) return fail(RIBBIT_E_ARG, "null argument");
     if (own_lo < 0 || own_hi < own_lo) return fail(RIBBIT_E_ARG, "bad own range");
     return perfect_begin(h, own_lo, own_hi, pos_offset);
+}
+
+int ribbit_hip_scan_perfect_end_device(RibbitHandle *h, const void **dev_runs, size_t *n, const void **dev_halves, size_t *n_halves) {
+    if (!h || !dev_runs || !n || !dev_halves || !n_halves) return fail(RIBBIT_E_ARG, "null argument");
+    int rc = perfect_collect(h);
+    if (rc) return rc;
+    h->runs_valid = false;
+    h->have_timing[1] = h->timing;
+    h->have_timing[2] = false;
+    *dev_runs = h->d_dense.p;
+    *n = h->n_runs;
+    *dev_halves = h->d_halves.p;
+    *n_halves = h->n_halves;
+    return RIBBIT_OK;
 }
 
 int ribbit_hip_scan_perfect_wait(RibbitHandle *h) {

@@ -1,9 +1,11 @@
-"""Exchange step of the multi-GPU path: an all-gather-v of sparse 16-byte records (runs, calls or
-seeds) across ranks -- one process per GPU, torch.distributed with backend "nccl" (= RCCL over xGMI on
-ROCm) on GPUs or "gloo" in the CPU tests.  The scan itself shards by record with no collective; this is
-the only communication on the path (BASELINE.json north_star: "RCCL all-gatherv of candidate seed
-intervals before host-side merge").  Payloads are KB-MB, i.e. latency-bound: one count all-gather plus
-one padded all-gather, nothing ring-shaped to tune."""
+"""Exchange step of the multi-GPU path: a gather-v of sparse 16-byte records (runs, calls or seeds) across
+ranks -- one process per GPU, torch.distributed with backend "nccl" (= RCCL over xGMI on ROCm) on GPUs or "gloo" in the
+CPU tests.  The scan itself shards by record with no collective; this is the only communication on the path
+(BASELINE.json north_star: "RCCL all-gatherv of candidate seed intervals before host-side merge").  The records start
+in HBM (the pairing kernels write them there) and DeviceGather moves them GPU-to-GPU: grouped send / recv to the rank
+that runs the host merge, nothing staged through numpy.  Payloads are KB-MB, i.e. latency-bound: one small count
+all-gather plus one message per rank, nothing ring-shaped to tune.  The host-array helpers below serve the CPU tests
+(gloo) and the one-off exchanges outside the timed path (halos, verification)."""
 from __future__ import annotations
 
 import numpy as np
@@ -73,6 +75,85 @@ def gather_array(arr: np.ndarray, device: torch.device | None = None, dst: int =
     if rank != dst:
         return None
     return [gathered[r][:counts[r]].cpu().numpy().view(arr.dtype).copy() for r in range(world)]
+
+
+class _DeviceView:
+    """zero-copy view of `nbytes` of device memory for torch.as_tensor (the CUDA array interface, which ROCm builds of
+    torch read the same way)"""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def device_bytes(ptr: int, nbytes: int, device: torch.device) -> torch.Tensor:
+    """uint8 tensor aliasing device memory the C ABI owns (no copy)"""
+    if nbytes == 0 or not ptr:
+        return torch.empty(0, dtype=torch.uint8, device=device)
+    return torch.as_tensor(_DeviceView(ptr, nbytes), device=device)
+
+
+class DeviceGather:
+    """gather-v of device-resident 16-byte records to rank `dst` over RCCL: the candidate seed intervals every rank's
+    pairing kernels left in HBM travel GPU-to-GPU over xGMI (grouped send / recv, one message per rank, no padding) into
+    one buffer on dst's GPU and come down dst's PCIe link once, into page-locked memory, for the host merge.  Only
+    counts cross in a collective of their own (one small all-gather).  Buffers are reused from step to step."""
+
+    def __init__(self, device: torch.device, dst: int = 0):
+        self.dev, self.dst = device, dst
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.counts = torch.zeros(2, dtype=torch.int64, device=device)
+        self.recv = torch.empty(0, dtype=torch.uint8, device=device)
+        self.host = torch.empty(0, dtype=torch.uint8).pin_memory() if device.type == "cuda" else torch.empty(0, dtype=torch.uint8)
+
+    def _room(self, nbytes: int):
+        if self.recv.numel() < nbytes:
+            self.recv = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.dev)
+        if self.host.numel() < nbytes:
+            self.host = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8)
+            if self.dev.type == "cuda":
+                self.host = self.host.pin_memory()
+
+    def gather(self, runs, n_runs: int, halves, n_halves: int, dtype):
+        """runs / halves: device pointers (int) of n_runs / n_halves 16-byte records, or uint8 tensors on self.dev holding
+        them.  -> on dst: ([runs of rank 0, runs of rank 1, ...], [halves ...]) as numpy views of page-locked memory that
+        stay valid until the next call; elsewhere (None, None)"""
+        rec = 16
+        as_bytes = lambda x, n: x[:n * rec] if isinstance(x, torch.Tensor) else device_bytes(x, n * rec, self.dev)
+        self.counts[0], self.counts[1] = n_runs, n_halves
+        gathered = [torch.zeros_like(self.counts) for _ in range(self.world)]
+        dist.all_gather(gathered, self.counts)
+        counts = torch.stack(gathered).cpu().numpy()
+        # a copy torch owns (D2D, a few MB): the handle may reuse its buffer before an asynchronous send has read it
+        mine = torch.cat([as_bytes(runs, n_runs), as_bytes(halves, n_halves)])
+        if self.dev.type == "cuda":
+            torch.cuda.current_stream(self.dev).synchronize()
+        sizes = [(int(c[0]) + int(c[1])) * rec for c in counts]
+        if self.rank != self.dst:
+            if sizes[self.rank]:
+                dist.send(mine, self.dst)
+            return None, None
+        total = sum(sizes)
+        self._room(total)
+        offs = np.concatenate(([0], np.cumsum(sizes)))
+        ops = []
+        for r in range(self.world):
+            if r == self.dst or sizes[r] == 0:
+                continue
+            ops.append(dist.P2POp(dist.irecv, self.recv[int(offs[r]):int(offs[r + 1])], r))
+        if sizes[self.dst]:
+            self.recv[int(offs[self.dst]):int(offs[self.dst + 1])].copy_(mine)
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        self.host[:total].copy_(self.recv[:total], non_blocking=True)
+        if self.dev.type == "cuda":
+            torch.cuda.current_stream(self.dev).synchronize()
+        flat = self.host[:total].numpy()
+        out_runs, out_halves = [], []
+        for r in range(self.world):
+            a, nr, nh = int(offs[r]), int(counts[r][0]) * rec, int(counts[r][1]) * rec
+            out_runs.append(flat[a:a + nr].view(dtype))
+            out_halves.append(flat[a + nr:a + nr + nh].view(dtype))
+        return out_runs, out_halves
 
 
 def same_node() -> bool:

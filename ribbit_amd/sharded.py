@@ -1,9 +1,9 @@
 """Chunk-sharded scan of ONE long record over several GPUs (BASELINE.json north_star; SURVEY.md 8e
 option 2).  Every rank loads its chunk plus halos as a record of its own, runs the three scan kernels,
-keeps the events it owns, and the ranks exchange events, packed planes and composed planes with an
-all-gather-v over RCCL (torch.distributed "nccl"; "gloo" in the CPU tests).  The order-dependent host
-replay (pairing, window state machines, seed merges) then runs once on the gathered data, exactly as
-for a single GPU.  Correctness does not depend on the partition: events are local functions of the
+keeps the events it owns, and the ranks send events, packed planes and composed planes to the ONE rank that
+runs the host merge (gather-v over RCCL: torch.distributed "nccl"; "gloo" in the CPU tests) -- nothing is
+replicated on the other ranks.  The order-dependent host replay (pairing, window state machines, seed
+merges) then runs once on the gathered data, exactly as for a single GPU.  Correctness does not depend on the partition: events are local functions of the
 sequence, and the halos cover their reach (include/ribbit_hip.h, "chunk-sharded operation")."""
 from __future__ import annotations
 
@@ -64,11 +64,12 @@ def merge_parts(min_motif: int, max_motif: int, length: int, parts: list) -> dic
                                             np.ascontiguousarray(xa) if anchored else None, stride, parts)
 
 
-def allgather_parts(part: dict, device=None) -> list:
-    """all-gather-v of every array of `part` across ranks (torch.distributed must be initialised)."""
+def gather_parts(part: dict, device=None, dst: int = 0):
+    """gather-v of every array of `part` to rank `dst` (torch.distributed must be initialised): the list of all ranks'
+    parts on dst, None elsewhere.  The composed planes are 12.4 B/base at 99 motif sizes: only dst receives them."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     dev = device if device is not None else torch.device("cpu")
     keys = ["ev0", "cnt0", "ev1", "cnt1", "ev2", "cnt2", "hi", "lo", "brk", "xa"]
     meta = torch.tensor([part["own_lo"], part["own_hi"]] +
@@ -89,11 +90,15 @@ def allgather_parts(part: dict, device=None) -> list:
         mine = part[k]
         if mine.size:
             buf[:mine.size * mine.itemsize] = torch.from_numpy(np.ascontiguousarray(mine).view(np.uint8).reshape(-1)).to(dev)
-        gathered = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(gathered, buf)
+        gathered = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, gathered, dst=dst)
+        if rank != dst:
+            continue
         for r in range(world):
             raw = gathered[r][:sizes[r]].cpu().numpy()
             out[r][k] = raw.view(dtypes.get(k, "<u8")).copy()
+    if rank != dst:
+        return None
     nm = len(out[0]["cnt0"])
     for o in out:
         if o["xa"] is not None:

@@ -73,3 +73,51 @@ def test_shard_records_balances_longest_first():
     assert sorted(sum(bins, [])) == [0, 1, 2, 3, 4]
     loads = [sum([10, 50, 20, 40, 30][i] for i in b) for b in bins]
     assert abs(loads[0] - loads[1]) <= 10
+
+
+def _gather_worker(rank, world, port, out_dir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import torch
+    import torch.distributed as dist
+
+    import ribbit_amd
+    from ribbit_amd.distributed import DeviceGather
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dg = DeviceGather(torch.device("cpu"))
+    ok = True
+    for step in range(4):                            # buffers are reused and must grow
+        rs = np.random.RandomState(100 * step + rank)
+        n, nh = int(rs.randint(0, 5000 * (step + 1))) if not (step == 1 and rank == 1) else 0, int(rs.randint(0, 40))
+        runs = np.zeros(n, ribbit_amd.RUN_DT)
+        runs["start"] = rs.randint(0, 1 << 30, n); runs["end"] = runs["start"] + 5; runs["mlen"] = rank; runs["term"] = step
+        halves = np.zeros(nh, ribbit_amd.RUN_DT)
+        halves["start"] = rs.randint(0, 1 << 30, nh); halves["mlen"] = rank; halves["term"] = 3
+        tr = torch.from_numpy(runs.view(np.uint8).reshape(-1).copy())
+        th = torch.from_numpy(halves.view(np.uint8).reshape(-1).copy())
+        got_runs, got_halves = dg.gather(tr, n, th, nh, ribbit_amd.RUN_DT)
+        if rank == 0:
+            for r in range(world):
+                rs2 = np.random.RandomState(100 * step + r)
+                n2 = int(rs2.randint(0, 5000 * (step + 1))) if not (step == 1 and r == 1) else 0
+                nh2 = int(rs2.randint(0, 40))
+                want_start = rs2.randint(0, 1 << 30, n2)
+                want_hstart = rs2.randint(0, 1 << 30, nh2)
+                ok &= len(got_runs[r]) == n2 and len(got_halves[r]) == nh2
+                ok &= bool(np.array_equal(got_runs[r]["start"], want_start) and np.all(got_runs[r]["mlen"] == r) and np.all(got_runs[r]["term"] == step))
+                ok &= bool(np.array_equal(got_halves[r]["start"], want_hstart) and np.all(got_halves[r]["term"] == 3))
+        else:
+            ok &= got_runs is None and got_halves is None
+    with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
+        f.write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_device_gather_delivers_every_ranks_records_to_rank0(tmp_path):
+    """DeviceGather (the RCCL path of the N > 1 bench: count all-gather + one message per rank into one buffer on rank 0)
+    with CPU tensors over gloo, world size 3: variable sizes incl. an empty rank, buffers that grow between steps."""
+    port = _free_port()
+    mp.spawn(_gather_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert all(open(tmp_path / f"ok{r}").read() == "1" for r in range(3))

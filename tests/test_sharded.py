@@ -68,17 +68,19 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     name, seq, m_lo, m_hi = simulated_cases()[2]
     parts, want = _oracle_parts(seq, m_lo, m_hi, world)      # every rank could scan only its own chunk; here they are precomputed
-    gathered = sharded.allgather_parts(parts[rank])
-    got = sharded.merge_parts(m_lo, m_hi, len(seq), gathered)
-    _same(got, want)
-    np.save(os.path.join(out_dir, f"dispatch{rank}.npy"), got["dispatch"])
+    gathered = sharded.gather_parts(parts[rank])            # only rank 0 receives (and merges)
+    assert (gathered is None) == (rank != 0)
+    if rank == 0:
+        got = sharded.merge_parts(m_lo, m_hi, len(seq), gathered)
+        _same(got, want)
+        np.save(os.path.join(out_dir, "dispatch0.npy"), got["dispatch"])
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_chunk_sharded_exchange_world2(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    assert np.array_equal(np.load(tmp_path / "dispatch0.npy"), np.load(tmp_path / "dispatch1.npy"))
+    assert len(np.load(tmp_path / "dispatch0.npy")) > 0
 
 
 def test_pair_halves_pairs_by_motif_and_position_and_rejects_garbage():

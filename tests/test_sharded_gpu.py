@@ -104,3 +104,23 @@ def test_chunk_records_land_in_a_page_locked_node_shared_segment():
         finally:
             parts = halves = rec = hv = None
             ng.close()
+
+
+def test_run_records_can_be_taken_from_device_memory_without_a_host_copy():
+    """ribbit_hip_scan_perfect_end_device: the run records where the pairing kernels left them, viewed as a torch tensor
+    (what the RCCL gather of the N > 1 bench sends GPU-to-GPU) equal the ones the ordinary end copies to the host."""
+    import torch
+    from ribbit_amd.distributed import device_bytes
+    name, seq, m_lo, m_hi = [c for c in simulated_cases() if c[0] == "sim_cfg2_120k"][0]
+    dev = torch.device("cuda", 0)
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc:
+        sc.load_record(seq)
+        want = sc.scan_perfect_runs()
+        sc.load_record(seq)
+        sc.scan_perfect_begin()
+        ptr, n, hptr, nh = sc.scan_perfect_end_device()
+        assert n == len(want) and nh == 0
+        got = device_bytes(ptr, n * 16, dev).cpu().numpy().view(ribbit_amd.RUN_DT)
+        assert np.array_equal(got.view("<i4"), want.view("<i4"))
+        # the handle is usable afterwards
+        assert np.array_equal(sc.scan_perfect_runs().view("<i4"), want.view("<i4"))
