@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -380,12 +381,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_PERFECT_
         // >= 15 an aligned byte, >= 31 an aligned halfword.  (On random DNA 96 % of the (tile, motif) pairs with
         // sp >= 15 have no such lane at all.)  sp = 6 (motif 6 only) has no such test and is scanned in place.
         if (sp >= 7) {
-            const uint32_t ones = sp >= 31 ? 0x00010001u : sp >= 15 ? 0x01010101u : 0x11111111u;
-            const uint32_t tops = sp >= 31 ? 0x80008000u : sp >= 15 ? 0x80808080u : 0x88888888u;
-            uint32_t hit = 0;
+            bool cand;
+            if (sp >= 31) {
+                // an aligned zero halfword somewhere in the window  <=>  the packed 16-bit minimum over the ten words has a
+                // zero half: nine v_pk_min_u16 and one zero-halfword test instead of ten of the latter
+                typedef unsigned short half2 __attribute__((ext_vector_type(2)));
+                auto pk_min = [](uint32_t a, uint32_t b) {
+                    const half2 m = __builtin_elementwise_min(__builtin_bit_cast(half2, a), __builtin_bit_cast(half2, b));
+                    return __builtin_bit_cast(uint32_t, m);
+                };
+                uint32_t lowest = Z[0];
 #pragma unroll
-            for (int j = 0; j < K + 2; j++) hit = bitop3<0xBA>(Z[j] - ones, Z[j], hit);      // ((Z - ones) & ~Z) | hit
-            const bool cand = (hit & tops) != 0;
+                for (int j = 1; j < K + 2; j++) lowest = pk_min(lowest, Z[j]);
+                cand = (((lowest - 0x00010001u) & ~lowest) & 0x80008000u) != 0;
+            } else {
+                const uint32_t ones = sp >= 15 ? 0x01010101u : 0x11111111u;
+                const uint32_t tops = sp >= 15 ? 0x80808080u : 0x88888888u;
+                uint32_t hit = 0;
+#pragma unroll
+                for (int j = 0; j < K + 2; j++) hit = bitop3<0xBA>(Z[j] - ones, Z[j], hit);      // ((Z - ones) & ~Z) | hit
+                cand = (hit & tops) != 0;
+            }
             const unsigned long long mask = __ballot(cand);
             if (mask == 0ull) continue;
             const int n = __popcll(mask);
@@ -664,16 +680,16 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
     uint32_t Hq[K + 3], Lq[K + 3];
     int cur_q = -1;
 
-    uint32_t AN[5][K + 2];   // anchor words of shifts s-4 .. s   (index j: word k = j-1)
-    uint32_t MM[3][K + 2];   // mismatch words of shifts s-2 .. s
+    // Ring over the last five shifts, slot = (s - s_first) mod 5: anchor words (index j: word k = j-1).  The shift loop
+    // is unrolled five-fold so that every slot index is a compile-time constant: the ring lives in registers and
+    // nothing is copied when the window of shifts moves on (a rotating ring cost 70 v_mov per shift).  The mismatch
+    // words of motif m = s - 2 are not kept across two shifts but recomputed when the motif is composed (4 ops per
+    // word against 30 registers).
+    uint32_t AN[5][K + 2];
 #pragma unroll
     for (int a = 0; a < 5; a++)
 #pragma unroll
         for (int j = 0; j < K + 2; j++) AN[a][j] = 0;
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int j = 0; j < K + 2; j++) MM[a][j] = 0;
 
     EventSink sink;
     sink.events = events;
@@ -684,7 +700,10 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
     int staged = 0;
 
     const int s_first = max(1, wm_lo - 2);
-    for (int s = s_first; s <= wm_hi + 2; ++s) {
+    const int s_last = wm_hi + 2;
+    auto step = [&](auto slot_c, int s) {
+        constexpr int R = decltype(slot_c)::value;             // ring slot of shift s; shift s - d lives in slot (R - d) mod 5
+        constexpr int R1 = (R + 4) % 5, R3 = (R + 2) % 5, R4 = (R + 1) % 5;
         const int q = s >> 5;
         const uint32_t r = (uint32_t)s & 31u;
         if (q != cur_q) {
@@ -692,21 +711,13 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
 #pragma unroll
             for (int j = 0; j < K + 3; j++) { Hq[j] = s_hi[lb + j + q]; Lq[j] = s_lo[lb + j + q]; }
         }
-        // rotate the rings: slot 4 / slot 2 receive shift s
-#pragma unroll
-        for (int j = 0; j < K + 2; j++) {
-            AN[0][j] = AN[1][j]; AN[1][j] = AN[2][j]; AN[2][j] = AN[3][j]; AN[3][j] = AN[4][j];
-            MM[0][j] = MM[1][j]; MM[1][j] = MM[2][j];
-        }
         uint32_t X[K];   // X'_s on the own words k = 0..K-1
 #pragma unroll
-        for (int j = 0; j < K + 2; j++) {
-            const uint32_t hs = funnel(Hq[j + 1], Hq[j], r);
-            const uint32_t ls = funnel(Lq[j + 1], Lq[j], r);
-            MM[2][j] = (H[j] ^ hs) | (Lo[j] ^ ls);
+        for (int k = 0; k < K; k++) {
+            const uint32_t hs = funnel(Hq[k + 2], Hq[k + 1], r);
+            const uint32_t ls = funnel(Lq[k + 2], Lq[k + 1], r);
+            X[k] = ~((H[k + 1] ^ hs) | (Lo[k + 1] ^ ls));
         }
-#pragma unroll
-        for (int k = 0; k < K; k++) X[k] = ~MM[2][k + 1];
         if (edge_wave) {
 #pragma unroll
             for (int k = 0; k < K; k++) {
@@ -740,14 +751,14 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
         // of lanes: after the loop the windows span >= hl lanes, which is as far as a length below 2s can reach
         int accL = span_trail, accR = span_lead, fullL = span_full ? 1 : 0, fullR = fullL;
         for (int d = 1; d < hl; d <<= 1) {          // wave-uniform; no iteration up to max_motif 110
-            int a = __shfl_up(accL, d), f = __shfl_up(fullL, d);
-            if (lane < d) { a = 0; f = 0; }
-            accL = min(accL + (fullL ? a : 0), RUN_SAT);
-            fullL &= f;
-            a = __shfl_down(accR, d); f = __shfl_down(fullR, d);
-            if (lane + d > 63) { a = 0; f = 0; }
-            accR = min(accR + (fullR ? a : 0), RUN_SAT);
-            fullR &= f;
+            int a2 = __shfl_up(accL, d), f2 = __shfl_up(fullL, d);
+            if (lane < d) { a2 = 0; f2 = 0; }
+            accL = min(accL + (fullL ? a2 : 0), RUN_SAT);
+            fullL &= f2;
+            a2 = __shfl_down(accR, d); f2 = __shfl_down(fullR, d);
+            if (lane + d > 63) { a2 = 0; f2 = 0; }
+            accR = min(accR + (fullR ? a2 : 0), RUN_SAT);
+            fullR &= f2;
         }
         int left_in = __shfl_up(accL, 1);
         int right_in = __shfl_down(accR, 1);
@@ -781,22 +792,48 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
             }
             if (lead1[k] > 0 && low_len >= 3 && low_len < two_s) keep |= mask_low;
             if (high_len >= 3 && high_len < two_s) keep |= mask_high;
-            AN[4][k + 1] = keep;
+            AN[R][k + 1] = keep;
         }
-        AN[4][0] = __shfl_up(AN[4][K], 1);          // left neighbour's last own word
-        AN[4][K + 1] = __shfl_down(AN[4][1], 1);    // right neighbour's first own word
+        AN[R][0] = __shfl_up(AN[R][K], 1);          // left neighbour's last own word
+        AN[R][K + 1] = __shfl_down(AN[R][1], 1);    // right neighbour's first own word
 
         const int m = s - 2;
-        if (m < wm_lo) continue;
+        if (m < wm_lo) return;
         // ---- composed mismatch of motif m:  ~XA_m = mismatch_m & ~(anchor_{m-2,m-1,m+1,m+2})
         uint32_t A1[K + 2], B1[K + 2], C1[K + 2];
+        {
+            // mismatch words of shift m (words k = -1 .. K): the shifted operands usually sit in the registers loaded for
+            // shift s = m + 2; only when m and s straddle a multiple of 32 they are read from LDS
+            const int qm = m >> 5;
+            const uint32_t rm = (uint32_t)m & 31u;
+            if (qm == cur_q) {
 #pragma unroll
-        for (int j = 0; j < K + 2; j++) A1[j] = MM[0][j] & ~(AN[0][j] | AN[1][j] | AN[3][j] | AN[4][j]);
+                for (int j = 0; j < K + 2; j++) {
+                    const uint32_t hs = funnel(Hq[j + 1], Hq[j], rm);
+                    const uint32_t ls = funnel(Lq[j + 1], Lq[j], rm);
+                    A1[j] = ((H[j] ^ hs) | (Lo[j] ^ ls)) & ~(AN[R4][j] | AN[R3][j] | AN[R1][j] | AN[R][j]);
+                }
+            } else {
+                uint32_t ph = s_hi[lb + qm], pl = s_lo[lb + qm];
+#pragma unroll
+                for (int j = 0; j < K + 2; j++) {
+                    const uint32_t nh = s_hi[lb + j + 1 + qm], nl = s_lo[lb + j + 1 + qm];
+                    A1[j] = ((H[j] ^ funnel(nh, ph, rm)) | (Lo[j] ^ funnel(nl, pl, rm))) & ~(AN[R4][j] | AN[R3][j] | AN[R1][j] | AN[R][j]);
+                    ph = nh; pl = nl;
+                }
+            }
+        }
         if (xa != nullptr && own_lane) {
             uint32_t *dst = xa + (int64_t)(m - pp.m_lo) * xa_stride + w_own0;
+            if (w_own0 + K <= xa_stride) {          // the lane's 8 words: two 16-byte stores, contiguous across lanes
+                static_assert(K == 8, "two uint4 stores cover a lane's words");
+                reinterpret_cast<uint4 *>(dst)[0] = make_uint4(~A1[1], ~A1[2], ~A1[3], ~A1[4]);
+                reinterpret_cast<uint4 *>(dst)[1] = make_uint4(~A1[5], ~A1[6], ~A1[7], ~A1[8]);
+            } else {
 #pragma unroll
-            for (int k = 0; k < K; k++)
-                if (w_own0 + k < xa_stride) dst[k] = ~A1[k + 1];
+                for (int k = 0; k < K; k++)
+                    if (w_own0 + k < xa_stride) dst[k] = ~A1[k + 1];
+            }
         }
 #pragma unroll
         for (int j = 0; j < K + 2; j++) {          // span 2
@@ -836,6 +873,13 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
                 return ((int64_t)pos + 7 >= length) ? (uint32_t)EV_END_EOS : (uint32_t)EV_END_N;
             });
         }
+    };
+    for (int s = s_first; s <= s_last; s += 5) {
+        step(std::integral_constant<int, 0>{}, s);
+        if (s + 1 <= s_last) step(std::integral_constant<int, 1>{}, s + 1);
+        if (s + 2 <= s_last) step(std::integral_constant<int, 2>{}, s + 2);
+        if (s + 3 <= s_last) step(std::integral_constant<int, 3>{}, s + 3);
+        if (s + 4 <= s_last) step(std::integral_constant<int, 4>{}, s + 4);
     }
     sink_flush(sink, stage, staged, lane);
 }
