@@ -257,6 +257,14 @@ typedef struct RibbitAlignment {
 int ribbit_ssw_align(const char *query, int32_t query_len, const char *ref, int32_t ref_len, int32_t mask_len,
                      RibbitAlignment *out, char *cigar, size_t cap);
 
+/* Whole alignments of n jobs on the loaded record with as much on the GPU as it takes (striped passes: ssw_kernels.hip; the
+ * banded path search of ssw.c:590-775: ssw_path.hip; the host writes the CIGAR text and aligns what the kernels leave alone):
+ * out[j] and the NUL-terminated CIGAR at cigars + cigar_off[j] are Aligner::Align's for jobs[j].  on_gpu[j] (may be NULL):
+ * 0 aligned on the host, 1 passes on the GPU, 2 passes and path on the GPU. */
+int ribbit_hip_ssw_align_jobs(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const char *motif_pool, size_t pool_len, int32_t mask_len,
+                              RibbitAlignment *out, char *cigars, size_t cap, int64_t *cigar_off, int32_t *on_gpu);
+
+
 /*
  * The rest of processSequence (fasta_utils.cpp:211-242): processSeedMotifWise (parse_smallmotif_seed.cpp:190-288)
  * / processSeed (parse_seed.cpp:318-464) for every dispatched seed -- motif discovery, alignment

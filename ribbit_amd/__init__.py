@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_stage_events", "ribbit_hip_xa_words", "ribbit_host_scan_from_events",
     "ribbit_host_perfect_runs_from_events", "ribbit_runs_free", "ribbit_hip_perfect_runs_partial",
     "ribbit_hip_scan_perfect_chunk", "ribbit_hip_host_register", "ribbit_hip_host_unregister",
-    "ribbit_hip_set_host_threads", "ribbit_hip_ssw_passes", "ribbit_hip_set_timing", "ribbit_hip_debug_set_event_capacity", "ribbit_hip_debug_pair_events", "ribbit_hip_scan_perfect_begin", "ribbit_hip_scan_perfect_end", "ribbit_hip_scan_perfect_wait", "ribbit_hip_scan_perfect_end_device",
+    "ribbit_hip_set_host_threads", "ribbit_hip_ssw_passes", "ribbit_hip_ssw_align_jobs", "ribbit_hip_set_timing", "ribbit_hip_debug_set_event_capacity", "ribbit_hip_debug_pair_events", "ribbit_hip_scan_perfect_begin", "ribbit_hip_scan_perfect_end", "ribbit_hip_scan_perfect_wait", "ribbit_hip_scan_perfect_end_device",
 ]
 
 
@@ -167,6 +167,7 @@ def load_library():
     L.ribbit_hip_debug_set_event_capacity.argtypes = [vp, C.c_size_t]
     L.ribbit_hip_debug_pair_events.argtypes = [vp, vp, C.c_size_t, i64, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]
     L.ribbit_hip_ssw_passes.argtypes = [vp, vp, C.c_size_t, C.c_char_p, C.c_size_t, i32, vp]
+    L.ribbit_hip_ssw_align_jobs.argtypes = [vp, vp, C.c_size_t, C.c_char_p, C.c_size_t, i32, vp, vp, C.c_size_t, vp, vp]
     L.ribbit_hip_scan_perfect_begin.argtypes = [vp, i64, i64, i64]
     L.ribbit_hip_scan_perfect_end.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int,
                                               C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -699,6 +700,23 @@ class Scanner:
         out = np.zeros(len(jobs), ENDS_DT)
         self._check(self._L.ribbit_hip_ssw_passes(self._h, jobs.ctypes.data, len(jobs), motif_pool, len(motif_pool), mask_len, out.ctypes.data))
         return out
+
+    def ssw_align_jobs(self, jobs: np.ndarray, motif_pool: bytes, mask_len: int = 15):
+        """ribbit_hip_ssw_align_jobs: whole alignments, passes and path search on the GPU where the kernels take them.
+        -> (list of (result dict, cigar string), on_gpu array: 0 host, 1 passes on the GPU, 2 passes and path)"""
+        jobs = np.ascontiguousarray(jobs, dtype=JOB_DT)
+        n = len(jobs)
+        out = (Alignment * max(n, 1))()
+        cap = int(16 * (jobs["query_length"].astype(np.int64) + jobs["ppr_length"]).sum()) + 64 * n + 64
+        buf = C.create_string_buffer(cap)
+        off = np.zeros(max(n, 1), dtype=np.int64)
+        on_gpu = np.zeros(max(n, 1), dtype=np.int32)
+        self._check(self._L.ribbit_hip_ssw_align_jobs(self._h, jobs.ctypes.data, n, motif_pool, len(motif_pool), mask_len, out, buf, cap,
+                                                      off.ctypes.data, on_gpu.ctypes.data))
+        res = []
+        for j in range(n):
+            res.append(({name: getattr(out[j], name) for name, _ in Alignment._fields_}, C.string_at(C.addressof(buf) + int(off[j])).decode()))
+        return res, on_gpu[:n]
 
     def host_register(self, address: int, nbytes: int) -> None:
         """Page-lock caller-owned host memory so that scan_perfect_chunk(out=...) DMAs straight into it."""

@@ -174,6 +174,12 @@ struct RibbitHandle {
     DevBuf<int32_t> d_slices;
     DevBuf<int32_t> d_ssw_jobs, d_ssw_order, d_ssw_out;   // batched striped passes (ssw_kernels.hip)
     DevBuf<uint8_t> d_ssw_pool;
+    DevBuf<int32_t> d_path_items, d_path_result;
+    DevBuf<uint64_t> d_path_cell_off, d_path_ops_off;
+    DevBuf<uint8_t> d_path_cells;
+    DevBuf<uint32_t> d_path_scratch, d_path_ops, d_path_count;
+    PinnedBuf<uint32_t> h_path_ops;
+    std::vector<rb::SswPath> ssw_paths;                    // per job of h->jobs: the path the GPU found (ops == null: none)
     std::vector<rb::SswEnds> ssw_ends;                     // per job of h->jobs; flag -1 = not computed on the GPU          // {job, first row} per 64-row slice of the long-motif seeds
     bool best_rows_valid = false;
     std::vector<int32_t> best_rows;       // per dispatch seed: mostFrequentLongerMotif's window start, or -1
@@ -1062,6 +1068,8 @@ int ribbit_hip_close(RibbitHandle *h) {
     h->d_ascii.release(); h->d_hi.release(); h->d_lo.release(); h->d_brk.release();
     h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release(); h->d_slices.release();
     h->d_ssw_jobs.release(); h->d_ssw_order.release(); h->d_ssw_out.release(); h->d_ssw_pool.release();
+    h->d_path_items.release(); h->d_path_result.release(); h->d_path_cell_off.release(); h->d_path_ops_off.release(); h->d_path_cells.release();
+    h->d_path_scratch.release(); h->d_path_ops.release(); h->d_path_count.release(); h->h_path_ops.release();
     h->h_events.release(); h->h_counters.release(); h->h_query.release();
     h->d_pair_table.release(); h->d_run_base.release(); h->d_pair_partial.release(); h->d_pair_status.release();
     h->h_pub.release(); h->h_runs.release(); h->h_halves.release(); h->d_halves.release();
@@ -1293,6 +1301,98 @@ static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n,
     return RIBBIT_OK;
 }
 
+// The banded path search of every job whose striped passes the GPU has done (run_ssw_passes left jobs, motif pool and end
+// points on the device): rounds of one launch each, the band doubling for the alignments still open (ssw.c:603-728).
+static int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const std::vector<rb::SswEnds> &ends, std::vector<rb::SswPath> &paths) {
+    paths.assign(n, rb::SswPath{});
+    if (n == 0) return RIBBIT_OK;
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    struct Open { int32_t job, band; };
+    std::vector<Open> open;
+    uint64_t worst_ops = 0;
+    auto dims = [&](size_t j, int &rl, int &ql) { rl = ends[j].ref_end - ends[j].ref_begin + 1; ql = ends[j].query_end - ends[j].query_begin + 1; };
+    for (size_t j = 0; j < n; ++j) {
+        const rb::SswEnds &e = ends[j];
+        if (e.flag == -1 || e.score == 0 || e.ref_end < 0 || e.ref_begin < 0 || e.query_begin < 0) continue;
+        int rl, ql;
+        dims(j, rl, ql);
+        if (rl - 1 > 32767 || ql - 1 > 32767 || rl <= 0 || ql <= 0) continue;      // the distance filter: no path is searched at all
+        const int band = std::abs(rl - ql) + 1;
+        if (band > rb::SSW_PATH_MAX_BAND) continue;                                 // left to the host
+        open.push_back({(int32_t)j, band});
+        worst_ops += (uint64_t)(rl + ql + 2);
+    }
+    if (open.empty()) return RIBBIT_OK;
+    const uint64_t path_cap = std::min<uint64_t>(worst_ops, 0xfffffff0u);
+    if ((rc = h->d_path_ops.ensure((size_t)path_cap))) return rc;
+    if ((rc = h->d_path_count.ensure(4))) return rc;
+    if ((rc = h->d_path_result.ensure(4 * n))) return rc;
+    HIP_TRY(hipMemsetAsync(h->d_path_count.p, 0, 4 * sizeof(uint32_t), h->stream));
+    std::vector<int32_t> items, result(4 * n, -1);
+    std::vector<uint64_t> cell_off, ops_off;
+    std::vector<Open> next;
+    constexpr uint64_t ARENA = (uint64_t)6 << 30;            // cell bytes per launch
+    while (!open.empty()) {
+        // one launch per arena-full of items
+        size_t at = 0;
+        next.clear();
+        while (at < open.size()) {
+            items.clear(); cell_off.clear(); ops_off.clear();
+            uint64_t cells = 0, ops = 0;
+            int max_band = 1;
+            size_t first = at;
+            for (; at < open.size(); ++at) {
+                int rl, ql;
+                dims((size_t)open[at].job, rl, ql);
+                const uint64_t need = (uint64_t)(2 * open[at].band + 1) * (uint64_t)ql;
+                if (cells + need > ARENA && at > first) break;
+                items.push_back(open[at].job); items.push_back(open[at].band); items.push_back(0); items.push_back(0);
+                cell_off.push_back(cells); ops_off.push_back(ops);
+                cells += need; ops += (uint64_t)(rl + ql + 2);
+                max_band = std::max(max_band, open[at].band);
+            }
+            const size_t ni = at - first;
+            if ((rc = h->d_path_items.ensure(items.size())) || (rc = h->d_path_cell_off.ensure(ni)) || (rc = h->d_path_ops_off.ensure(ni)) ||
+                (rc = h->d_path_cells.ensure((size_t)std::max<uint64_t>(cells, 16))) || (rc = h->d_path_scratch.ensure((size_t)ops)))
+                return rc;
+            HIP_TRY(hipMemcpyAsync(h->d_path_items.p, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->d_path_cell_off.p, cell_off.data(), ni * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->d_path_ops_off.p, ops_off.data(), ni * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+            rb::launch_ssw_paths(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_out.p, h->d_path_items.p, h->d_path_cell_off.p,
+                                 h->d_path_ops_off.p, (int)ni, max_band, h->d_path_cells.p, h->d_path_scratch.p, h->d_path_ops.p, (uint32_t)path_cap,
+                                 h->d_path_count.p, h->d_path_result.p, h->stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(h->stream));       // the item arrays above are reused by the next launch
+        }
+        HIP_TRY(hipMemcpyAsync(result.data(), h->d_path_result.p, 4 * n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (const Open &o : open) {
+            const int32_t *r = &result[4 * (size_t)o.job];
+            if (r[0] == 2) {
+                if (o.band * 2 <= rb::SSW_PATH_MAX_BAND) next.push_back({o.job, o.band * 2});
+            } else if (r[0] == 1) {
+                paths[(size_t)o.job].failed = true;
+            } else if (r[0] == 0) {
+                paths[(size_t)o.job].n_ops = r[3];
+            }
+        }
+        open.swap(next);
+    }
+    uint32_t used = 0;
+    HIP_TRY(hipMemcpyAsync(&used, h->d_path_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (used > path_cap) return fail(RIBBIT_E_INTERNAL, "path operations overflowed their arena");
+    if ((rc = h->h_path_ops.ensure(std::max<size_t>(used, 1)))) return rc;
+    if (used) {
+        HIP_TRY(hipMemcpyAsync(h->h_path_ops.p, h->d_path_ops.p, (size_t)used * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    for (size_t j = 0; j < n; ++j)
+        if (result[4 * j] == 0 && !paths[j].failed) paths[j].ops = h->h_path_ops.p + (uint32_t)result[4 * j + 2];
+    return RIBBIT_OK;
+}
+
 int ribbit_hip_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const char *motif_pool, size_t pool_len,
                           int32_t mask_len, RibbitSswEnds *out) {
     if (!h || (n && (!jobs || !out || !motif_pool))) return fail(RIBBIT_E_ARG, "null argument");
@@ -1305,6 +1405,53 @@ int ribbit_hip_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n,
     if (rc) return rc;
     static_assert(sizeof(RibbitSswEnds) == sizeof(rb::SswEnds), "ends record layout");
     if (n) std::memcpy(out, ends.data(), n * sizeof(RibbitSswEnds));
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_ssw_align_jobs(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const char *motif_pool, size_t pool_len, int32_t mask_len,
+                              RibbitAlignment *out, char *cigars, size_t cap, int64_t *cigar_off, int32_t *on_gpu) {
+    if (!h || (n && (!jobs || !out || !motif_pool || !cigars || !cigar_off))) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    for (size_t j = 0; j < n; ++j)
+        if (jobs[j].atomicity <= 0 || jobs[j].motif_offset < 0 || (size_t)jobs[j].motif_offset + (size_t)jobs[j].atomicity > pool_len)
+            return fail(RIBBIT_E_ARG, "job %zu: motif outside the pool", j);
+    std::vector<rb::SswEnds> ends;
+    std::vector<rb::SswPath> paths;
+    int rc = run_ssw_passes(h, jobs, n, motif_pool, pool_len, mask_len, ends);
+    if (rc) return rc;
+    if ((rc = run_ssw_paths(h, jobs, n, ends, paths))) return rc;
+    // the bases of the record for the host's share (CIGAR text; whole alignments the GPU left alone)
+    std::string bases((size_t)h->length, 'N');
+    if (h->length) {
+        HIP_TRY(hipMemcpyAsync(&bases[0], h->dev_ascii_src, (size_t)h->length, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    size_t at = 0;
+    for (size_t j = 0; j < n; ++j) {
+        int qs = jobs[j].query_start, ql = jobs[j].query_length;
+        if (qs < 0) { ql += qs; qs = 0; }
+        if ((int64_t)qs + ql > h->length) ql = (int)(h->length - qs);
+        std::string ref;
+        while ((long)ref.size() <= (long)jobs[j].ppr_length) ref.append(motif_pool + jobs[j].motif_offset, (size_t)jobs[j].atomicity);
+        rb::SswResult r;
+        const bool gpu_ends = ends[j].flag != -1 && ql > 0;
+        const bool gpu_path = gpu_ends && (paths[j].ops || paths[j].failed);
+        if (ql <= 0) { r = rb::SswResult{}; r.ref_begin = r.query_begin = -1; }
+        else if (gpu_path) rb::ssw_finish_with_path(bases.data() + qs, ql, ref.data(), jobs[j].ppr_length, ends[j], paths[j], r);
+        else if (gpu_ends) rb::ssw_finish(bases.data() + qs, ql, ref.data(), jobs[j].ppr_length, ends[j], r);
+        else rb::ssw_align(bases.data() + qs, ql, ref.data(), jobs[j].ppr_length, mask_len, r);
+        if (on_gpu) on_gpu[j] = gpu_path ? 2 : gpu_ends ? 1 : 0;
+        out[j].sw_score = r.score; out[j].sw_score_next_best = r.score2;
+        out[j].ref_begin = r.ref_begin; out[j].ref_end = r.ref_end;
+        out[j].query_begin = r.query_begin; out[j].query_end = r.query_end;
+        out[j].ref_end_next_best = r.ref_end2; out[j].mismatches = r.mismatches;
+        out[j].flag = r.flag;
+        out[j].cigar_len = (int32_t)r.cigar.size();
+        cigar_off[j] = (int64_t)at;
+        if (at + r.cigar.size() + 1 > cap) return fail(RIBBIT_E_OVERFLOW, "CIGAR buffer too small");
+        std::memcpy(cigars + at, r.cigar.c_str(), r.cigar.size() + 1);
+        at += r.cigar.size() + 1;
+    }
     return RIBBIT_OK;
 }
 
@@ -1415,13 +1562,16 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
         rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), h->jobs, h->motif_pool, threads);
         const double tp = now_ms();
         if ((rc = run_ssw_passes(h, h->jobs.data(), h->jobs.size(), h->motif_pool.data(), h->motif_pool.size(), 15, h->ssw_ends))) return rc;
-        if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs: set-up %.1f ms, GPU striped passes incl. transfers %.1f ms\n", h->jobs.size(), tp - tj, now_ms() - tp);
+        const double tq = now_ms();
+        if ((rc = run_ssw_paths(h, h->jobs.data(), h->jobs.size(), h->ssw_ends, h->ssw_paths))) return rc;
+        if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs: set-up %.1f ms, GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms\n",
+                                  h->jobs.size(), tp - tj, tq - tp, now_ms() - tq);
         jobs = &h->jobs;
     }
     t_jobs += now_ms() - t0;
     t0 = now_ms();
     rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sequence_id, h->bed,
-                      h->host_threads, jobs, jobs ? &h->ssw_ends : nullptr);
+                      h->host_threads, jobs, jobs ? &h->ssw_ends : nullptr, jobs ? &h->ssw_paths : nullptr);
     t_text += now_ms() - t0;
     if (profile) std::fprintf(stderr, "[refine_bed] cumulative: GPU scans of the seeds %.1f ms, alignment set-up + GPU striped passes %.1f ms, host refinement + BED %.1f ms\n", t_rows, t_jobs, t_text);
     *text = h->bed.c_str();

@@ -138,6 +138,18 @@ void launch_ssw_passes(const uint8_t *ascii, int64_t length, const uint8_t *moti
                        const int32_t *order_small, int n_small, const int32_t *order_big, int n_big, int mask_len,
                        int32_t *out, hipStream_t stream);
 
+// The banded path search (ssw.c:590-775) of n_items alignments whose end points are known, one wavefront each (ssw_path.hip).
+// items[4*t] = job index, items[4*t+1] = band of this round; cell_off[t] / ops_off[t]: where item t's cell bytes
+// ((2*band+1) * read_len) and scratch operations (ref_len + read_len + 2 entries) go; finished paths are appended to
+// path_ops (path_cap entries, *path_count their number so far); result[4*job..] = {state, band, first operation in
+// path_ops, operations}: state 0 path found, 1 walk failed, 2 band too narrow (run again with twice the band).
+// max_band: the largest band among the items (sizes the LDS).
+constexpr int SSW_PATH_MAX_BAND = 2048;
+void launch_ssw_paths(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs, const int32_t *ends,
+                      const int32_t *items, const uint64_t *cell_off, const uint64_t *ops_off, int n_items, int max_band,
+                      uint8_t *cells, uint32_t *ops, uint32_t *path_ops, uint32_t path_cap, uint32_t *path_count, int32_t *result,
+                      hipStream_t stream);
+
 // profiling aid: reads nwords dwords of src with one coalesced dword per lane (known byte count)
 void launch_calib_stream_read(const uint32_t *src, int64_t nwords, uint32_t *sink, hipStream_t stream);
 

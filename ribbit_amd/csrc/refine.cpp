@@ -306,7 +306,7 @@ namespace {
 
 // RIBBIT_PROFILE=1: wall-clock split of the refinement stages on stderr (summed over the worker threads)
 std::atomic<long long> g_t_align{0}, g_t_small{0}, g_t_long{0};       // nanoseconds
-std::atomic<long> g_n_align{0}, g_n_known{0};
+std::atomic<long> g_n_align{0}, g_n_known{0}, g_n_paths{0};
 struct Stopwatch {
     std::atomic<long long> *acc;
     std::chrono::steady_clock::time_point t0;
@@ -427,18 +427,22 @@ struct Writer {
     // order in which small_seed / long_seed reach them (build_align_jobs follows the same control flow)
     const RibbitAlignJob *jobs = nullptr;
     const SswEnds *ends = nullptr;
+    const SswPath *paths = nullptr;     // per job; ops == nullptr && !failed: path not found on the GPU, searched here
     size_t next_job = 0, last_job = 0;
     void begin_seed(size_t first, size_t last) { next_job = first; last_job = last; }
     // query_start < 0: not a first-level alignment (flank recursion), always aligned here
     std::string align(const std::string &query, const std::string &motif, int ppr_len, int query_start = -1) {
         const SswEnds *known = nullptr;
+        const SswPath *known_path = nullptr;
         if (query_start >= 0 && jobs && next_job < last_job) {
             const RibbitAlignJob &jb = jobs[next_job];
             const SswEnds &e = ends[next_job];
-            ++next_job;
             if (e.flag != -1 && jb.query_start == query_start && jb.ppr_length == ppr_len &&
-                (int)query.size() == std::min(jb.query_length, b.L - jb.query_start) && jb.atomicity == (int)motif.size())
+                (int)query.size() == std::min(jb.query_length, b.L - jb.query_start) && jb.atomicity == (int)motif.size()) {
                 known = &e;
+                if (paths && (paths[next_job].ops || paths[next_job].failed)) known_path = &paths[next_job];
+            }
+            ++next_job;
         }
         if (query.empty()) { saw_empty_query = true; return last_cigar; }
         std::string ref;
@@ -447,7 +451,8 @@ struct Writer {
         {
             Stopwatch sw(&g_t_align);
             ++g_n_align;
-            if (known) { ++g_n_known; ssw_finish(query.data(), (int)query.size(), ref.data(), ppr_len, *known, res); }
+            if (known && known_path) { ++g_n_known; ++g_n_paths; ssw_finish_with_path(query.data(), (int)query.size(), ref.data(), ppr_len, *known, *known_path, res); }
+            else if (known) { ++g_n_known; ssw_finish(query.data(), (int)query.size(), ref.data(), ppr_len, *known, res); }
             else ssw_align(query.data(), (int)query.size(), ref.data(), ppr_len, 15, res);
         }
         last_cigar = res.cigar;
@@ -509,7 +514,7 @@ struct Writer {
 void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
                    const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
                    const std::string &sequence_id, std::string &bed, unsigned host_threads,
-                   const std::vector<RibbitAlignJob> *jobs, const std::vector<SswEnds> *ends) {
+                   const std::vector<RibbitAlignJob> *jobs, const std::vector<SswEnds> *ends, const std::vector<SswPath> *paths) {
     const Bases b(hp);
     // first job of every seed (jobs are in seed order)
     std::vector<uint32_t> job_first;
@@ -519,7 +524,7 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
         for (size_t i = dispatch.size(); i-- > 0;) job_first[i] = std::min(job_first[i], job_first[i + 1]);
     }
     auto run_range = [&](size_t lo, size_t hi, Writer &w) {
-        if (!job_first.empty()) { w.jobs = jobs->data(); w.ends = ends->data(); }
+        if (!job_first.empty()) { w.jobs = jobs->data(); w.ends = ends->data(); w.paths = (paths && paths->size() == jobs->size()) ? paths->data() : nullptr; }
         for (size_t i = lo; i < hi; ++i) {
             const RibbitSeed &seed = dispatch[i];
             if (!job_first.empty()) w.begin_seed(job_first[i], job_first[i + 1]);
@@ -565,8 +570,8 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
         bed += w.os.str();
     }
     if (std::getenv("RIBBIT_PROFILE"))
-        std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld (%ld with GPU passes)  (summed over threads) align %.2fs  small-motif discovery %.2fs  long-motif consensus %.2fs\n",
-                     dispatch.size(), threads, g_n_align.load(), g_n_known.load(), g_t_align.load() * 1e-9, g_t_small.load() * 1e-9, g_t_long.load() * 1e-9);
+        std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld (%ld with GPU passes, %ld with GPU paths)  (summed over threads) align %.2fs  small-motif discovery %.2fs  long-motif consensus %.2fs\n",
+                     dispatch.size(), threads, g_n_align.load(), g_n_known.load(), g_n_paths.load(), g_t_align.load() * 1e-9, g_t_small.load() * 1e-9, g_t_long.load() * 1e-9);
 }
 
 }  // namespace rb

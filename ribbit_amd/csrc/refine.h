@@ -38,7 +38,8 @@ int longest_run_host(const HostPlanes &hp, int mlen, int start, int end);
 void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
                    const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
                    const std::string &sequence_id, std::string &bed, unsigned host_threads = 0,
-                   const std::vector<RibbitAlignJob> *jobs = nullptr, const std::vector<SswEnds> *ends = nullptr);
+                   const std::vector<RibbitAlignJob> *jobs = nullptr, const std::vector<SswEnds> *ends = nullptr,
+                   const std::vector<SswPath> *paths = nullptr);
 // jobs / ends (optional): the first-level alignment jobs of build_align_jobs and the end points of their striped
 // passes as the GPU computed them (flag -1 = not computed); such alignments only need the traceback here.
 

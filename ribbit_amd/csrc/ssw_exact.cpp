@@ -340,7 +340,9 @@ void ssw_passes(const char *query, int query_len, const char *ref, int ref_len, 
     if (e.score > rev.score) e.flag = 2;
 }
 
-void ssw_finish(const char *query, int query_len, const char *ref, int ref_len, const SswEnds &e, SswResult &out) {
+namespace {
+// everything of an alignment after the passes; gpu_path: the path the GPU found (ssw_path.hip), null = search it here
+void finish(const char *query, int query_len, const char *ref, int ref_len, const SswEnds &e, const SswPath *gpu_path, SswResult &out) {
     out = SswResult{};
     out.score = e.score; out.ref_end = e.ref_end; out.query_end = e.query_end;
     out.score2 = e.score2; out.ref_end2 = e.ref_end2;
@@ -352,17 +354,24 @@ void ssw_finish(const char *query, int query_len, const char *ref, int ref_len, 
         out.ref_end = -1; out.ref_begin = -1; out.query_begin = -1;
         return;
     }
-    std::vector<int8_t> q((size_t)query_len), r((size_t)std::max(ref_len, 1));
+    static thread_local std::vector<int8_t> q, r;
+    q.resize((size_t)query_len); r.resize((size_t)std::max(ref_len, 1));
     for (int i = 0; i < query_len; ++i) q[(size_t)i] = translate(query[i]);
     for (int i = 0; i < ref_len; ++i) r[(size_t)i] = translate(ref[i]);
 
-    std::vector<Op> path;
+    static thread_local std::vector<Op> path;
+    path.clear();
     const bool too_far = out.ref_end - out.ref_begin > DISTANCE_FILTER || out.query_end - out.query_begin > DISTANCE_FILTER;
     if (!too_far) {
-        const int rl = out.ref_end - out.ref_begin + 1, ql = out.query_end - out.query_begin + 1;
-        if (!banded_path(r.data() + out.ref_begin, q.data() + out.query_begin, rl, ql, out.score, std::abs(rl - ql) + 1, path)) {
-            out.flag = 1;
-            path.clear();
+        if (gpu_path) {
+            if (gpu_path->failed) out.flag = 1;
+            else for (int k = 0; k < gpu_path->n_ops; ++k) path.push_back({"MID"[gpu_path->ops[k] & 3u], (int)(gpu_path->ops[k] >> 2)});
+        } else {
+            const int rl = out.ref_end - out.ref_begin + 1, ql = out.query_end - out.query_begin + 1;
+            if (!banded_path(r.data() + out.ref_begin, q.data() + out.query_begin, rl, ql, out.score, std::abs(rl - ql) + 1, path)) {
+                out.flag = 1;
+                path.clear();
+            }
         }
     }
 
@@ -385,6 +394,15 @@ void ssw_finish(const char *query, int query_len, const char *ref, int ref_len, 
     close_run();
     const int tail = query_len - out.query_end - 1;
     if (tail > 0) put(tail, 'S');
+}
+}  // namespace
+
+void ssw_finish(const char *query, int query_len, const char *ref, int ref_len, const SswEnds &e, SswResult &out) {
+    finish(query, query_len, ref, ref_len, e, nullptr, out);
+}
+
+void ssw_finish_with_path(const char *query, int query_len, const char *ref, int ref_len, const SswEnds &e, const SswPath &path, SswResult &out) {
+    finish(query, query_len, ref, ref_len, e, &path, out);
 }
 
 void ssw_align(const char *query, int query_len, const char *ref, int ref_len, int mask_len, SswResult &out) {

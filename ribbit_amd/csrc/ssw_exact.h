@@ -31,6 +31,16 @@ void ssw_passes(const char *query, int query_len, const char *ref, int ref_len, 
 // banded traceback between the end points and CIGAR / mismatch count (ssw.c:893-927, ssw_cpp.cpp:126-207)
 void ssw_finish(const char *query, int query_len, const char *ref, int ref_len, const SswEnds &ends, SswResult &out);
 
+// The path between the end points as the GPU found it (ssw_path.hip): run-length operations, length << 2 | {0 'M', 1 'I',
+// 2 'D'}, in path order; failed = the library's "traceback error" (flag 1).
+struct SswPath {
+    const uint32_t *ops = nullptr;
+    int32_t n_ops = 0;
+    bool failed = false;
+};
+// ssw_finish with the path already known
+void ssw_finish_with_path(const char *query, int query_len, const char *ref, int ref_len, const SswEnds &ends, const SswPath &path, SswResult &out);
+
 // Aligner().Align(query, ref, ref_len, Filter(), &alignment, mask_len) with the default scores
 // (match 2, mismatch 2, gap open 3, gap extend 1; ssw_cpp.cpp:230-242).
 void ssw_align(const char *query, int query_len, const char *ref, int ref_len, int mask_len, SswResult &out);

@@ -122,4 +122,69 @@ def test_bed_is_identical_with_the_striped_passes_on_the_gpu(tmp_path):
                            capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         assert bed.read_text() == want
-        assert ("with GPU passes" in r.stderr and "(0 with GPU passes)" not in r.stderr.split("[refine]")[-1]) == bool(flag)
+        assert ("with GPU passes" in r.stderr and "(0 with GPU passes" not in r.stderr.split("[refine]")[-1]) == bool(flag)
+        assert ("with GPU paths" in r.stderr and ", 0 with GPU paths)" not in r.stderr.split("[refine]")[-1]) == bool(flag)
+
+
+def _check_whole_alignments(pairs, need_paths):
+    """passes + banded path search on the GPU (ssw_kernels.hip, ssw_path.hip), CIGAR text on the host: everything
+    Aligner::Align returns must equal the reference library's"""
+    record, jobs, pool = _batch(pairs)
+    with ribbit_amd.Scanner(2, 8) as sc:
+        sc.load_record(record)
+        got, on_gpu = sc.ssw_align_jobs(jobs, pool)
+    for k, (query, motif, ppr_len) in enumerate(pairs):
+        ref = motif * (ppr_len // len(motif) + 2)
+        want, want_cigar = ref_align(query, ref, ppr_len)
+        res, cigar = got[k]
+        if want["sw_score"] == 0:                        # the library reads ref[-1] here (UB); defined as one soft clip
+            assert cigar == f"{len(query)}S", (k, cigar)
+            continue
+        assert cigar == want_cigar, (k, query, motif, ppr_len, cigar, want_cigar, int(on_gpu[k]))
+        for f in ("sw_score", "ref_begin", "ref_end", "query_begin", "query_end", "mismatches", "flag"):
+            assert res[f] == want[f], (k, f, res, want)
+    assert int((on_gpu == 2).sum()) >= need_paths, on_gpu
+    return on_gpu
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_gpu_path_search_gives_the_reference_librarys_cigars(seed):
+    rs = np.random.RandomState(1900 + seed)
+    pairs = []
+    for _ in range(600):
+        m = int(rs.randint(1, 30))
+        motif = _rand(rs, m)
+        units = int(rs.randint(2, 40))
+        rot = int(rs.randint(0, m))
+        pure = (motif * (units + 2))[rot:rot + m * units + int(rs.randint(0, m))]
+        query = _mutate(rs, pure, float(rs.choice([0.0, 0.03, 0.1, 0.2, 0.35])))
+        if query:
+            pairs.append((query, motif, len(query) + m + int(0.15 * len(query))))
+    _check_whole_alignments(pairs, need_paths=400)
+
+
+def test_gpu_path_search_with_wide_bands_and_long_queries():
+    """indel-rich long alignments: the band doubles several times, rows wider than a wavefront are walked in chunks"""
+    rs = np.random.RandomState(31)
+    pairs = []
+    for n in (90, 150, 260, 400, 480, 500):
+        for rate in (0.05, 0.15, 0.3):
+            motif = _rand(rs, int(rs.randint(2, 14)))
+            pure = (motif * (n // len(motif) + 2))[:n]
+            query = _mutate(rs, pure, rate)[:n]
+            # long deletions / insertions move the path far off the diagonal
+            cut = int(rs.randint(10, 60))
+            query = query[:len(query) // 2] + query[len(query) // 2 + cut:] if rs.random_sample() < 0.5 else query[:len(query) // 3] + _rand(rs, cut) + query[len(query) // 3:]
+            query = query[:512]
+            pairs.append((query, motif, min(1024, len(query) + len(motif) + int(0.15 * len(query)))))
+    _check_whole_alignments(pairs, need_paths=12)
+
+
+def test_gpu_path_search_on_random_pairs_and_unknown_bases():
+    rs = np.random.RandomState(78)
+    pairs = []
+    for _ in range(500):
+        q = _rand(rs, int(rs.randint(1, 120)), b"ACGTN" if rs.random_sample() < 0.2 else b"ACGTacgtU")
+        motif = _rand(rs, int(rs.randint(1, 200)))
+        pairs.append((q, motif, len(motif)))
+    _check_whole_alignments(pairs, need_paths=300)
