@@ -198,7 +198,7 @@ typedef struct RibbitAlignJob {
  * What the two striped passes of an alignment determine (ssw.c:843-891: score, end point, second best score outside
  * the mask window, begin point): everything of StripedSmithWaterman::Alignment except the CIGAR.
  * flag: 0 ok, 2 the reverse pass scored less than the forward pass, -1 not computed (job too large for the
- * GPU kernel: query_length > 512 or ppr_length > 1024) -- align those with ribbit_ssw_align.
+ * GPU kernels: query_length > 2048 or ppr_length > 4096) -- align those with ribbit_ssw_align.
  */
 typedef struct RibbitSswEnds {
     int32_t score, ref_end, query_end, score2, ref_end2, ref_begin, query_begin, flag;
@@ -431,6 +431,18 @@ void ribbit_debug_set_merge_min_range(size_t calls);
 /* Test hook: what the last merge of a stage (0 substitution, 1 anchored) on the calling thread did: out = {ranges, ranges
  * merged again after validation, whole stage redone in order (0/1), list-head writes that forced it, first range empty (0/1)}. */
 void ribbit_debug_last_merge(int stage, int32_t out[5]);
+
+/* possibleMotifs (parse_smallmotif_seed.cpp:76-188) of every dispatched seed with m <= 10 that reaches it, computed
+ * by one GPU launch (small_motifs.hip) -- what ribbit_hip_refine_jobs / ribbit_hip_refine_bed use for those seeds.
+ * head: 4 ints per dispatched seed {first record, early reports, classes, flags}; flags != 0: the seed has no device
+ * result (m > 10, filtered out by the continuous-ones threshold: -1; more than 64 classes or reports: 1; record arena
+ * full: 2) and the library runs the host twin for it.  records: 4 words each {rotation class, first start, last end,
+ * units}: a seed's early reports (already filtered by MINIMUM_LENGTH / PERFECT_UNITS, in the reference's push order),
+ * then all its classes in order of first appearance with their final state.  Valid until the next call on the handle. */
+int ribbit_hip_small_motifs(RibbitHandle *h, const RibbitRefineParams *prm, const int32_t **head, size_t *n_seeds,
+                            const uint32_t **records, size_t *n_records);
+/* Test hook: cumulative, process-wide: small-motif seeds that refinement took from the GPU's table / computed on the host. */
+void ribbit_debug_small_motif_counters(int64_t out[2]);
 
 /* HIP events behind ribbit_hip_last_timing_ms are recorded by default; every record is a barrier packet between two
  * kernels of the stream (~6 us each on MI355X).  A caller that streams many records can switch them off per handle

@@ -40,6 +40,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_last_timing_ms", "ribbit_hip_last_event_count",
     "ribbit_hip_subst_calls", "ribbit_hip_seeds_substitutions",
     "ribbit_host_replay_calls", "ribbit_seed_lists_free", "ribbit_host_longest_runs", "ribbit_debug_set_merge_min_range", "ribbit_debug_last_merge",
+    "ribbit_hip_small_motifs", "ribbit_debug_small_motif_counters",
     "ribbit_hip_anchored_calls", "ribbit_hip_seeds_anchored", "ribbit_hip_dispatch_seeds", "ribbit_hip_guard_hits",
     "ribbit_hip_debug_stream_read",
     "ribbit_refine_params_default", "ribbit_hip_seed_longest_runs", "ribbit_hip_refine_jobs",
@@ -132,6 +133,9 @@ def load_library():
     L.ribbit_seed_lists_free.argtypes = [C.POINTER(SeedLists)]
     L.ribbit_debug_last_merge.restype = None
     L.ribbit_debug_last_merge.argtypes = [C.c_int, C.POINTER(C.c_int32 * 5)]
+    L.ribbit_debug_small_motif_counters.restype = None
+    L.ribbit_debug_small_motif_counters.argtypes = [C.POINTER(C.c_int64 * 2)]
+    L.ribbit_hip_small_motifs.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ribbit_debug_set_merge_min_range.restype = None
     L.ribbit_debug_set_merge_min_range.argtypes = [C.c_size_t]
     L.ribbit_host_longest_runs.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp]
@@ -266,6 +270,14 @@ def ssw_align(query: bytes, ref: bytes, ref_len: int | None = None, mask_len: in
 def _jobs_with_motifs(jobs, pool: bytes):
     """-> list of (job record, motif string)"""
     return [(j, pool[int(j["motif_offset"]):int(j["motif_offset"]) + int(j["atomicity"])].decode()) for j in jobs]
+
+
+def small_motif_counters():
+    """(seeds refinement took from the GPU's possibleMotifs table, seeds it computed on the host), cumulative"""
+    L = load_library()
+    out = (C.c_int64 * 2)()
+    L.ribbit_debug_small_motif_counters(C.byref(out))
+    return int(out[0]), int(out[1])
 
 
 def host_longest_runs(min_motif: int, max_motif: int, sequence: bytes, seeds):
@@ -609,6 +621,17 @@ class Scanner:
         arr = _copy(jobs.value, n.value, JOB_DT)
         size = int((arr["motif_offset"] + arr["atomicity"]).max()) if len(arr) else 0
         return arr, (C.string_at(pool.value, size) if size else b"")
+
+    def small_motifs(self, refine_params=None):
+        """ribbit_hip_small_motifs: (head [n_seeds, 4] int32, records [n_records, 4] uint32) -- possibleMotifs of the
+        dispatched seeds with m <= 10 as the GPU computed it"""
+        rp = refine_params
+        if rp is None:
+            rp = RefineParams()
+            self._L.ribbit_refine_params_default(C.byref(rp), self.params.min_motif, self.params.max_motif)
+        head, n, rec, nr = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        self._check(self._L.ribbit_hip_small_motifs(self._h, C.byref(rp), C.byref(head), C.byref(n), C.byref(rec), C.byref(nr)))
+        return _copy(head.value, 4 * n.value, np.dtype("<i4")).reshape(-1, 4), _copy(rec.value, 4 * nr.value, np.dtype("<u4")).reshape(-1, 4)
 
     def refine_bed(self, sequence_id: str = "seq", refine_params=None) -> str:
         """BED rows of the loaded record (fasta_utils.cpp:211-242 and everything below it)"""

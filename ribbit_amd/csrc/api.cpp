@@ -5,11 +5,14 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -170,6 +173,13 @@ struct RibbitHandle {
     DevBuf<RibbitSeed> d_seeds;
     DevBuf<int32_t> d_longest;
     DevBuf<uint8_t> d_sym;
+    bool sym_valid = false;                                 // d_sym holds the loaded record
+    DevBuf<uint32_t> d_small_records, d_small_count;        // possibleMotifs of the dispatched seeds (small_motifs.hip)
+    DevBuf<int32_t> d_small_head;
+    PinnedBuf<int32_t> small_head;                          // 4 per dispatched seed; flags (4 i + 3) != 0: no device result
+    PinnedBuf<uint32_t> small_records;
+    size_t n_small_records = 0;
+    bool small_valid = false;
     DevBuf<unsigned long long> d_best;
     DevBuf<int32_t> d_slices;
     DevBuf<int32_t> d_ssw_jobs, d_ssw_order, d_ssw_out;   // batched striped passes (ssw_kernels.hip)
@@ -235,6 +245,8 @@ int pack_loaded_ascii(RibbitHandle *h, const uint8_t *dev_ascii, int64_t length)
     h->runs_valid = h->calls_valid = h->subst_calls_valid = h->anchored_calls_valid = false;
     h->longest_valid = false;
     h->best_rows_valid = false;
+    h->small_valid = false;
+    h->sym_valid = false;
     h->host_planes_valid = false;
     h->eval_valid = false;
     h->xa_on_device = false;
@@ -957,8 +969,7 @@ int build_best_rows(RibbitHandle *h, const RibbitRefineParams &prm) {
         if ((rc = h->d_sym.ensure((size_t)h->length + 16))) return rc;
         if ((rc = h->d_seeds.ensure(jobs.size()))) return rc;
         if ((rc = h->d_best.ensure(jobs.size()))) return rc;
-        rb::launch_sym(h->dev_ascii_src, h->length, h->d_sym.p, h->stream);
-        HIP_TRY(hipGetLastError());
+        if (!h->sym_valid) { rb::launch_sym(h->dev_ascii_src, h->length, h->d_sym.p, h->stream); HIP_TRY(hipGetLastError()); h->sym_valid = true; }
         HIP_TRY(hipMemcpyAsync(h->d_seeds.p, jobs.data(), jobs.size() * sizeof(RibbitSeed), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemsetAsync(h->d_best.p, 0, jobs.size() * sizeof(unsigned long long), h->stream));
         // 64-row slices of every seed: {job, first row}
@@ -981,6 +992,65 @@ int build_best_rows(RibbitHandle *h, const RibbitRefineParams &prm) {
             h->best_rows[(size_t)jobs[j].type] = best[j] ? (int32_t)(0xffffffffu - (uint32_t)best[j]) : 0;
     }
     h->best_rows_valid = true;
+    return RIBBIT_OK;
+}
+
+// possibleMotifs of every dispatched seed with m <= 10 that reaches it (parse_smallmotif_seed.cpp:234-236), one GPU
+// launch (a14 / f2); seeds the kernel flags (more than 64 classes) keep flags != 0 and the host twin runs for them
+int build_small_motifs(RibbitHandle *h, const RibbitRefineParams &prm) {
+    if (h->small_valid) return RIBBIT_OK;
+    int rc = build_longest_runs(h);
+    if (rc) return rc;
+    const size_t n = h->dispatch.size();
+    const double t0 = now_ms();
+    if ((rc = h->small_head.ensure(std::max<size_t>(4 * n, 4)))) return rc;
+    h->n_small_records = 0;
+    std::vector<RibbitSeed> jobs;          // reused as int4 {seed start, seed end, m, dispatch index}
+    jobs.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        const RibbitSeed &s = h->dispatch[i];
+        if (s.mlen > 10 || s.mlen < 1 || h->longest_runs[i] < prm.continuous_ones_threshold) continue;
+        jobs.push_back(RibbitSeed{s.start, s.end, s.mlen, (int32_t)i});
+    }
+    if (jobs.empty()) {
+        for (size_t i = 0; i < n; ++i) h->small_head.p[4 * i + 3] = -1;
+    } else {
+        if ((rc = bind_device(h))) return rc;
+        rb::SmallMotifLimits lim{};
+        for (int m = 1; m <= 10; ++m) {
+            int d = 0;
+            while (!(d >= 0.9 * m - 1)) ++d;                 // the reference's test, in its own (double) arithmetic
+            lim.first_window[m] = d;
+            lim.min_length[m] = prm.min_length[m];
+            lim.min_units[m] = prm.perfect_units[m];
+        }
+        // room for eight records a seed and a million more; a seed that finds the arena full is left to the host
+        const size_t cap = std::min<size_t>(8 * jobs.size() + (1u << 20), 0x7fffffffu);
+        if ((rc = h->d_sym.ensure((size_t)h->length + 16)) || (rc = h->d_seeds.ensure(jobs.size())) || (rc = h->d_small_head.ensure(4 * n)) ||
+            (rc = h->d_small_records.ensure(4 * cap)) || (rc = h->d_small_count.ensure(4)))
+            return rc;
+        if (!h->sym_valid) { rb::launch_sym(h->dev_ascii_src, h->length, h->d_sym.p, h->stream); HIP_TRY(hipGetLastError()); h->sym_valid = true; }
+        HIP_TRY(hipMemcpyAsync(h->d_seeds.p, jobs.data(), jobs.size() * sizeof(RibbitSeed), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_small_count.p, 0, 4 * sizeof(uint32_t), h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_small_head.p, 0xff, 4 * n * sizeof(int32_t), h->stream));      // flags -1: no device result
+        rb::launch_small_motifs(h->d_sym.p, h->length, h->d_seeds.p, (int64_t)jobs.size(), lim, h->d_small_records.p, (uint32_t)cap, h->d_small_count.p,
+                                h->d_small_head.p, h->stream);
+        HIP_TRY(hipGetLastError());
+        uint32_t used = 0;
+        HIP_TRY(hipMemcpyAsync(h->small_head.p, h->d_small_head.p, 4 * n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(&used, h->d_small_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        used = (uint32_t)std::min<size_t>(used, cap);
+        if ((rc = h->small_records.ensure(std::max<size_t>(4 * (size_t)used, 4)))) return rc;
+        if (used) {
+            HIP_TRY(hipMemcpyAsync(h->small_records.p, h->d_small_records.p, 4 * (size_t)used * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        h->n_small_records = used;
+    }
+    static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
+    if (profile) std::fprintf(stderr, "[small motifs] %zu seeds on the GPU, %zu records, %.1f ms incl. transfers\n", jobs.size(), h->n_small_records, now_ms() - t0);
+    h->small_valid = true;
     return RIBBIT_OK;
 }
 
@@ -1070,6 +1140,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     h->d_ssw_jobs.release(); h->d_ssw_order.release(); h->d_ssw_out.release(); h->d_ssw_pool.release();
     h->d_path_items.release(); h->d_path_result.release(); h->d_path_cell_off.release(); h->d_path_ops_off.release(); h->d_path_cells.release();
     h->d_path_scratch.release(); h->d_path_ops.release(); h->d_path_count.release(); h->h_path_ops.release();
+    h->d_small_head.release(); h->d_small_records.release(); h->d_small_count.release(); h->small_head.release(); h->small_records.release();
     h->h_events.release(); h->h_counters.release(); h->h_query.release();
     h->d_pair_table.release(); h->d_run_base.release(); h->d_pair_partial.release(); h->d_pair_status.release();
     h->h_pub.release(); h->h_runs.release(); h->h_halves.release(); h->d_halves.release();
@@ -1259,7 +1330,7 @@ int ribbit_hip_seed_longest_runs(RibbitHandle *h, const int32_t **out, size_t *n
 // forward + reverse striped Smith-Waterman passes of every job in one (two) launches; ends[j].flag == -1 where the
 // job is too large for the kernel's LDS budget (the host aligns those)
 static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const char *pool, size_t pool_len, int mask_len,
-                          std::vector<rb::SswEnds> &ends) {
+                          std::vector<rb::SswEnds> &ends, bool large_class = true) {
     static_assert(sizeof(RibbitAlignJob) == 9 * sizeof(int32_t), "job record layout");
     static_assert(sizeof(rb::SswEnds) == 8 * sizeof(int32_t), "ends record layout");
     ends.assign(n, rb::SswEnds{});
@@ -1268,22 +1339,27 @@ static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n,
     if (!h->dev_ascii_src) return fail(RIBBIT_E_STATE, "the record's bases are not resident on the device");
     int rc;
     if ((rc = bind_device(h))) return rc;
-    // two size classes, each sorted by work so that the four alignments of a wavefront are alike
-    std::vector<int32_t> small, big;
+    // three size classes, each sorted by work (largest first) so that the alignments of a wavefront are alike
+    const bool no_huge = !large_class;
+    std::vector<uint64_t> keyed[3];
     for (size_t j = 0; j < n; ++j) {
         const RibbitAlignJob &jb = jobs[j];
-        if (jb.query_length <= rb::SSW_SMALL_Q && jb.ppr_length <= rb::SSW_SMALL_R) small.push_back((int32_t)j);
-        else if (jb.query_length <= rb::SSW_BIG_Q && jb.ppr_length <= rb::SSW_BIG_R) big.push_back((int32_t)j);
-        else ends[j].flag = -1;
+        int cls;
+        if (jb.query_length <= rb::SSW_SMALL_Q && jb.ppr_length <= rb::SSW_SMALL_R) cls = 0;
+        else if (jb.query_length <= rb::SSW_BIG_Q && jb.ppr_length <= rb::SSW_BIG_R) cls = 1;
+        else if (!no_huge && jb.query_length <= rb::SSW_HUGE_Q && jb.ppr_length <= rb::SSW_HUGE_R) cls = 2;
+        else { ends[j].flag = -1; continue; }
+        const uint64_t work = (uint64_t)std::max(jb.query_length, 0) * (uint64_t)std::max(jb.ppr_length, 0);      // < 2^23
+        keyed[cls].push_back(((0xffffffffull - work) << 32) | (uint64_t)j);
     }
-    auto by_work = [&](int32_t a, int32_t b) {
-        const int64_t wa = (int64_t)jobs[a].query_length * jobs[a].ppr_length, wb = (int64_t)jobs[b].query_length * jobs[b].ppr_length;
-        return wa != wb ? wa > wb : a < b;
-    };
-    std::sort(small.begin(), small.end(), by_work);
-    std::sort(big.begin(), big.end(), by_work);
-    std::vector<int32_t> order(big);
-    order.insert(order.end(), small.begin(), small.end());
+    std::vector<int32_t> order;
+    size_t class_count[3];
+    for (int cls = 2; cls >= 0; --cls) {
+        std::sort(keyed[cls].begin(), keyed[cls].end());
+        class_count[cls] = keyed[cls].size();
+        for (uint64_t k : keyed[cls]) order.push_back((int32_t)(k & 0xffffffffu));
+    }
+    const size_t n_huge = class_count[2], n_big = class_count[1], n_small = class_count[0];
     if (order.empty()) return RIBBIT_OK;
     if ((rc = h->d_ssw_jobs.ensure(n * 9))) return rc;
     if ((rc = h->d_ssw_out.ensure(n * 8))) return rc;
@@ -1293,8 +1369,8 @@ static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n,
     HIP_TRY(hipMemcpyAsync(h->d_ssw_order.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     if (pool_len) HIP_TRY(hipMemcpyAsync(h->d_ssw_pool.p, pool, pool_len, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_ssw_out.p, 0xff, n * 8 * sizeof(int32_t), h->stream));      // flag -1 unless a kernel writes the record
-    rb::launch_ssw_passes(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_order.p + big.size(), (int)small.size(),
-                          h->d_ssw_order.p, (int)big.size(), mask_len, h->d_ssw_out.p, h->stream);
+    rb::launch_ssw_passes(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_order.p + n_huge + n_big, (int)n_small,
+                          h->d_ssw_order.p + n_huge, (int)n_big, h->d_ssw_order.p, (int)n_huge, mask_len, h->d_ssw_out.p, h->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ends.data(), h->d_ssw_out.p, n * sizeof(rb::SswEnds), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1329,6 +1405,7 @@ static int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, 
     if ((rc = h->d_path_count.ensure(4))) return rc;
     if ((rc = h->d_path_result.ensure(4 * n))) return rc;
     HIP_TRY(hipMemsetAsync(h->d_path_count.p, 0, 4 * sizeof(uint32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_path_result.p, 0xff, 4 * n * sizeof(int32_t), h->stream));      // state -1: no path searched (the buffer is reused)
     std::vector<int32_t> items, result(4 * n, -1);
     std::vector<uint64_t> cell_off, ops_off;
     std::vector<Open> next;
@@ -1460,9 +1537,12 @@ int ribbit_hip_refine_jobs(RibbitHandle *h, const RibbitRefineParams *prm, const
     if (!h || !prm || !jobs || !n || !motif_pool) return fail(RIBBIT_E_ARG, "null argument");
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
     h->best_rows_valid = false;            // depends on prm's thresholds
+    h->small_valid = false;
     int rc = build_best_rows(h, *prm);
     if (rc) return rc;
-    rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), h->jobs, h->motif_pool);
+    if ((rc = build_small_motifs(h, *prm))) return rc;
+    const rb::SmallMotifTable small{h->small_head.p, h->small_records.p};
+    rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), h->jobs, h->motif_pool, 1, 0, (size_t)-1, &small);
     *jobs = h->jobs.data();
     *n = h->jobs.size();
     *motif_pool = h->motif_pool.c_str();
@@ -1531,11 +1611,14 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
     if (!h || !prm || !sequence_id || !text || !len) return fail(RIBBIT_E_ARG, "null argument");
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
     h->best_rows_valid = false;
+    h->small_valid = false;
     static double t_rows = 0, t_text = 0, t_jobs = 0;
     static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
     double t0 = now_ms();
     int rc = build_best_rows(h, *prm);
     if (rc) return rc;
+    if ((rc = build_small_motifs(h, *prm))) return rc;
+    const rb::SmallMotifTable small{h->small_head.p, h->small_records.p};
     t_rows += now_ms() - t0;
     t0 = now_ms();
     if (!h->host_bases && !h->host_ascii_valid) {      // bases not on the host in memory we may keep reading: fetch them once
@@ -1556,22 +1639,93 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
     unsigned threads = h->host_threads ? h->host_threads : std::min(std::thread::hardware_concurrency(), 16u);
     if (!h->host_threads)
         if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
-    const std::vector<RibbitAlignJob> *jobs = nullptr;
+    bool done = false;
     if (gpu_ssw && !h->dispatch.empty()) {
-        const double tj = now_ms();
-        rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), h->jobs, h->motif_pool, threads);
-        const double tp = now_ms();
-        if ((rc = run_ssw_passes(h, h->jobs.data(), h->jobs.size(), h->motif_pool.data(), h->motif_pool.size(), 15, h->ssw_ends))) return rc;
-        const double tq = now_ms();
-        if ((rc = run_ssw_paths(h, h->jobs.data(), h->jobs.size(), h->ssw_ends, h->ssw_paths))) return rc;
-        if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs: set-up %.1f ms, GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms\n",
-                                  h->jobs.size(), tp - tj, tq - tp, now_ms() - tq);
-        jobs = &h->jobs;
+        // The record's seeds go through in slices: a feeder thread sets up the alignment jobs of slice c + 1 and runs
+        // their striped passes and path searches on the GPU while the worker threads refine slice c with the results
+        // of its own batch (host copies; the device buffers are the feeder's alone).
+        struct Slice {
+            size_t lo = 0, hi = 0;
+            std::vector<RibbitAlignJob> jobs;
+            std::string pool;
+            std::vector<rb::SswEnds> ends;
+            std::vector<rb::SswPath> paths;
+            std::vector<uint32_t> ops;
+            int rc = RIBBIT_OK;
+            std::string error;
+            bool ready = false;
+            double t_setup = 0, t_passes = 0, t_paths = 0;
+        };
+        // Measured (20 Mbp, 16 threads): the batches take work off the workers that the set-up puts back, so
+        // one slice (no overlap) is the default and RIBBIT_SSW_SLICES / RIBBIT_SSW_LARGE are there to measure with.
+        size_t n_slices = 1;
+        if (const char *env = std::getenv("RIBBIT_SSW_SLICES")) n_slices = (size_t)std::max(1, std::atoi(env));
+        static const bool large_class = std::getenv("RIBBIT_SSW_LARGE") != nullptr;      // queries of 513..2048 bases on the GPU too
+        n_slices = std::min(n_slices, h->dispatch.size());
+        std::vector<Slice> slices(n_slices);
+        for (size_t c = 0; c < n_slices; ++c) {
+            slices[c].lo = h->dispatch.size() * c / n_slices;
+            slices[c].hi = h->dispatch.size() * (c + 1) / n_slices;
+        }
+        std::mutex mu;
+        std::condition_variable cv;
+        std::atomic<bool> stop{false};
+        const unsigned feed_threads = std::max(1u, threads / 4);
+        std::thread feeder([&]() {
+            for (size_t c = 0; c < n_slices && !stop; ++c) {
+                Slice &sl = slices[c];
+                const double tj = now_ms();
+                rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sl.jobs, sl.pool,
+                                     c == 0 ? threads : feed_threads, sl.lo, sl.hi, &small);
+                const double tp = now_ms();
+                sl.rc = run_ssw_passes(h, sl.jobs.data(), sl.jobs.size(), sl.pool.data(), sl.pool.size(), 15, sl.ends, large_class);
+                const double tq = now_ms();
+                if (!sl.rc) sl.rc = run_ssw_paths(h, sl.jobs.data(), sl.jobs.size(), sl.ends, sl.paths);
+                if (!sl.rc) {
+                    // the paths point into the handle's pinned buffer, which the next slice overwrites
+                    size_t n_ops = 0;
+                    for (const rb::SswPath &pt : sl.paths) if (pt.ops) n_ops = std::max(n_ops, (size_t)(pt.ops - h->h_path_ops.p) + (size_t)pt.n_ops);
+                    sl.ops.assign(h->h_path_ops.p, h->h_path_ops.p + n_ops);
+                    for (rb::SswPath &pt : sl.paths) if (pt.ops) pt.ops = sl.ops.data() + (pt.ops - h->h_path_ops.p);
+                } else {
+                    sl.error = g_last_error;
+                }
+                sl.t_setup = tp - tj; sl.t_passes = tq - tp; sl.t_paths = now_ms() - tq;
+                { std::lock_guard<std::mutex> lk(mu); sl.ready = true; }
+                cv.notify_all();
+                if (sl.rc) break;
+            }
+        });
+        bool order_dependent = false;
+        double t_wait = 0, t_setup = 0, t_passes = 0, t_paths = 0;
+        size_t n_jobs = 0;
+        for (size_t c = 0; c < n_slices; ++c) {
+            Slice &sl = slices[c];
+            const double tw = now_ms();
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return sl.ready; }); }
+            t_wait += now_ms() - tw;
+            if (sl.rc) { rc = sl.rc; g_last_error = sl.error; break; }
+            t_setup += sl.t_setup; t_passes += sl.t_passes; t_paths += sl.t_paths; n_jobs += sl.jobs.size();
+            rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
+                              sequence_id, h->bed, h->host_threads, &sl.jobs, &sl.ends, &sl.paths, sl.lo, sl.hi, &order_dependent, &small);
+            if (order_dependent) break;
+            sl = Slice{};                                   // free the slice's memory
+            sl.ready = true;
+        }
+        stop = true;
+        feeder.join();
+        if (rc) return rc;
+        if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs in %zu slices: feeder thread set-up %.1f ms, GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms; workers waited %.1f ms for it\n",
+                                  n_jobs, n_slices, t_setup, t_passes, t_paths, t_wait);
+        t_jobs += t_wait;
+        done = !order_dependent;
+        if (order_dependent) h->bed.clear();               // an empty query somewhere: the whole record in one call (below)
     }
-    t_jobs += now_ms() - t0;
-    t0 = now_ms();
-    rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sequence_id, h->bed,
-                      h->host_threads, jobs, jobs ? &h->ssw_ends : nullptr, jobs ? &h->ssw_paths : nullptr);
+    if (!done) {
+        t0 = now_ms();
+        rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sequence_id, h->bed,
+                          h->host_threads, nullptr, nullptr, nullptr, 0, (size_t)-1, nullptr, &small);
+    }
     t_text += now_ms() - t0;
     if (profile) std::fprintf(stderr, "[refine_bed] cumulative: GPU scans of the seeds %.1f ms, alignment set-up + GPU striped passes %.1f ms, host refinement + BED %.1f ms\n", t_rows, t_jobs, t_text);
     *text = h->bed.c_str();
@@ -1790,6 +1944,26 @@ int ribbit_hip_debug_set_event_capacity(RibbitHandle *h, size_t events) {
 }
 
 void ribbit_debug_set_merge_min_range(size_t calls) { rb::set_merge_min_range(calls); }
+
+int ribbit_hip_small_motifs(RibbitHandle *h, const RibbitRefineParams *prm, const int32_t **head, size_t *n_seeds,
+                            const uint32_t **records, size_t *n_records) {
+    if (!h || !prm || !head || !n_seeds || !records || !n_records) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    h->small_valid = false;                // depends on prm's thresholds
+    const int rc = build_small_motifs(h, *prm);
+    if (rc) return rc;
+    *head = h->small_head.p;
+    *n_seeds = h->dispatch.size();
+    *records = h->small_records.p;
+    *n_records = h->n_small_records;
+    return RIBBIT_OK;
+}
+
+void ribbit_debug_small_motif_counters(int64_t out[2]) {
+    long a = 0, b = 0;
+    rb::small_motif_counters(a, b);
+    out[0] = a; out[1] = b;
+}
 
 void ribbit_debug_last_merge(int stage, int32_t out[5]) {
     const rb::MergeStats st = rb::last_merge_stats(stage);

@@ -122,6 +122,15 @@ void launch_seed_longest_runs(const uint32_t *xa, int64_t xa_stride, int m_lo, c
 
 // one byte per base (0..3 = A C G T, 4 = N) from the resident ASCII record
 void launch_sym(const uint8_t *ascii, int64_t length, uint8_t *sym, hipStream_t stream);
+
+// small_motifs.hip: possibleMotifs of every dispatched seed with m <= 10 (one wavefront per seed)
+struct SmallMotifLimits {
+    int32_t first_window[11];      // smallest j - seed_start with j - seed_start >= 0.9 m - 1 (parse_smallmotif_seed.cpp:96)
+    int32_t min_length[11];        // MINIMUM_LENGTH[m]
+    int32_t min_units[11];         // PERFECT_UNITS[m]
+};
+void launch_small_motifs(const uint8_t *sym, int64_t length, const void *jobs, int64_t njobs, const SmallMotifLimits &lim, void *records,
+                         uint32_t record_cap, uint32_t *record_count, void *head, hipStream_t stream);
 // mostFrequentLongerMotif's row scores (parse_seed.cpp:165-243) for njobs seeds {seed_start, seed_sequence_length, m, -}:
 // best[job] = (best score << 32) | (0xffffffff - first row with that score), 0 when every row scores 0.
 // best[] must be zeroed by the caller.  blocks[nblocks] = {job, first row of a 64-row slice of that seed}: every
@@ -131,12 +140,12 @@ void launch_long_motif_rows(const uint8_t *sym, int64_t length, const void *jobs
 
 // The two striped Smith-Waterman passes (ssw.c:843-891) of njobs alignment jobs (RibbitAlignJob records, 9 ints each):
 // query = record[query_start, +query_length), reference = the job's motif repeated to ppr_length.  Jobs are launched in
-// two size classes (order_small / order_big: job indices, each list sorted by size); out[8*job .. +8) = score,
+// three size classes (order_small / order_big / order_huge: job indices, each list sorted by size); out[8*job .. +8) = score,
 // ref_end, query_end, score2, ref_end2, ref_begin, query_begin, flag -- flag -1: too large for its class, not computed.
-constexpr int SSW_SMALL_Q = 128, SSW_SMALL_R = 256, SSW_BIG_Q = 512, SSW_BIG_R = 1024;
+constexpr int SSW_SMALL_Q = 128, SSW_SMALL_R = 256, SSW_BIG_Q = 512, SSW_BIG_R = 1024, SSW_HUGE_Q = 2048, SSW_HUGE_R = 4096;
 void launch_ssw_passes(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs,
-                       const int32_t *order_small, int n_small, const int32_t *order_big, int n_big, int mask_len,
-                       int32_t *out, hipStream_t stream);
+                       const int32_t *order_small, int n_small, const int32_t *order_big, int n_big, const int32_t *order_huge, int n_huge,
+                       int mask_len, int32_t *out, hipStream_t stream);
 
 // The banded path search (ssw.c:590-775) of n_items alignments whose end points are known, one wavefront each (ssw_path.hip).
 // items[4*t] = job index, items[4*t+1] = band of this round; cell_off[t] / ops_off[t]: where item t's cell bytes

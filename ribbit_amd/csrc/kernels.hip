@@ -343,7 +343,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_PERFECT_
 #pragma unroll
             for (int k = 0; k < K; k++) { SQ[k] = 0; EQ[k] = 0; }
         }
+#ifdef RB_ABLATE_STAGING        // tools/build_variant.sh: timing without the event staging
+        if (__ballot(any == 0xdeadbeefu) != 0ull) {
+#else
         if (__ballot(any != 0) != 0ull) {
+#endif
             const uint32_t src_word0 = (uint32_t)tile_base + src * (uint32_t)K;
             stage_events(SQ, EQ, src_word0, qm, sink, stage, staged, lane, [&](int k, uint32_t b, uint32_t pos) {
                 if (pos >= length) return (uint32_t)EV_END_EOS;
@@ -402,7 +406,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_PERFECT_
                 for (int j = 0; j < K + 2; j++) hit = bitop3<0xBA>(Z[j] - ones, Z[j], hit);      // ((Z - ones) & ~Z) | hit
                 cand = (hit & tops) != 0;
             }
+#ifdef RB_ABLATE_CHAIN          // ... and without the doubling chain / candidate queue: what remains is Z + prefilter
+            const unsigned long long mask = __ballot(cand && Z[0] == 0xdeadbeefu);
+#else
             const unsigned long long mask = __ballot(cand);
+#endif
             if (mask == 0ull) continue;
             const int n = __popcll(mask);
             if (n <= CAND_DIRECT) {
@@ -422,7 +430,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_PERFECT_
         // either way a (tile, motif) pair's events stay in one piece)
         uint32_t SQ[K], EQ[K];
         const uint32_t any = perfect_edges<true>(Z, t3, t4, t5, 32u - (uint32_t)sp, SQ, EQ);
+#ifdef RB_ABLATE_STAGING
+        if (__ballot(any == 0xdeadbeefu) != 0ull) {
+#else
         if (__ballot(any != 0) != 0ull) {
+#endif
             stage_events(SQ, EQ, word0, (uint32_t)m, sink, stage, staged, lane, [&](int k, uint32_t b, uint32_t pos) {
                 if (pos >= length) return (uint32_t)EV_END_EOS;
                 return ((Bk[k + 1] >> b) & 1u) ? (uint32_t)EV_END_N : (uint32_t)EV_END_ZERO;

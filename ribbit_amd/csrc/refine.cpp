@@ -148,6 +148,31 @@ void discover_small_motifs(const Bases &b, int seed_start, int seq_len, int m, i
     }
 }
 
+// The same list from the GPU's records of seed i (small_motifs.hip): the early reports as they are, then the classes
+// that survive to the seed's end in the iteration order of the reference's unordered_map, which the keys' insertion
+// order (= order of first appearance = record order) determines.  False: the seed has no device result.
+bool small_motifs_from_table(const SmallMotifTable *table, size_t i, int min_len, int min_units,
+                             std::vector<uint32_t> &classes, std::vector<int> &starts, std::vector<int> &ends) {
+    if (!table || !table->head) return false;
+    const int32_t *hd = table->head + 4 * i;
+    if (hd[3] != 0) return false;
+    const uint32_t *rec = table->records + 4 * (size_t)(uint32_t)hd[0];
+    for (int k = 0; k < hd[1]; ++k, rec += 4) { classes.push_back(rec[0]); starts.push_back((int)rec[1]); ends.push_back((int)rec[2]); }
+    auto qualifies = [&](const uint32_t *r) { return (int)r[2] - (int)r[1] >= min_len && (int)r[3] >= min_units; };
+    auto report = [&](const uint32_t *r) { classes.push_back(r[0]); starts.push_back((int)r[1]); ends.push_back((int)r[2]); };
+    // the order only matters between survivors that are reported: with fewer than two of them no map is needed
+    int n_reported = 0, only = -1;
+    for (int k = 0; k < hd[2]; ++k)
+        if (qualifies(rec + 4 * k)) { ++n_reported; only = k; }
+    if (n_reported == 0) return true;
+    if (n_reported == 1) { report(rec + 4 * only); return true; }
+    std::unordered_map<uint32_t, int> order;
+    for (int k = 0; k < hd[2]; ++k) order[rec[4 * k]] = k;
+    for (const auto &kv : order)
+        if (qualifies(rec + 4 * kv.second)) report(rec + 4 * kv.second);
+    return true;
+}
+
 // mostFrequentLongerMotif (parse_seed.cpp:153-256): every window row_start..row_start+m-1 of the seed is
 // scored by walking down- and upstream in steps of m with a +-2 jitter, counting identical bases on the
 // best-matching diagonal; the best row's bases form the motif.
@@ -228,7 +253,7 @@ int usable_length_host(const HostPlanes &hp, int start, int end, int m) {
 namespace {
 void build_align_jobs_range(const Bases &b, const RibbitRefineParams &prm, const std::vector<RibbitSeed> &dispatch,
                             const int32_t *longest_runs, const int32_t *best_rows, size_t lo, size_t hi,
-                            std::vector<RibbitAlignJob> &jobs, std::string &motif_pool) {
+                            std::vector<RibbitAlignJob> &jobs, std::string &motif_pool, const SmallMotifTable *small) {
     std::vector<uint32_t> classes;
     std::vector<int> starts, ends;
     for (size_t i = lo; i < hi; ++i) {
@@ -243,7 +268,8 @@ void build_align_jobs_range(const Bases &b, const RibbitRefineParams &prm, const
         job.motif_length = m;
         if (m <= 10) {
             classes.clear(); starts.clear(); ends.clear();
-            discover_small_motifs(b, seed.start, seq_len, m, prm.min_length[m], prm.perfect_units[m], classes, starts, ends);
+            if (!small_motifs_from_table(small, i, prm.min_length[m], prm.perfect_units[m], classes, starts, ends))
+                discover_small_motifs(b, seed.start, seq_len, m, prm.min_length[m], prm.perfect_units[m], classes, starts, ends);
             for (size_t k = 0; k < classes.size(); ++k) {
                 Wide unit; unit.limb[0] = classes[k];
                 job.atomicity = small_atomicity(classes[k], m);
@@ -274,13 +300,15 @@ void build_align_jobs_range(const Bases &b, const RibbitRefineParams &prm, const
 
 void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const std::vector<RibbitSeed> &dispatch,
                       const int32_t *longest_runs, const int32_t *best_rows, std::vector<RibbitAlignJob> &jobs,
-                      std::string &motif_pool, unsigned host_threads) {
+                      std::string &motif_pool, unsigned host_threads, size_t seed_lo, size_t seed_hi, const SmallMotifTable *small) {
     jobs.clear();
     motif_pool.clear();
     const Bases b(hp);
-    const size_t n = dispatch.size();
+    seed_hi = std::min(seed_hi, dispatch.size());
+    seed_lo = std::min(seed_lo, seed_hi);
+    const size_t n = seed_hi - seed_lo;
     const unsigned threads = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads ? host_threads : 1, n / 1024 + 1));
-    if (threads == 1) { build_align_jobs_range(b, prm, dispatch, longest_runs, best_rows, 0, n, jobs, motif_pool); return; }
+    if (threads == 1) { build_align_jobs_range(b, prm, dispatch, longest_runs, best_rows, seed_lo, seed_hi, jobs, motif_pool, small); return; }
     // seeds are independent here: chunks on worker threads, concatenated in seed order with the motif offsets rebased
     const size_t chunk = 2048, nchunks = (n + chunk - 1) / chunk;
     std::vector<std::vector<RibbitAlignJob>> part_jobs(nchunks);
@@ -290,7 +318,7 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
     for (unsigned t = 0; t < threads; ++t)
         pool.emplace_back([&]() {
             for (size_t c; (c = next.fetch_add(1)) < nchunks;)
-                build_align_jobs_range(b, prm, dispatch, longest_runs, best_rows, c * chunk, std::min(n, (c + 1) * chunk), part_jobs[c], part_pool[c]);
+                build_align_jobs_range(b, prm, dispatch, longest_runs, best_rows, seed_lo + c * chunk, seed_lo + std::min(n, (c + 1) * chunk), part_jobs[c], part_pool[c], small);
         });
     for (std::thread &th : pool) th.join();
     for (size_t c = 0; c < nchunks; ++c) {
@@ -306,7 +334,7 @@ namespace {
 
 // RIBBIT_PROFILE=1: wall-clock split of the refinement stages on stderr (summed over the worker threads)
 std::atomic<long long> g_t_align{0}, g_t_small{0}, g_t_long{0};       // nanoseconds
-std::atomic<long> g_n_align{0}, g_n_known{0}, g_n_paths{0};
+std::atomic<long> g_n_align{0}, g_n_known{0}, g_n_paths{0}, g_n_small_device{0}, g_n_small_host{0};
 struct Stopwatch {
     std::atomic<long long> *acc;
     std::chrono::steady_clock::time_point t0;
@@ -463,12 +491,16 @@ struct Writer {
            << (r.end - r.start) / atom << "\t" << r.purity << "\t" << "+\tSEED-" << type << "\t" << r.cigar << "\n";
     }
 
-    void small_seed(const RibbitSeed &seed, int longest) {                              // processSeedMotifWise
+    const SmallMotifTable *small = nullptr;     // possibleMotifs of the dispatched seeds from the GPU (optional)
+    void small_seed(const RibbitSeed &seed, int longest, size_t index) {                // processSeedMotifWise
         const int m = seed.mlen;
         if (longest < prm.continuous_ones_threshold) return;
-        const int seq_len = usable_length(b, seed.start, seed.end, m);
         std::vector<uint32_t> classes; std::vector<int> starts, ends;
-        { Stopwatch sw(&g_t_small); discover_small_motifs(b, seed.start, seq_len, m, prm.min_length[m], prm.perfect_units[m], classes, starts, ends); }
+        {
+            Stopwatch sw(&g_t_small);
+            if (small_motifs_from_table(small, index, prm.min_length[m], prm.perfect_units[m], classes, starts, ends)) g_n_small_device += 1;
+            else { g_n_small_host += 1; discover_small_motifs(b, seed.start, usable_length(b, seed.start, seed.end, m), m, prm.min_length[m], prm.perfect_units[m], classes, starts, ends); }
+        }
         for (size_t k = 0; k < classes.size(); ++k) {
             const int atom = small_atomicity(classes[k], m);
             Wide unit; unit.limb[0] = classes[k];
@@ -514,21 +546,29 @@ struct Writer {
 void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
                    const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
                    const std::string &sequence_id, std::string &bed, unsigned host_threads,
-                   const std::vector<RibbitAlignJob> *jobs, const std::vector<SswEnds> *ends, const std::vector<SswPath> *paths) {
+                   const std::vector<RibbitAlignJob> *jobs, const std::vector<SswEnds> *ends, const std::vector<SswPath> *paths,
+                   size_t seed_lo, size_t seed_hi, bool *order_dependent, const SmallMotifTable *small) {
     const Bases b(hp);
-    // first job of every seed (jobs are in seed order)
+    seed_hi = std::min(seed_hi, dispatch.size());
+    seed_lo = std::min(seed_lo, seed_hi);
+    const size_t n_seeds = seed_hi - seed_lo;
+    // first job of every seed of the range (jobs are in seed order)
     std::vector<uint32_t> job_first;
     if (jobs && ends && ends->size() == jobs->size()) {
-        job_first.assign(dispatch.size() + 1, (uint32_t)jobs->size());
-        for (size_t j = jobs->size(); j-- > 0;) job_first[(size_t)(*jobs)[j].seed_index] = (uint32_t)j;
-        for (size_t i = dispatch.size(); i-- > 0;) job_first[i] = std::min(job_first[i], job_first[i + 1]);
+        job_first.assign(n_seeds + 1, (uint32_t)jobs->size());
+        for (size_t j = jobs->size(); j-- > 0;) {
+            const size_t si = (size_t)(*jobs)[j].seed_index;
+            if (si >= seed_lo && si < seed_hi) job_first[si - seed_lo] = (uint32_t)j;
+        }
+        for (size_t i = n_seeds; i-- > 0;) job_first[i] = std::min(job_first[i], job_first[i + 1]);
     }
     auto run_range = [&](size_t lo, size_t hi, Writer &w) {
         if (!job_first.empty()) { w.jobs = jobs->data(); w.ends = ends->data(); w.paths = (paths && paths->size() == jobs->size()) ? paths->data() : nullptr; }
+        w.small = small;
         for (size_t i = lo; i < hi; ++i) {
             const RibbitSeed &seed = dispatch[i];
-            if (!job_first.empty()) w.begin_seed(job_first[i], job_first[i + 1]);
-            if (seed.mlen <= 10) w.small_seed(seed, longest_runs[i]);
+            if (!job_first.empty()) w.begin_seed(job_first[i - seed_lo], job_first[i - seed_lo + 1]);
+            if (seed.mlen <= 10) w.small_seed(seed, longest_runs[i], i);
             else w.long_seed(seed.start, seed.end, seed.mlen, seed.type, longest_runs[i], best_rows ? best_rows[i] : -1, 0);
         }
     };
@@ -540,13 +580,13 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
     if (!host_threads)
         if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
     threads = std::max(1u, std::min(threads, 256u));
-    if (dispatch.size() < 512) threads = 1;
-    bool sequential = threads == 1;
+    if (n_seeds < 512 && !order_dependent) threads = 1;
+    bool sequential = threads == 1 && !order_dependent;
     if (!sequential) {
         // ~8 chunks per thread (seed costs vary by orders of magnitude), 64..2048 seeds each
-        const size_t chunk = std::min<size_t>(2048, std::max<size_t>(64, dispatch.size() / (threads * 8)));
-        threads = (unsigned)std::min<size_t>(threads, (dispatch.size() + chunk - 1) / chunk);
-        const size_t nchunks = (dispatch.size() + chunk - 1) / chunk;
+        const size_t chunk = std::min<size_t>(2048, std::max<size_t>(64, n_seeds / (threads * 8)));
+        threads = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, (n_seeds + chunk - 1) / chunk));
+        const size_t nchunks = (n_seeds + chunk - 1) / chunk;
         std::vector<std::string> parts(nchunks);
         std::atomic<size_t> next{0};
         std::atomic<bool> empty_seen{false};
@@ -555,23 +595,26 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
             pool.emplace_back([&]() {
                 for (size_t c; (c = next.fetch_add(1)) < nchunks;) {
                     Writer w{b, hp, sequence, prm, sequence_id, {}, {}};
-                    run_range(c * chunk, std::min(dispatch.size(), (c + 1) * chunk), w);
+                    run_range(seed_lo + c * chunk, seed_lo + std::min(n_seeds, (c + 1) * chunk), w);
                     if (w.saw_empty_query) empty_seen = true;
                     parts[c] = w.os.str();
                 }
             });
         for (std::thread &th : pool) th.join();
+        if (empty_seen && order_dependent) { *order_dependent = true; return; }
         if (empty_seen) sequential = true;
         else for (const std::string &p : parts) bed += p;
     }
     if (sequential) {
         Writer w{b, hp, sequence, prm, sequence_id, {}, {}};
-        run_range(0, dispatch.size(), w);
+        run_range(seed_lo, seed_hi, w);
         bed += w.os.str();
     }
     if (std::getenv("RIBBIT_PROFILE"))
-        std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld (%ld with GPU passes, %ld with GPU paths)  (summed over threads) align %.2fs  small-motif discovery %.2fs  long-motif consensus %.2fs\n",
-                     dispatch.size(), threads, g_n_align.load(), g_n_known.load(), g_n_paths.load(), g_t_align.load() * 1e-9, g_t_small.load() * 1e-9, g_t_long.load() * 1e-9);
+        std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld (%ld with GPU passes, %ld with GPU paths)  small-motif seeds %ld from the GPU / %ld on the host  (summed over threads) align %.2fs  small-motif discovery %.2fs  long-motif consensus %.2fs\n",
+                     n_seeds, threads, g_n_align.load(), g_n_known.load(), g_n_paths.load(), g_n_small_device.load(), g_n_small_host.load(), g_t_align.load() * 1e-9, g_t_small.load() * 1e-9, g_t_long.load() * 1e-9);
 }
+
+void small_motif_counters(long &from_device, long &on_host) { from_device = g_n_small_device.load(); on_host = g_n_small_host.load(); }
 
 }  // namespace rb

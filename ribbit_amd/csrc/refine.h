@@ -17,12 +17,25 @@
 
 namespace rb {
 
+// possibleMotifs as the GPU computed it (small_motifs.hip): head = 4 ints per dispatched seed {first record, early
+// reports, classes, flags}, flags != 0: not computed for this seed (the host twin runs); records = 4 words each
+// {class, first start, last end, units}.
+struct SmallMotifTable {
+    const int32_t *head = nullptr;
+    const uint32_t *records = nullptr;
+};
+
 // longest_runs[i] = longestContinuousMatches of dispatch seed i on its composed plane.
 // best_rows (may be null): for seeds with m > 10, the window start mostFrequentLongerMotif selects
 // (computed by long_motif_rows_kernel), or -1 to compute it on the host.
 void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const std::vector<RibbitSeed> &dispatch,
                       const int32_t *longest_runs, const int32_t *best_rows, std::vector<RibbitAlignJob> &jobs,
-                      std::string &motif_pool, unsigned host_threads = 1);
+                      std::string &motif_pool, unsigned host_threads = 1, size_t seed_lo = 0, size_t seed_hi = (size_t)-1,
+                      const SmallMotifTable *small = nullptr);
+// (seed_lo, seed_hi: only the seeds dispatch[seed_lo .. seed_hi); job.seed_index stays an index into dispatch)
+
+// cumulative, process-wide: small-motif seeds refine_to_bed took from a SmallMotifTable / ran possibleMotifs for itself
+void small_motif_counters(long &from_device, long &on_host);
 
 // seed_sequence_length of parse_seed.cpp:342-349: seed + one motif, cut at the first N
 int usable_length_host(const HostPlanes &hp, int start, int end, int m);
@@ -39,7 +52,12 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
                    const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
                    const std::string &sequence_id, std::string &bed, unsigned host_threads = 0,
                    const std::vector<RibbitAlignJob> *jobs = nullptr, const std::vector<SswEnds> *ends = nullptr,
-                   const std::vector<SswPath> *paths = nullptr);
+                   const std::vector<SswPath> *paths = nullptr, size_t seed_lo = 0, size_t seed_hi = (size_t)-1,
+                   bool *order_dependent = nullptr, const SmallMotifTable *small = nullptr);
+// seed_lo, seed_hi: refine the seeds dispatch[seed_lo .. seed_hi) only (jobs, if given, are those of that range).
+// order_dependent (optional): a slice cannot resolve the one order dependence between seeds (an empty query sees the
+// previous seed's CIGAR) on its own; when it meets one it appends nothing, sets the flag and the caller redoes the
+// whole record in one call.
 // jobs / ends (optional): the first-level alignment jobs of build_align_jobs and the end points of their striped
 // passes as the GPU computed them (flag -1 = not computed); such alignments only need the traceback here.
 

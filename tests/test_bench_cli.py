@@ -17,10 +17,11 @@ def test_world_size_that_disagrees_with_gpus_is_refused():
 
 
 def test_gpus_2_without_a_launcher_spawns_two_ranks():
-    """No GPU here, so both ranks stop at "bench.py needs an MI355X" -- twice, which shows two ranks were started -- and the
-    parent leaves with their failure, not with a silent single-process run."""
+    """No GPU here, so the ranks stop at "bench.py needs an MI355X" (the launcher may end the second rank before it has
+    said so: its own failure report shows that ranks were started) and the parent leaves with their failure, not with a
+    silent single-process run."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
                        text=True, timeout=600, cwd=ROOT, env=_env())
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert r.stderr.count("needs an MI355X") >= 2, r.stderr[-2000:]
+    assert r.stderr.count("needs an MI355X") >= 2 or ("needs an MI355X" in r.stderr and "ChildFailedError" in r.stderr), r.stderr[-2000:]

@@ -34,3 +34,62 @@ def test_longest_runs_and_jobs_match_oracle(name, seq, m_lo, m_hi):
         for f in ("seed_index", "seed_type", "motif_length", "atomicity", "query_start", "query_length", "ppr_length", "small"):
             assert np.array_equal(gjobs[f], wjobs[f]), f
         assert [m for _, m in ribbit_amd._jobs_with_motifs(gjobs, gpool)] == [m for _, m in ribbit_amd._jobs_with_motifs(wjobs, wpool)]
+
+
+def _seed_table_checks(sc, seq):
+    """head/records of small_motifs.hip are self-consistent, and refinement takes exactly those seeds from the table"""
+    head, rec = sc.small_motifs()
+    d = sc.dispatch_seeds()
+    assert len(head) == len(d)
+    small = d["mlen"] <= 10
+    assert (head[~small, 3] == -1).all()                       # long motifs never get a device result
+    served = head[:, 3] == 0
+    for i in np.nonzero(served)[0]:
+        first, n_early, n_cls = (int(x) for x in head[i, :3])
+        assert n_cls >= 1 and first + n_early + n_cls <= len(rec)
+        finals = rec[first + n_early:first + n_early + n_cls]
+        assert len(set(int(c) for c in finals[:, 0])) == n_cls  # one record per rotation class
+    before = ribbit_amd.small_motif_counters()
+    sc.refine_bed("x")
+    after = ribbit_amd.small_motif_counters()
+    assert after[0] - before[0] == int(served.sum())
+    assert after[1] - before[1] == int((head[small, 3] > 0).sum())
+    return head
+
+
+def test_small_motif_seeds_are_served_from_the_gpu_table():
+    """... and the few seeds that show more rotation classes than a wavefront has lanes (long impure ones) are flagged and
+    computed by the host twin; the BED text equals the oracle's either way"""
+    name, seq, m_lo, m_hi = simulated_cases()[1]
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc, Oracle(seq, m_lo, m_hi) as o:
+        sc.load_record(seq)
+        head = _seed_table_checks(sc, seq)
+        assert int((head[:, 3] == 0).sum()) > 1000 and 0 < int((head[:, 3] == 1).sum()) < 0.02 * len(head)
+        o.run_all()
+        assert sc.refine_bed("s") == o.refine_bed("s")
+
+
+def test_substitution_rich_seed_of_a_ten_base_motif():
+    """a 10-base repeat with substitutions in two units of three: dozens of rotation classes in one seed, early reports
+    and restarts -- jobs and BED text from the GPU's table equal the oracle's"""
+    rs = np.random.RandomState(5)
+    unit = b"ACGTTGCAGC"
+    units = []
+    for k in range(90):
+        u = bytearray(unit)
+        if k % 3:
+            p = int(rs.randint(0, 10))
+            u[p] = ord(rs.choice([c for c in "ACGT" if c != chr(u[p])]))
+        units.append(bytes(u))
+    flank = bytes(rs.choice(list(b"ACGT"), 300).astype(np.uint8))
+    seq = flank + b"".join(units) + flank[::-1] + b"AC" * 40 + flank + b"".join(units[:30]) + flank
+    with ribbit_amd.Scanner(2, 12) as sc, Oracle(seq, 2, 12) as o:
+        sc.load_record(seq)
+        head = _seed_table_checks(sc, seq)
+        assert (head[:, 3] == 0).any() and int(head[head[:, 3] == 0, 2].max()) >= 10
+        o.run_all()
+        wjobs, wpool = o.refine_jobs()
+        gjobs, gpool = sc.refine_jobs()
+        for f in ("seed_index", "atomicity", "query_start", "query_length", "ppr_length", "small"):
+            assert np.array_equal(gjobs[f], wjobs[f]), f
+        assert sc.refine_bed("s") == o.refine_bed("s")
