@@ -1,0 +1,44 @@
+"""Whole FASTA->BED path on ONE record of 64 Mbp (BASELINE configs[2]'s shape: N blocks, lower case, motifs 2..100;
+RIBBIT_TEST_BASES sets another size) against the oracle pipeline run on the same whole record, byte for byte.
+The oracle needs ~5 s per Mbp on one core (5-6 minutes here), in a spawned process that never touches the GPU; the GPU
+path takes seconds.  A line a minute goes to the terminal and to gpurun_out/ so that the wait is not taken for a hang."""
+import multiprocessing
+import os
+import time
+
+import pytest
+
+import ribbit_amd
+import segments
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_whole_path_on_a_64_megabase_record_matches_oracle(capsys):
+    total = int(os.environ.get("RIBBIT_TEST_BASES", "64000000"))
+    with multiprocessing.get_context("spawn").Pool(1) as pool:
+        pending = pool.apply_async(segments.oracle_bed_of_simulated_record, ((total, 500, "chr"),))
+        record = segments.simulated_record(total, 500)
+        assert len(record) >= total
+        t0 = time.time()
+        with ribbit_amd.Scanner(2, 100) as sc:
+            sc.load_record(record)
+            got = sc.refine_bed("chr")
+        gpu_s = time.time() - t0
+        del record
+        progress = os.path.join(ROOT, "gpurun_out", "large_test_progress.log")
+        while not pending.ready():
+            pending.wait(60)
+            line = f"[64-Mbp whole-path test] GPU path done in {gpu_s:.1f} s ({got.count(chr(10))} rows); oracle running for {time.time() - t0:.0f} s"
+            with capsys.disabled():
+                print(line, flush=True)
+            if os.path.isdir(os.path.dirname(progress)):
+                with open(progress, "a") as f:
+                    f.write(line + "\n")
+        want = pending.get()
+    assert want.count("\n") > 9000 * (total // 1_000_000)
+    if got != want:                      # name the first differing row instead of dumping two 60-MB strings
+        g, w = got.splitlines(), want.splitlines()
+        k = next((i for i, (a, b) in enumerate(zip(g, w)) if a != b), min(len(g), len(w)))
+        pytest.fail(f"rows {len(g)} vs {len(w)}; first difference at row {k}: {g[k] if k < len(g) else None!r} vs {w[k] if k < len(w) else None!r}")
