@@ -41,8 +41,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 WORKLOAD_BASES = 100_000_000
 M_LO, M_HI = 2, 100
 ALGO_BYTES_PER_BASE = 0.375      # 2 code bits + 1 N bit per base read by the scan kernel
-ALIGNBIT_SHARE = 0.31            # v_alignbit_b32 among the executed VALU instructions of scan_perfect_kernel (from its ISA: 20 of
-                                 # ~66 per motif in the filter pass, 61 of ~175 in a run of the doubling chain)
+def alignbit_share():
+    """v_alignbit_b32 among the executed VALU instructions of scan_perfect_kernel: profiles/isa_mix.json (measured dynamic
+    weights of the kernel's parts x exact content of its branch-free ISA blocks, tools/isa_mix.py) -> (share, bracket, source)"""
+    path = os.path.join(ROOT, "profiles", "isa_mix.json")
+    d = json.load(open(path))
+    return float(d["alignbit_share"]), [float(x) for x in d["alignbit_share_bracket"]], "profiles/isa_mix.json"
+
+
 ALIGNBIT_RATE = 550e9            # wave-instr/s chip-wide at 4 waves/SIMD (profiles/r01b_valu_peak_probe.txt)
 PLAIN_VALU_RATE = 930e9          # v_or / v_xor / v_bitop3, same probe
 CPU_FULL_PATH_BASES = 1_000_000  # whole-path CPU oracle sample (a few seconds)
@@ -595,11 +601,13 @@ def main():
             if rccl_error:
                 out["exchange"]["rccl_error"] = rccl_error
         if n_valu:
-            # the honest limiter: wave-instructions per launch from the committed SQ_INSTS_VALU pass,
-            # ALIGNBIT_SHARE of them v_alignbit (ISA of the hot loop), against the issue rates measured on this part by
+            # the honest limiter: wave-instructions per launch from the committed SQ_INSTS_VALU pass, the share of
+            # v_alignbit among them from profiles/isa_mix.json, against the issue rates measured on this part by
             # tools/probes/valu_peak.hip at the kernel's occupancy
-            roof_ms = (n_valu * ALIGNBIT_SHARE / ALIGNBIT_RATE + n_valu * (1 - ALIGNBIT_SHARE) / PLAIN_VALU_RATE) * 1e3
-            out["roofline"]["valu"] = {"wave_instr_per_launch": n_valu, "alignbit_share": ALIGNBIT_SHARE,
+            share, bracket, source = alignbit_share()
+            roof_ms = (n_valu * share / ALIGNBIT_RATE + n_valu * (1 - share) / PLAIN_VALU_RATE) * 1e3
+            out["roofline"]["valu"] = {"wave_instr_per_launch": n_valu, "alignbit_share": share, "alignbit_share_bracket": bracket,
+                                       "alignbit_share_source": source,
                                        "issue_rate_wave_instr_per_s": {"v_alignbit_b32": ALIGNBIT_RATE, "other": PLAIN_VALU_RATE},
                                        "issue_bound_ms": roof_ms, "frac": roof_ms / kavg}
         if args.stage_kernels:
