@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -88,6 +89,7 @@ def library_path() -> str:
 
 
 _lib = None
+loaded_before_torch = False      # libribbit_hip.so entered the process before torch did: torch.cuda will not work in it
 
 
 def load_library():
@@ -99,6 +101,8 @@ def load_library():
     if not os.path.exists(path):
         raise RibbitHipError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(make -C ribbit_amd/csrc). ribbit_amd has no CPU fallback.")
+    global loaded_before_torch
+    loaded_before_torch = "torch" not in sys.modules      # see ribbit_amd.distributed.device_bytes
     L = C.CDLL(path)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.ribbit_scan_params_default.restype = None

@@ -87,9 +87,16 @@ class _DeviceView:
 
 def device_bytes(ptr: int, nbytes: int, device: torch.device) -> torch.Tensor:
     """uint8 tensor aliasing device memory the C ABI owns (no copy)"""
-    if nbytes == 0 or not ptr:
-        return torch.empty(0, dtype=torch.uint8, device=device)
-    return torch.as_tensor(_DeviceView(ptr, nbytes), device=device)
+    try:
+        if nbytes == 0 or not ptr:
+            return torch.empty(0, dtype=torch.uint8, device=device)
+        return torch.as_tensor(_DeviceView(ptr, nbytes), device=device)
+    except RuntimeError as e:
+        import ribbit_amd
+        if ribbit_amd.loaded_before_torch and "No HIP GPUs" in str(e):
+            raise RuntimeError("torch cannot use the GPU in this process because libribbit_hip.so was loaded before torch was imported "
+                               "(two HIP runtimes, tests/conftest.py): import torch first") from e
+        raise
 
 
 class DeviceGather:
