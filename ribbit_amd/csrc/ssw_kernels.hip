@@ -157,8 +157,8 @@ struct RowMem {
     uint8_t refc[RCAP];                                // reference codes: the motif repeated
 };
 
-// ROWS alignments per workgroup (16 lanes each): four share a wavefront in the two small classes; the large class
-// keeps one alignment's columns (46 KB) in LDS per workgroup of 16 lanes.
+// ROWS alignments per workgroup (16 lanes each): four share a wavefront.  Used for queries of up to 128 bases (a handful of
+// stripes per column); longer ones go to ssw_wave.hip.
 template <int QCAP, int RCAP, int ROWS>
 __global__ __launch_bounds__(16 * ROWS) void ssw_passes_kernel(const uint8_t *__restrict__ ascii, int64_t length,
                                                         const uint8_t *__restrict__ motif_pool,
@@ -220,13 +220,10 @@ __global__ __launch_bounds__(16 * ROWS) void ssw_passes_kernel(const uint8_t *__
 void launch_ssw_passes(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs,
                        const int32_t *order_small, int n_small, const int32_t *order_big, int n_big, const int32_t *order_huge, int n_huge,
                        int mask_len, int32_t *out, hipStream_t stream) {
-    // the longest first: one of them takes as long as thousands of the short ones, which then fill the chip around it
-    if (n_huge > 0)
-        hipLaunchKernelGGL((ssw_passes_kernel<SSW_HUGE_Q, SSW_HUGE_R, 1>), dim3((unsigned)n_huge), dim3(16), 0, stream,
-                           ascii, length, motif_pool, jobs, order_huge, n_huge, mask_len, out);
-    if (n_big > 0)
-        hipLaunchKernelGGL((ssw_passes_kernel<SSW_BIG_Q, SSW_BIG_R, 4>), dim3((unsigned)((n_big + 3) / 4)), dim3(64), 0, stream,
-                           ascii, length, motif_pool, jobs, order_big, n_big, mask_len, out);
+    // queries of more than 128 bases: one wavefront per alignment, stripes spread over its lanes (ssw_wave.hip); the
+    // longest first
+    launch_ssw_passes_wave(ascii, length, motif_pool, jobs, order_huge, n_huge, mask_len, SSW_HUGE_Q, SSW_HUGE_R, out, stream);
+    launch_ssw_passes_wave(ascii, length, motif_pool, jobs, order_big, n_big, mask_len, SSW_BIG_Q, SSW_BIG_R, out, stream);
     if (n_small > 0)
         hipLaunchKernelGGL((ssw_passes_kernel<SSW_SMALL_Q, SSW_SMALL_R, 4>), dim3((unsigned)((n_small + 3) / 4)), dim3(64), 0, stream,
                            ascii, length, motif_pool, jobs, order_small, n_small, mask_len, out);

@@ -188,3 +188,31 @@ def test_gpu_path_search_on_random_pairs_and_unknown_bases():
         motif = _rand(rs, int(rs.randint(1, 200)))
         pairs.append((q, motif, len(motif)))
     _check_whole_alignments(pairs, need_paths=300)
+
+
+def test_wave_kernel_on_long_queries_of_every_kind():
+    """ssw_wave.hip (queries of 129..2048 bases, one wavefront per alignment): low-scoring pairs whose 8-bit pass runs to the
+    end in its wave form, heavily mutated repeats around the 255 overflow threshold, ragged stripe counts (lengths around the
+    multiples of 8, 16 and 64), unknown bases, references shorter and longer than the query -- passes and whole alignments
+    equal the reference library's"""
+    rs = np.random.RandomState(4242)
+    pairs = []
+    for n in list(range(129, 150)) + [159, 160, 161, 191, 192, 193, 255, 256, 257, 511, 512, 513, 640, 1023, 1024, 1025, 2047, 2048]:
+        motif = _rand(rs, int(rs.randint(1, 40)))
+        pure = (motif * (n // len(motif) + 2))[:n]
+        for rate in (0.0, 0.2, 0.45):
+            q = _mutate(rs, pure, rate)[:n]
+            if len(q) > 128:
+                pairs.append((q, motif, min(4096, len(q) + len(motif) + int(0.15 * len(q)))))
+    for _ in range(150):                                   # unrelated query and reference: scores of a few dozen, many lazy-F rounds
+        q = _rand(rs, int(rs.randint(129, 700)), b"ACGTN" if rs.random_sample() < 0.3 else b"ACGT")
+        ref = _rand(rs, int(rs.randint(20, 900)))
+        pairs.append((q, ref, len(ref)))
+    for _ in range(60):                                    # a short repeat inside a long unrelated query, reference far shorter / longer
+        motif = _rand(rs, int(rs.randint(2, 9)))
+        core = _mutate(rs, motif * int(rs.randint(5, 60)), 0.1)
+        q = _rand(rs, int(rs.randint(60, 300))) + core + _rand(rs, int(rs.randint(60, 300)))
+        if 128 < len(q) <= 2048:
+            pairs.append((q, motif, int(rs.choice([40, len(q) // 2, len(q) + 50, 2 * len(q)]))))
+    assert _check_batch(pairs) == len(pairs)
+    _check_whole_alignments(pairs, need_paths=len(pairs) // 2)
