@@ -515,16 +515,19 @@ int perfect_finish(RibbitHandle *h, RibbitRun *dst, size_t dst_cap, RibbitRun *h
     int rc = perfect_collect(h);
     if (rc) return rc;
     const rb::PairLaunch &pr = h->pair;
+    // everything that can fail is checked before the first copy is enqueued: an error return must not leave a DMA in flight
+    // into a buffer the caller may free
     if (half_dst && h->n_halves > half_dst_cap) return fail(RIBBIT_E_OVERFLOW, "%zu half records do not fit the caller's buffer of %zu", h->n_halves, half_dst_cap);
-    if (!half_dst) half_dst = h->h_halves.p;
-    if (h->n_halves)
-        HIP_TRY(hipMemcpyAsync(half_dst, h->d_halves.p, h->n_halves * sizeof(RibbitRun), hipMemcpyDeviceToHost, h->copy_stream));
     if (dst && h->n_runs > dst_cap) return fail(RIBBIT_E_OVERFLOW, "%zu run records do not fit the caller's buffer of %zu", h->n_runs, dst_cap);
     const bool whole = pr.own_lo == 0 && pr.own_hi == INT64_MAX && pr.pos_offset == 0 && !dst;
     if (!dst) {
         if ((rc = h->h_runs.ensure(std::max<size_t>(h->n_runs, 1)))) return rc;
         dst = h->h_runs.p;
     }
+    if (!half_dst) half_dst = h->h_halves.p;
+    if (h->n_halves)
+        HIP_TRY(hipMemcpyAsync(half_dst, h->d_halves.p, h->n_halves * sizeof(RibbitRun), hipMemcpyDeviceToHost, h->copy_stream));
+    h->copy_pending = h->n_halves != 0;      // from here on a failure leaves the wait to the next call on the handle
     if (h->n_runs)
         HIP_TRY(hipMemcpyAsync(dst, h->d_dense.p, h->n_runs * sizeof(RibbitRun), hipMemcpyDeviceToHost, h->copy_stream));
     if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->copy_stream));
@@ -1635,11 +1638,11 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
         h->host_ascii_valid = true;
     }
     h->bed.clear();
-    // Optional (RIBBIT_GPU_SSW=1): first-level alignments set up on host threads, the striped passes of all of them in
-    // one GPU batch, the host then only runs the tracebacks (whole alignments for oversized jobs and the flank
-    // recursion).  Off by default: measured on a 20-Mbp record with 16 host threads the batch (0.4 M alignments: 5 ms
-    // of kernel for the 95 % short ones, 28 ms for the long ones, plus set-up and transfers) costs what it saves,
-    // and with many short records in flight it delays the other records' scans.
+    // Optional (RIBBIT_GPU_SSW=1): first-level alignments set up on host threads, the striped passes and the banded path
+    // search of all of them in GPU batches, the host then only writes the CIGAR text (whole alignments for oversized jobs
+    // and the flank recursion).  Off by default, on measurements: one 20-Mbp record gains 40 ms of 566 in
+    // this function and nothing end to end; 400 records of 50 kb with 8 in flight take 2.28 s instead of 1.3-1.45 s, because
+    // every small record's batches queue on the one GPU and stall that record's workers.
     static const bool gpu_ssw = std::getenv("RIBBIT_GPU_SSW") != nullptr;
     unsigned threads = h->host_threads ? h->host_threads : std::min(std::thread::hardware_concurrency(), 16u);
     if (!h->host_threads)

@@ -92,8 +92,7 @@ void perfect_calls_from_runs(const RibbitRun *runs, size_t n_runs, int64_t lengt
     std::stable_sort(calls.begin(), calls.end(), call_order);
 }
 
-bool replay_window_events(const EventSource &src, const HostPlanes &hp, CallVec &calls, std::string *why, unsigned host_threads,
-                          CompactCalls *compact, int (*min_span)(int)) {
+bool replay_window_events(const EventSource &src, const HostPlanes &hp, CallVec &calls, std::string *why, unsigned host_threads) {
     calls.clear();
     const size_t nm = src.nm;
     const int32_t m_lo = src.m_lo;
@@ -167,21 +166,17 @@ bool replay_window_events(const EventSource &src, const HostPlanes &hp, CallVec 
     // (parallel over buckets): (pos, motif) order by two stable counting sorts.
     const size_t nb = (size_t)ntile + 1;
     std::vector<size_t> bucket_n(nb + 1, 0);          // all calls per bucket
-    std::vector<size_t> kept_n(nb + 1, 0);            // compact mode: calls that pass the length filter, per bucket
     auto bucket_of = [&](const RibbitCall &c) { return (size_t)(c.pos / TILE); };
-    auto passes = [&](const RibbitCall &c) { return c.end - c.start >= min_span(c.mlen); };
     {
         // every worker counts its own calls (hundreds of millions of them on a chromosome), then the counts are added up
-        std::vector<std::vector<uint32_t>> all_w(threads), kept_w(threads);
+        std::vector<std::vector<uint32_t>> all_w(threads);
         std::atomic<bool> beyond{false};
         auto count_worker = [&](unsigned wi) {
             all_w[wi].assign(nb, 0);
-            if (compact) kept_w[wi].assign(nb, 0);
             for (const RibbitCall &c : work[wi].calls) {
                 const size_t bk = bucket_of(c);
                 if (bk >= nb) { beyond = true; return; }
                 ++all_w[wi][bk];
-                if (compact && passes(c)) ++kept_w[wi][bk];
             }
         };
         std::vector<std::thread> pool;
@@ -190,24 +185,13 @@ bool replay_window_events(const EventSource &src, const HostPlanes &hp, CallVec 
         for (std::thread &t : pool) t.join();
         if (beyond) { if (why) *why = "call beyond the end of the record"; return false; }
         for (unsigned wi = 0; wi < threads; ++wi)
-            for (size_t k = 0; k < nb; ++k) {
-                bucket_n[k + 1] += all_w[wi][k];
-                if (compact) kept_n[k + 1] += kept_w[wi][k];
-            }
+            for (size_t k = 0; k < nb; ++k) bucket_n[k + 1] += all_w[wi][k];
     }
-    for (size_t k = 0; k < nb; ++k) { bucket_n[k + 1] += bucket_n[k]; kept_n[k + 1] += kept_n[k]; }
+    for (size_t k = 0; k < nb; ++k) bucket_n[k + 1] += bucket_n[k];
     size_t n_flush = 0;
     for (unsigned wi = 0; wi < threads; ++wi) n_flush += work[wi].flush.size();
-    std::vector<int32_t> bucket_tail;                 // compact mode: pend left over at the end of each bucket
-    if (compact) {
-        calls.clear();
-        compact->calls.resize(kept_n[nb]);
-        compact->pend_before.resize(kept_n[nb]);
-        bucket_tail.assign(nb, -1);
-    } else {
-        calls.reserve(bucket_n[nb] + n_flush);  // the flush is appended below: no second half-gigabyte move
-        calls.resize(bucket_n[nb]);
-    }
+    calls.reserve(bucket_n[nb] + n_flush);      // the flush is appended below: no second half-gigabyte move
+    calls.resize(bucket_n[nb]);
     const double t_count = now();
     std::atomic<size_t> next{0};
     std::atomic<bool> bad{false};
@@ -236,26 +220,8 @@ bool replay_window_events(const EventSource &src, const HostPlanes &hp, CallVec 
             count.assign((size_t)TILE + 1, 0);
             for (const RibbitCall &c : by_motif) ++count[(size_t)(c.pos - base_pos) + 1];
             for (int64_t k = 0; k < TILE; ++k) count[(size_t)k + 1] += count[(size_t)k];
-            if (!compact) {
-                RibbitCall *dst = calls.data() + bucket_n[bk];
-                for (const RibbitCall &c : by_motif) dst[count[(size_t)(c.pos - base_pos)]++] = c;
-                continue;
-            }
-            // compact mode: order the bucket in scratch, then keep the calls that pass the filter, each with the
-            // largest end of the filtered-out calls before it (inside this bucket; the buckets are stitched below)
-            batch.resize(by_motif.size());
-            for (const RibbitCall &c : by_motif) batch[count[(size_t)(c.pos - base_pos)]++] = c;
-            size_t at = kept_n[bk];
-            int32_t pend = -1;
-            for (const RibbitCall &c : batch) {
-                if (!passes(c)) { pend = std::max(pend, c.end); continue; }
-                compact->calls[at] = c;
-                compact->pend_before[at] = pend;
-                pend = -1;
-                ++at;
-            }
-            if (at != kept_n[bk + 1]) { bad = true; return; }
-            bucket_tail[bk] = pend;
+            RibbitCall *dst = calls.data() + bucket_n[bk];
+            for (const RibbitCall &c : by_motif) dst[count[(size_t)(c.pos - base_pos)]++] = c;
         }
     };
     {
@@ -267,28 +233,13 @@ bool replay_window_events(const EventSource &src, const HostPlanes &hp, CallVec 
     if (bad) { if (why) *why = "call generated outside its ordering buckets"; return false; }
     if (profile)
         std::fprintf(stderr, "[window replay] %u threads: state machines %.1f ms, bucket count %.1f ms, ordering %.1f ms, %zu calls%s\n",
-                     threads, t_phase1 - t_begin, t_count - t_phase1, now() - t_count, bucket_n[nb], compact ? " (kept compact)" : "");
+                     threads, t_phase1 - t_begin, t_count - t_phase1, now() - t_count, bucket_n[nb], "");
 
     // the end-of-sequence flush comes last, in motif order
     CallVec flush;
     for (unsigned wi = 0; wi < threads; ++wi) flush.insert(flush.end(), work[wi].flush.begin(), work[wi].flush.end());
     std::stable_sort(flush.begin(), flush.end(), call_order);
-    if (!compact) {
-        calls.insert(calls.end(), flush.begin(), flush.end());
-        return true;
-    }
-    // stitch the buckets: what a bucket leaves pending goes to the first kept call of a later bucket
-    int32_t carry = -1;
-    for (size_t bk = 0; bk < nb; ++bk) {
-        if (kept_n[bk + 1] > kept_n[bk]) {
-            int32_t &first = compact->pend_before[kept_n[bk]];
-            first = std::max(first, carry);
-            carry = -1;
-        }
-        carry = std::max(carry, bucket_tail[bk]);
-    }
-    compact->tail_pend = carry;
-    compact->flush.swap(flush);
+    calls.insert(calls.end(), flush.begin(), flush.end());
     return true;
 }
 

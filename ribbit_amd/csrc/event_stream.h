@@ -60,19 +60,8 @@ void perfect_calls_from_runs(const RibbitRun *runs, size_t n_runs, int64_t lengt
 // Replay of the per-motif window state machines (window_fsm.h), tile by tile, producing the call list in the
 // reference's call order (scan position major, motif minor, end-of-sequence flush last) without a global
 // sort.  O(events + calls).
-// What the seed merges need of a window stage's calls when the full list is not asked for: the calls that pass the
-// stage's length filter (`keep`), in call order, each with the largest `end` among the filtered-out calls that come
-// between it and the previous kept one (those only move the merge's cursors, seed_lists.h: advance_cursor; -1 if
-// none).  tail_pend: the same for the filtered-out calls after the last kept call.  The end-of-sequence flush
-// (at most two calls per motif) is kept whole, in `flush`.
-struct CompactCalls {
-    CallVec calls;
-    std::vector<int32_t> pend_before;
-    int32_t tail_pend = -1;
-    CallVec flush;
-};
-// min_span(mlen): smallest end - start a call of that motif needs to pass the filter
-bool replay_window_events(const EventSource &src, const HostPlanes &hp, CallVec &calls, std::string *why, unsigned host_threads = 0,
-                          CompactCalls *compact = nullptr, int (*min_span)(int) = nullptr);
+// (The single-GPU path runs these state machines on the device, window_stage.hip, and filters the calls there; this host
+// replay serves ribbit_host_scan_from_events, where rank 0 merges the events of several chunks.)
+bool replay_window_events(const EventSource &src, const HostPlanes &hp, CallVec &calls, std::string *why, unsigned host_threads = 0);
 
 }  // namespace rb
