@@ -30,7 +30,7 @@ def test_whole_path_on_a_64_megabase_record_matches_oracle(capsys):
         progress = os.path.join(ROOT, "gpurun_out", "large_test_progress.log")
         while not pending.ready():
             pending.wait(60)
-            line = f"[64-Mbp whole-path test] GPU path done in {gpu_s:.1f} s ({got.count(chr(10))} rows); oracle running for {time.time() - t0:.0f} s"
+            line = f"[whole-path test, {total / 1e6:.0f} Mbp] GPU path done in {gpu_s:.1f} s ({got.count(chr(10))} rows); oracle running for {time.time() - t0:.0f} s"
             with capsys.disabled():
                 print(line, flush=True)
             if os.path.isdir(os.path.dirname(progress)):
