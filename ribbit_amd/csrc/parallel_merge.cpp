@@ -6,6 +6,7 @@
 #include <chrono>
 #include <climits>
 #include <cstdlib>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -76,16 +77,18 @@ struct Coverage {
     std::vector<uint64_t> w;
     int64_t top;      // largest position
     explicit Coverage(int64_t length) : w((size_t)(length / 64 + 2), 0), top(length) {}
+    // (atomic: the intervals are marked by several threads at once, and neighbours in call order share words)
+    void set(int64_t word, uint64_t bits) { __atomic_fetch_or(&w[(size_t)word], bits, __ATOMIC_RELAXED); }
     void mark(int64_t a, int64_t b) {
         a = std::max<int64_t>(a, 0);
         b = std::min<int64_t>(b, top);
         if (b < a) return;
         const int64_t wa = a >> 6, wb = b >> 6;
         const uint64_t lo = ~0ull << (a & 63), hi = ~0ull >> (63 - (b & 63));
-        if (wa == wb) { w[(size_t)wa] |= lo & hi; return; }
-        w[(size_t)wa] |= lo;
-        for (int64_t k = wa + 1; k < wb; ++k) w[(size_t)k] = ~0ull;
-        w[(size_t)wb] |= hi;
+        if (wa == wb) { set(wa, lo & hi); return; }
+        set(wa, lo);
+        for (int64_t k = wa + 1; k < wb; ++k) set(k, ~0ull);
+        set(wb, hi);
     }
     // first uncovered position in [from, to], -1 if none
     int64_t first_clear(int64_t from, int64_t to) const {
@@ -103,10 +106,72 @@ struct Coverage {
     }
 };
 
+// fn(lo, hi, t) on `threads` threads over [0, n) cut into contiguous pieces (piece t = [n t / T, n (t+1) / T))
+// smallest piece worth a thread: 64 K items, or 16 x the smallest range when the test hook has made the ranges tiny (so that
+// the tests that force ranges of 1, 5 and 64 calls also run these scans in many pieces)
+size_t piece_grain() { return std::max<size_t>(1, std::min<size_t>(65536, g_min_range.load() * 16)); }
+unsigned pieces_for(size_t n, unsigned threads) { return (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / piece_grain() + 1)); }
+
+template <class Fn>
+void parallel_pieces(size_t n, unsigned threads, Fn fn) {
+    threads = pieces_for(n, threads);
+    if (threads == 1) { fn((size_t)0, n, 0u); return; }
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(fn, n * t / threads, n * (t + 1) / threads, t);
+    fn((size_t)0, n / threads, 0u);
+    for (std::thread &th : pool) th.join();
+}
+
+// Running extrema over the kept calls, built by two-pass scans on the host threads:
+//   end_before[i]  = largest end of the calls before i (-1 if none): what a cut before call i has on its left;
+//   seen_before[i] = the same with the filtered-out calls' ends (pend) folded in: what the merge's cursors have seen;
+//   start_from[i]  = smallest start of the calls from i on (INT32_MAX at n): what a cut before call i has on its right.
+struct CallExtrema {
+    // plain arrays that only grow: a vector would zero a quarter of a gigabyte on one thread before the scans overwrite it
+    std::unique_ptr<int32_t[]> store;
+    size_t cap = 0;
+    int32_t *end_before = nullptr, *seen_before = nullptr, *start_from = nullptr;
+    void build(const KeptCalls &kc, unsigned threads) {
+        const size_t n = kc.n;
+        if (n + 1 > cap) { cap = (n + 1) + (n + 1) / 8; store.reset(new int32_t[3 * cap]); }
+        end_before = store.get(); seen_before = end_before + cap; start_from = seen_before + cap;
+        const unsigned T = pieces_for(n, threads);
+        std::vector<int32_t> top_end(T, -1), top_seen(T, -1), low_start(T, INT32_MAX);
+        parallel_pieces(n, T, [&](size_t lo, size_t hi, unsigned t) {          // pass 1: piece-local scans
+            int32_t e = -1, sn = -1;
+            for (size_t i = lo; i < hi; ++i) {
+                end_before[i] = e; seen_before[i] = sn;
+                e = std::max(e, kc.calls[i].end);
+                sn = std::max(sn, std::max(kc.calls[i].end, kc.pend ? kc.pend[i] : -1));
+            }
+            top_end[t] = e; top_seen[t] = sn;
+            int32_t st = INT32_MAX;
+            for (size_t i = hi; i-- > lo;) { st = std::min(st, kc.calls[i].start); start_from[i] = st; }
+            low_start[t] = st;
+        });
+        std::vector<int32_t> carry_end(T, -1), carry_seen(T, -1), carry_start(T, INT32_MAX);
+        for (unsigned t = 1; t < T; ++t) { carry_end[t] = std::max(carry_end[t - 1], top_end[t - 1]); carry_seen[t] = std::max(carry_seen[t - 1], top_seen[t - 1]); }
+        for (unsigned t = T - 1; t-- > 0;) carry_start[t] = std::min(carry_start[t + 1], low_start[t + 1]);
+        parallel_pieces(n, T, [&](size_t lo, size_t hi, unsigned t) {          // pass 2: the pieces before / after
+            const int32_t ce = carry_end[t], cs = carry_seen[t], cst = carry_start[t];
+            for (size_t i = lo; i < hi; ++i) {
+                end_before[i] = std::max(end_before[i], ce);
+                seen_before[i] = std::max(seen_before[i], cs);
+                start_from[i] = std::min(start_from[i], cst);
+            }
+        });
+        end_before[n] = n ? std::max(carry_end[T - 1], top_end[T - 1]) : -1;
+        seen_before[n] = n ? std::max(carry_seen[T - 1], top_seen[T - 1]) : -1;
+        start_from[n] = INT32_MAX;
+    }
+};
+
 // first call of every range; a range boundary before call i is valid iff some position p, covered by no call and no
-// seed of the static lists, has every earlier call's interval to its left and every later call's to its right
+// seed of the static lists, has every earlier call's interval to its left and every later call's to its right.
+// The coverage bitmap is filled and the running extrema are scanned on the host threads; the search itself looks at
+// the candidates in call order (the first valid one at or after every `per`-th call), as a sequential walk would.
 std::vector<size_t> cut_ranges(const KeptCalls &kc, std::initializer_list<const std::vector<RibbitSeed> *> statics, int64_t length,
-                               size_t want_ranges, std::vector<int> &cut_pos) {
+                               size_t want_ranges, std::vector<int> &cut_pos, unsigned threads, CallExtrema &ext) {
     const size_t n = kc.n;
     std::vector<size_t> first{0};
     cut_pos.assign(1, INT32_MIN);
@@ -114,24 +179,22 @@ std::vector<size_t> cut_ranges(const KeptCalls &kc, std::initializer_list<const 
     const size_t per = std::max(min_range, (n + want_ranges - 1) / std::max<size_t>(want_ranges, 1));
     if (n < 2 * per) return first;
     Coverage cov(length);
-    for (const std::vector<RibbitSeed> *list : statics)
-        for (const RibbitSeed &s : *list) cov.mark(s.start, s.end);
-    for (size_t i = 0; i < n; ++i) cov.mark(kc.calls[i].start, kc.calls[i].end);
-    std::vector<int32_t> later_start(n + 1);
-    later_start[n] = INT32_MAX;
-    for (size_t i = n; i-- > 0;) later_start[i] = std::min(later_start[i + 1], kc.calls[i].start);
-    int32_t earlier_end = -1;
-    size_t next = per;
-    for (size_t i = 0; i < n; ++i) {
-        if (i >= next && n - i >= min_range && (int64_t)earlier_end + 1 <= (int64_t)later_start[i] - 1) {
-            const int64_t p = cov.first_clear((int64_t)earlier_end + 1, (int64_t)later_start[i] - 1);
-            if (p >= 0) {
-                first.push_back(i);
-                cut_pos.push_back((int)p);
-                next = i + per;
-            }
+    for (const std::vector<RibbitSeed> *list : statics) {
+        const std::vector<RibbitSeed> &l = *list;
+        parallel_pieces(l.size(), threads, [&](size_t lo, size_t hi, unsigned) { for (size_t i = lo; i < hi; ++i) cov.mark(l[i].start, l[i].end); });
+    }
+    parallel_pieces(n, threads, [&](size_t lo, size_t hi, unsigned) { for (size_t i = lo; i < hi; ++i) cov.mark(kc.calls[i].start, kc.calls[i].end); });
+    ext.build(kc, threads);
+    for (size_t i = per; i < n && n - i >= min_range;) {
+        const int64_t left = (int64_t)ext.end_before[i] + 1, right = (int64_t)ext.start_from[i] - 1;
+        const int64_t p = left <= right ? cov.first_clear(left, right) : -1;
+        if (p >= 0) {
+            first.push_back(i);
+            cut_pos.push_back((int)p);
+            i += per;
+        } else {
+            ++i;
         }
-        earlier_end = std::max(earlier_end, kc.calls[i].end);
     }
     return first;
 }
@@ -294,7 +357,8 @@ void merge_subst_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, 
     const double t0 = now_ms();
     std::vector<size_t> first{0};
     std::vector<int> cut_pos;
-    if (threads > 1) first = cut_ranges(kc, {&lists.perfect}, lists.length, (size_t)threads * 8, cut_pos);
+    static thread_local CallExtrema ext;      // scratch that lives across the records of the calling thread
+    if (threads > 1) first = cut_ranges(kc, {&lists.perfect}, lists.length, (size_t)threads * 8, cut_pos, threads, ext);
     const size_t nr = first.size();
     st.ranges = (unsigned)nr;
     if (nr == 1) {
@@ -308,9 +372,9 @@ void merge_subst_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, 
     // the cursor every range starts from: a function of the largest end among the earlier calls (advance_cursor)
     std::vector<int> start_cursor(nr, 0);
     {
-        int cur = 0, seen = -1;
-        for (size_t k = 0, i = 0; k < nr; ++k) {
-            for (; i < first[k]; ++i) seen = std::max(seen, std::max(kc.calls[i].end, kc.pend ? kc.pend[i] : -1));
+        int cur = 0;
+        for (size_t k = 0; k < nr; ++k) {
+            const int seen = ext.seen_before[first[k]];
             if (seen >= 0) cur = advance_cursor(lists.perfect, cur, seen);
             start_cursor[k] = cur;
         }
@@ -365,7 +429,8 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
     const double t0 = now_ms();
     std::vector<size_t> first{0};
     std::vector<int> cut_pos;
-    if (threads > 1) first = cut_ranges(kc, {&lists.perfect, &lists.subst}, lists.length, (size_t)threads * 8, cut_pos);
+    static thread_local CallExtrema ext;      // scratch that lives across the records of the calling thread
+    if (threads > 1) first = cut_ranges(kc, {&lists.perfect, &lists.subst}, lists.length, (size_t)threads * 8, cut_pos, threads, ext);
     const size_t nr = first.size();
     st.ranges = (unsigned)nr;
     if (nr == 1) {
@@ -379,9 +444,8 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
     std::vector<Cursor2> start_cursor(nr);
     {
         Cursor2 cur;
-        int seen = -1;
-        for (size_t k = 0, i = 0; k < nr; ++k) {
-            for (; i < first[k]; ++i) seen = std::max(seen, std::max(kc.calls[i].end, kc.pend ? kc.pend[i] : -1));
+        for (size_t k = 0; k < nr; ++k) {
+            const int seen = ext.seen_before[first[k]];
             if (seen >= 0) {
                 cur.perfect = advance_cursor(lists.perfect, cur.perfect, seen);
                 cur.subst = advance_cursor(lists.subst, cur.subst, seen);
@@ -428,6 +492,7 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
         anchored_in_order(lists, kc);
         st.redone_in_order = true;
     } else {
+        const double tc = now_ms();
         size_t total = 0;
         for (const RangeState &r : state) total += r.own.size();
         lists.anchored.clear();
@@ -436,6 +501,7 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
             lists.anchored.insert(lists.anchored.end(), state[k].own.begin() + (k > 0 ? 1 : 0), state[k].own.end());
             lists.guard_hits += state[k].guard_hits;
         }
+        st.concat_ms = now_ms() - tc;
         AnchoredReplay<SeedLists> r{lists, state[nr - 1].cursor};
         r.pending_end = kc.tail_pend;
         r.run(kc.flush, kc.n_flush, lists.length);

@@ -48,7 +48,7 @@ struct MergeStats {
     bool redone_in_order = false;
     long long head_writes = 0;     // Q8 writes to list heads that would change an entry (any: the stage is redone in order)
     bool first_range_empty = false;
-    double prepare_ms = 0.0, merge_ms = 0.0;
+    double prepare_ms = 0.0, merge_ms = 0.0, concat_ms = 0.0;      // concat_ms: the part of merge_ms spent joining the ranges' lists
 };
 
 // lists.subst is rebuilt from kc (lists.perfect as the perfect stage left it)
