@@ -192,11 +192,14 @@ def chr1_full_path(ribbit_amd, bases: int, device: int, traffic: dict):
         for rep in range(2):
             t0 = time.perf_counter()
             sc.load_record_pinned(buf.ptr, bases)
-            perfect_seeds = sc.processShiftXORsPerfect()
+            # copy=False: the lists as the C ABI hands them out (pointers into the library's memory); copying half a
+            # gigabyte of seeds into numpy arrays is the Python mirror's business, not the path's
+            perfect_seeds = sc.processShiftXORsPerfect(copy=False)
             t1 = time.perf_counter()
-            perfect, subst, anchored = sc.processShiftXORsAnchored()
-            dispatch = sc.dispatch_seeds()
+            perfect, subst, anchored = sc.processShiftXORsAnchored(copy=False)
+            dispatch = sc.dispatch_seeds(copy=False)
             t2 = time.perf_counter()
+            n_lists = (int(len(perfect)), int(len(subst)), int(len(anchored)), int(len(dispatch)))
             passes.append({"load_and_perfect_stage_s": t1 - t0, "substitution_and_anchored_stages_s": t2 - t1, "scans_and_merges_s": t2 - t0,
                            "merge_ms": {"substitution": sc.timing_ms(5), "anchored": sc.timing_ms(4)}})
         kern = {"pack_kernel": sc.timing_ms(0), "scan_window_kernel<1>": sc.timing_ms(6), "scan_anchored_kernel": sc.timing_ms(7)}
@@ -211,10 +214,10 @@ def chr1_full_path(ribbit_amd, bases: int, device: int, traffic: dict):
         "passes": passes, "kernel_ms": kern, "scans_and_merges_s": scans, "refinement_and_bed_s": t4 - t3,
         "seconds": scans + (t4 - t3), "value": bases / (scans + (t4 - t3)) / 1e9, "unit": "Gbases/s",
         "scans_and_merges_gbases_per_s": bases / scans / 1e9,
-        "seeds": {"perfect": int(len(perfect)), "substitution": int(len(subst)), "anchored": int(len(anchored))},
-        "dispatched": int(len(dispatch)), "bed_rows": bed.count("\n"),
+        "seeds": {"perfect": n_lists[0], "substitution": n_lists[1], "anchored": n_lists[2]},
+        "dispatched": n_lists[3], "bed_rows": bed.count("\n"),
         "what": "one chromosome-1-sized record, -m 2 -M 100: FASTA record in page-locked memory -> BED text (pass 2 of the scans and "
-                "merges; pass 1, with every allocation, is listed too)"})
+                "merges; pass 1, with every allocation, is listed too); the seed lists are taken as the C ABI returns them, by pointer"})
     roof = {}
     for name, key in (("scan_window_kernel<1>", "scan_window_kernel"), ("scan_anchored_kernel", "scan_anchored_kernel"), ("scan_perfect_kernel", None)):
         ms = kern[name]

@@ -201,6 +201,15 @@ def _copy(ptr, n, dt):
     return np.frombuffer(buf, dtype=dt).copy()
 
 
+def _view(ptr, n, dt):
+    """read-only numpy view of n records at ptr (no copy)"""
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dt)
+    v = np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(ptr), dtype=dt)
+    v.flags.writeable = False
+    return v
+
+
 def pack_planes(sequence: bytes, max_motif: int):
     """numpy packing of a record into (hi, lo, brk) uint32 planes with the padding
     ribbit_host_replay_calls needs.  Host-side helper for replaying call lists that came from
@@ -564,11 +573,7 @@ class Scanner:
     def _list(self, fn, dt, copy=True):
         p, n = C.c_void_p(), C.c_size_t()
         self._check(fn(self._h, C.byref(p), C.byref(n)))
-        if copy or n.value == 0:
-            return _copy(p.value, n.value, dt)
-        view = np.frombuffer((C.c_char * (n.value * dt.itemsize)).from_address(p.value), dtype=dt)
-        view.flags.writeable = False
-        return view
+        return _copy(p.value, n.value, dt) if copy else _view(p.value, n.value, dt)
 
     # parse_perfect_shiftxor.cpp:146-226 ---------------------------------------------------
     def scan_perfect_runs(self, copy=True):
@@ -579,8 +584,9 @@ class Scanner:
     def perfect_calls(self):
         return self._list(self._L.ribbit_hip_perfect_calls, CALL_DT)
 
-    def processShiftXORsPerfect(self):
-        return self._list(self._L.ribbit_hip_seeds_perfect, SEED_DT)
+    def processShiftXORsPerfect(self, copy=True):
+        """copy=False: a read-only view of the library's list, valid until the next call on this Scanner (what a C caller gets)"""
+        return self._list(self._L.ribbit_hip_seeds_perfect, SEED_DT, copy)
 
     # parse_substitute_shiftxor.cpp:391-577 ------------------------------------------------
     def subst_calls(self):
@@ -596,18 +602,21 @@ class Scanner:
     def anchored_calls(self):
         return self._list(self._L.ribbit_hip_anchored_calls, CALL_DT)
 
-    def processShiftXORsAnchored(self):
-        """-> (perfect, substitution, anchored seed lists as the anchored stage leaves them)"""
+    def processShiftXORsAnchored(self, copy=True):
+        """-> (perfect, substitution, anchored seed lists as the anchored stage leaves them); copy=False: read-only views of
+        the library's lists, valid until the next call on this Scanner (what a C caller gets: three pointers)"""
         ptrs = [C.c_void_p() for _ in range(3)]
         ns = [C.c_size_t() for _ in range(3)]
         args = []
         for p, n in zip(ptrs, ns):
             args += [C.byref(p), C.byref(n)]
         self._check(self._L.ribbit_hip_seeds_anchored(self._h, *args))
-        return tuple(_copy(p.value, n.value, SEED_DT) for p, n in zip(ptrs, ns))
+        if copy:
+            return tuple(_copy(p.value, n.value, SEED_DT) for p, n in zip(ptrs, ns))
+        return tuple(_view(p.value, n.value, SEED_DT) for p, n in zip(ptrs, ns))
 
-    def dispatch_seeds(self):
-        return self._list(self._L.ribbit_hip_dispatch_seeds, SEED_DT)
+    def dispatch_seeds(self, copy=True):
+        return self._list(self._L.ribbit_hip_dispatch_seeds, SEED_DT, copy)
 
     # parse_seed.cpp:26-44 (batched on the GPU), parse_smallmotif_seed.cpp:76-270, parse_seed.cpp:153-404 ----
     def seed_longest_runs(self):
