@@ -438,7 +438,9 @@ void ribbit_debug_last_merge(int stage, int32_t out[5]);
  * result (m > 10, filtered out by the continuous-ones threshold: -1; more than 64 classes or reports: 1; record arena
  * full: 2) and the library runs the host twin for it.  records: 4 words each {rotation class, first start, last end,
  * units}: a seed's early reports (already filtered by MINIMUM_LENGTH / PERFECT_UNITS, in the reference's push order),
- * then all its classes in order of first appearance with their final state.  Valid until the next call on the handle. */
+ * then its classes with their final state: all of them in order of first appearance when two or more pass the filters
+ * at the seed's end (the reference reports those in its unordered_map's iteration order, which every key determines),
+ * otherwise only the one that passes, or none.  Valid until the next call on the handle. */
 int ribbit_hip_small_motifs(RibbitHandle *h, const RibbitRefineParams *prm, const int32_t **head, size_t *n_seeds,
                             const uint32_t **records, size_t *n_records);
 /* Test hook: cumulative, process-wide: small-motif seeds that refinement took from the GPU's table / computed on the host. */

@@ -1027,8 +1027,10 @@ int build_small_motifs(RibbitHandle *h, const RibbitRefineParams &prm) {
             lim.min_length[m] = prm.min_length[m];
             lim.min_units[m] = prm.perfect_units[m];
         }
-        // room for eight records a seed and a million more; a seed that finds the arena full is left to the host
-        const size_t cap = std::min<size_t>(8 * jobs.size() + (1u << 20), 0x7fffffffu);
+        // room for four records a seed (0.43 on average on the simulated 20-Mbp record: early reports, the one reported
+        // survivor, and all classes only for the seeds with two or more) and a million more; a seed that finds the arena
+        // full is left to the host
+        const size_t cap = std::min<size_t>(4 * jobs.size() + (1u << 20), 0x7fffffffu);
         if ((rc = h->d_sym.ensure((size_t)h->length + 16)) || (rc = h->d_seeds.ensure(jobs.size())) || (rc = h->d_small_head.ensure(4 * n)) ||
             (rc = h->d_small_records.ensure(4 * cap)) || (rc = h->d_small_count.ensure(4)))
             return rc;

@@ -41,7 +41,9 @@ __device__ __forceinline__ uint32_t row_min(uint32_t v) {      // minimum over t
 // jobs[s] = {seed start, seed end, m, dispatch index}; head[dispatch index] = {first record, early reports, classes, flags}
 // (flags: 1 = more than 64 classes or early reports, 2 = the record arena is full: the host computes the seed itself);
 // records: {class, first start, last end, units}: the early reports (only those long enough, in the order the reference
-// pushes them), then every class in order of first appearance with its final state.
+// pushes them), then the classes with their final state: all of them, in order of first appearance, when two or more will
+// be reported at the seed's end (the host needs every key to replay the map's order); otherwise just the one that will be,
+// or none.
 __global__ __launch_bounds__(64) void small_motifs_kernel(const uint8_t *__restrict__ sym, int64_t length, const int4 *__restrict__ jobs,
                                                           int64_t njobs, SmallMotifLimits lim, uint4 *__restrict__ records,
                                                           uint32_t record_cap, uint32_t *__restrict__ record_count, int4 *__restrict__ head) {
@@ -106,18 +108,27 @@ __global__ __launch_bounds__(64) void small_motifs_kernel(const uint8_t *__restr
     }
     __builtin_amdgcn_wave_barrier();
     int flags = overflow ? 1 : 0;
+    // The survivors' order only matters between those that are reported.  With fewer than two of them (nearly every seed)
+    // the classes that are not reported need not leave the device: one record or none instead of eight on average.
+    const bool reported = lane < count && my_last - my_first >= min_len && my_units >= min_units;
+    const unsigned long long rmask = __ballot(reported);
+    const int n_reported = __popcll(rmask);
+    const bool all_classes = n_reported >= 2;
+    const int n_final = all_classes ? count : n_reported;
     uint32_t base = 0;
-    const uint32_t total = overflow ? 0u : (uint32_t)(n_early + count);
+    const uint32_t total = overflow ? 0u : (uint32_t)(n_early + n_final);
     if (total) {
         if (lane == 0) base = atomicAdd(record_count, total);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if ((uint64_t)base + total > record_cap) flags |= 2;
         else {
             if (lane < n_early) records[base + (uint32_t)lane] = early[lane];
-            if (lane < count) records[base + (uint32_t)n_early + (uint32_t)lane] = make_uint4(my_class, (uint32_t)my_first, (uint32_t)my_last, (uint32_t)my_units);
+            const uint4 mine = make_uint4(my_class, (uint32_t)my_first, (uint32_t)my_last, (uint32_t)my_units);
+            if (all_classes) { if (lane < count) records[base + (uint32_t)n_early + (uint32_t)lane] = mine; }
+            else if (reported) records[base + (uint32_t)n_early] = mine;
         }
     }
-    if (lane == 0) head[jb.w] = make_int4((int)base, n_early, count, flags);
+    if (lane == 0) head[jb.w] = make_int4((int)base, n_early, overflow ? 0 : n_final, flags);
 }
 
 void launch_small_motifs(const uint8_t *sym, int64_t length, const void *jobs, int64_t njobs, const SmallMotifLimits &lim, void *records,
