@@ -140,3 +140,31 @@ def test_long_pairs_match_reference(seed):
         q = _rand(rs, int(rs.randint(0, 60))) + core + _rand(rs, int(rs.randint(0, 60)))
         ref = _rand(rs, int(rs.randint(0, 80))) + core + _rand(rs, int(rs.randint(0, 80)))
         _check(q, ref)
+
+
+def test_alignment_longer_than_the_distance_filter_gets_no_cigar():
+    """Filter().distance_filter = 32767 (ssw_cpp.h:58-63, ssw.c:893-896): an alignment that spans more reference or query
+    than that keeps its scores and end points but no path is searched.  With match +2 the 16-bit score saturates after
+    16384 matching bases, long before that span, so the filter is only reachable by a very impure repeat: 31 % substitutions
+    keep the score of a 36-kb alignment under 32767.  The product returns the reference library's record either way, and a
+    pure repeat of the same length shows the saturation instead (16384 matches, the rest soft-clipped)"""
+    rs = np.random.RandomState(12)
+    motif = _rand(rs, 7)
+    n = 36_000
+    pure = bytearray((motif * (n // len(motif) + 2))[:n])
+    impure = bytearray(pure)
+    for i in np.nonzero(rs.random_sample(n) < 0.31)[0]:
+        impure[i] = int(rs.choice([c for c in b"ACGT" if c != impure[i]]))
+    ref_len = n + 2000
+    ref = motif * (ref_len // len(motif) + 2)
+    spans = []
+    for q in (bytes(impure), bytes(pure)):
+        want, wc = ref_align(q, ref, ref_len)
+        got, gc = ribbit_amd.ssw_align(q, ref, ref_len)
+        assert (got, gc) == (want, wc)
+        spans.append((want["query_end"] - want["query_begin"], want["sw_score"], wc))
+    # filtered: the span exceeds the limit, the score does not saturate, and the CIGAR holds no aligned operation at all
+    # (the wrapper still writes the leading soft clip)
+    assert spans[0][0] > 32767 and spans[0][1] < 32767 and not any(c in spans[0][2] for c in "=XID")
+    # saturated: the score stops at 32767 after 16384 matches, the rest of the query is clipped
+    assert spans[1][1] == 32767 and spans[1][0] == 16383 and spans[1][2].startswith("16384=")
