@@ -367,9 +367,11 @@ def main():
     # are then gathered for the host-side merge on rank 0.  Transports:
     #   rccl  the records stay in HBM and travel GPU-to-GPU over xGMI (grouped send / recv through RCCL) to rank 0's
     #         GPU, then down rank 0's PCIe link once (ribbit_amd.distributed.DeviceGather) -- what north_star names;
-    #         this is the headline;
     #   shm   (one node) every GPU copies its records down its OWN PCIe link into a page-locked segment all ranks map:
-    #         N links in parallel, no second hop.  Timed as well and reported beside the headline.
+    #         N links in parallel, no second hop.
+    # Both are timed in every N > 1 run on one node and both are in the line (`exchange`); `value` is the faster one's.  By
+    # bandwidth arithmetic that should be shm from a few GPUs on (N x 10.6 MB per step through rank 0's one link against N
+    # links side by side) -- arithmetic, not a measurement: the development box has one GPU.
     transports = ["local"]
     if world > 1:
         first = "rccl" if args.exchange == "auto" else args.exchange
@@ -558,10 +560,19 @@ def main():
             assert np.array_equal(got.view("<i4"), want.view("<i4")), "chunk-sharded runs differ from the single-GPU scan"
             print(f"verify: {len(want)} runs identical to the single-GPU scan of the whole record", file=sys.stderr)
 
+    first_transport, first_dt = used_transport, dt
     for name in transports[1:]:
         teardown()
         sec, _r, _k, _p, _g, _c, used = timed_region(name)
         other[used] = {"ms_per_step": sec / args.steps * 1e3, "value": args.bases * world * args.steps / sec / 1e9, "unit": "Gbases/s"}
+        # `value` is the job's throughput: with both transports timed on the same ranks in the same run, it is that of the
+        # faster one (rank 0 decides, every rank timed the same max-over-ranks seconds); both stay in `exchange`
+        if sec < dt:
+            other[first_transport] = {"ms_per_step": first_dt / args.steps * 1e3, "value": args.bases * world * args.steps / first_dt / 1e9, "unit": "Gbases/s"}
+            del other[used]
+            dt, used_transport = sec, used
+    headline_ng = used_transport == "shm"
+    headline_dg = used_transport == "rccl" and device_gather
 
     if rank == 0:
         traffic = n_valu = None
@@ -587,7 +598,7 @@ def main():
                        "bases_per_gpu": args.bases, "min_motif": M_LO, "max_motif": M_HI,
                        "parallelism": (f"one record chunk-sharded x{world} (halos), runs paired on each GPU, gathered for rank 0's host merge "
                                        + ("through page-locked node-shared memory (one PCIe link per GPU)" if headline_ng else
-                                          ("by gather-v of the device-resident records over RCCL / xGMI (grouped send/recv)" if device_gather else "by gather-v over the collective backend")))
+                                          ("by gather-v of the device-resident records over RCCL / xGMI (grouped send/recv)" if headline_dg else "by gather-v over the collective backend")))
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "scan_perfect_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -599,7 +610,8 @@ def main():
             "gpu_side_ms_per_step": float(np.mean(gpu_ms)) if gpu_ms else None,   # scan + pairing kernels + D2H of the runs (HIP events)
         }
         if world > 1:
-            out["exchange"] = {"headline": used_transport, used_transport: {"ms_per_step": dt / args.steps * 1e3, "value": total_bases / dt / 1e9, "unit": "Gbases/s"}}
+            out["exchange"] = {"headline": used_transport, "headline_rule": "the faster of the transports timed in this run",
+                               used_transport: {"ms_per_step": dt / args.steps * 1e3, "value": total_bases / dt / 1e9, "unit": "Gbases/s"}}
             out["exchange"].update(other)
             if rccl_error:
                 out["exchange"]["rccl_error"] = rccl_error

@@ -66,14 +66,21 @@ def test_gpus_flag_without_a_launcher_starts_the_ranks_itself_or_fails():
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
 
 
-@pytest.mark.parametrize("exchange", ["shm", "rccl"])
+@pytest.mark.parametrize("exchange", ["shm", "rccl", "auto"])
 def test_two_ranks_on_one_gpu_reproduce_the_unsharded_runs(exchange):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533" if exchange == "shm" else "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--master-port", {"shm": "29533", "rccl": "29534", "auto": "29535"}[exchange], os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
            "--warmup", "1", "--bases", "2000000", "--backend", "gloo", "--single-device", "--verify", "--exchange", exchange]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _line(r.stdout)
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d and "identical to the single-GPU scan" in r.stderr
-    assert ("node-shared" in d["config"]["parallelism"]) == (exchange == "shm")
+    if exchange == "auto":
+        # both transports timed in the one run, both in the line; `value` is the faster one's and says which
+        ex = d["exchange"]
+        assert set(("rccl", "shm")) <= set(ex) and ex["headline"] in ("rccl", "shm")
+        assert ex[ex["headline"]]["value"] == max(ex["rccl"]["value"], ex["shm"]["value"]) == d["value"]
+        assert ("node-shared" in d["config"]["parallelism"]) == (ex["headline"] == "shm")
+    else:
+        assert ("node-shared" in d["config"]["parallelism"]) == (exchange == "shm")
