@@ -431,6 +431,9 @@ void ribbit_debug_set_merge_min_range(size_t calls);
 /* Test hook: what the last merge of a stage (0 substitution, 1 anchored) on the calling thread did: out = {ranges, ranges
  * merged again after validation, whole stage redone in order (0/1), list-head writes that forced it, first range empty (0/1)}. */
 void ribbit_debug_last_merge(int stage, int32_t out[5]);
+/* Test hook: in how many independent ranges the calling thread's last dispatch merge (fasta_utils.cpp:187-224) ran; 1 = the
+ * sequential merge (no cuts, or a list did not split cleanly at them). */
+int32_t ribbit_debug_last_dispatch_ranges(void);
 
 /* possibleMotifs (parse_smallmotif_seed.cpp:76-188) of every dispatched seed with m <= 10 that reaches it, computed
  * by one GPU launch (small_motifs.hip) -- what ribbit_hip_refine_jobs / ribbit_hip_refine_bed use for those seeds.

@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_last_timing_ms", "ribbit_hip_last_event_count",
     "ribbit_hip_subst_calls", "ribbit_hip_seeds_substitutions",
     "ribbit_host_replay_calls", "ribbit_seed_lists_free", "ribbit_host_longest_runs", "ribbit_debug_set_merge_min_range", "ribbit_debug_last_merge",
-    "ribbit_hip_small_motifs", "ribbit_debug_small_motif_counters",
+    "ribbit_hip_small_motifs", "ribbit_debug_small_motif_counters", "ribbit_debug_last_dispatch_ranges",
     "ribbit_hip_anchored_calls", "ribbit_hip_seeds_anchored", "ribbit_hip_dispatch_seeds", "ribbit_hip_guard_hits",
     "ribbit_hip_debug_stream_read",
     "ribbit_refine_params_default", "ribbit_hip_seed_longest_runs", "ribbit_hip_refine_jobs",
@@ -137,6 +137,8 @@ def load_library():
     L.ribbit_seed_lists_free.argtypes = [C.POINTER(SeedLists)]
     L.ribbit_debug_last_merge.restype = None
     L.ribbit_debug_last_merge.argtypes = [C.c_int, C.POINTER(C.c_int32 * 5)]
+    L.ribbit_debug_last_dispatch_ranges.restype = C.c_int32
+    L.ribbit_debug_last_dispatch_ranges.argtypes = []
     L.ribbit_debug_small_motif_counters.restype = None
     L.ribbit_debug_small_motif_counters.argtypes = [C.POINTER(C.c_int64 * 2)]
     L.ribbit_hip_small_motifs.argtypes = [vp, vp, vp, vp, vp, vp]

@@ -167,7 +167,7 @@ struct RibbitHandle {
     rb::CallVec subst_calls;
     bool anchored_calls_valid = false;
     rb::CallVec anchored_calls;
-    std::vector<RibbitSeed> dispatch;
+    rb::SeedVec dispatch;
     bool longest_valid = false;
     std::vector<int32_t> longest_runs;
     DevBuf<RibbitSeed> d_seeds;
@@ -921,12 +921,12 @@ int advance_to_anchored(RibbitHandle *h) {
     if (full) rb::merge_anchored_stage_full(h->lists, h->anchored_calls.data(), h->anchored_calls.size(), threads, &st);
     else rb::merge_anchored_stage(h->lists, dca, threads, &st);
     const double t1 = now_ms();
-    rb::dispatch_order(h->lists, h->dispatch);
+    const unsigned dispatch_ranges = rb::dispatch_order_ranges(h->lists, st.cut_pos, threads, h->dispatch);
     h->merge_ms = now_ms() - t0;
     static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
     if (profile)
-        std::fprintf(stderr, "[anchored merge] %zu seeds: %u ranges on %u threads%s, preparation %.1f ms, merges %.1f ms (%.1f ms of it joining the ranges' lists), dispatch order %.1f ms\n",
-                     h->lists.anchored.size(), st.ranges, st.threads, st.redone_in_order ? (st.head_writes ? " (REDONE IN ORDER: list-head writes)" : " (REDONE IN ORDER: first range empty)") : "", st.prepare_ms, st.merge_ms, st.concat_ms, now_ms() - t1);
+        std::fprintf(stderr, "[anchored merge] %zu seeds: %u ranges on %u threads%s, preparation %.1f ms, merges %.1f ms (%.1f ms of it joining the ranges' lists), dispatch order %.1f ms in %u ranges\n",
+                     h->lists.anchored.size(), st.ranges, st.threads, st.redone_in_order ? (st.head_writes ? " (REDONE IN ORDER: list-head writes)" : " (REDONE IN ORDER: first range empty)") : "", st.prepare_ms, st.merge_ms, st.concat_ms, now_ms() - t1, dispatch_ranges);
     h->subst_merge_ms = subst_todo ? merge_s : 0.0;
     h->stage_done = STAGE_ANCHORED;
     return RIBBIT_OK;
@@ -961,7 +961,7 @@ int build_best_rows(RibbitHandle *h, const RibbitRefineParams &prm) {
     if (rc) return rc;
     const size_t n = h->dispatch.size();
     h->best_rows.assign(n, -1);
-    std::vector<RibbitSeed> jobs;          // reused as int4 {seed_start, seed_sequence_length, m, dispatch index}
+    rb::SeedVec jobs;          // reused as int4 {seed_start, seed_sequence_length, m, dispatch index}
     for (size_t i = 0; i < n; ++i) {
         const RibbitSeed &s = h->dispatch[i];
         if (s.mlen <= 10 || s.end - s.start < 0.9 * s.mlen || h->longest_runs[i] < prm.continuous_ones_threshold) continue;
@@ -1008,7 +1008,7 @@ int build_small_motifs(RibbitHandle *h, const RibbitRefineParams &prm) {
     const double t0 = now_ms();
     if ((rc = h->small_head.ensure(std::max<size_t>(4 * n, 4)))) return rc;
     h->n_small_records = 0;
-    std::vector<RibbitSeed> jobs;          // reused as int4 {seed start, seed end, m, dispatch index}
+    rb::SeedVec jobs;          // reused as int4 {seed start, seed end, m, dispatch index}
     jobs.reserve(n);
     for (size_t i = 0; i < n; ++i) {
         const RibbitSeed &s = h->dispatch[i];
@@ -1580,7 +1580,7 @@ int ribbit_host_refine_jobs(const RibbitScanParams *params, const RibbitRefinePa
     hp.xa_stride = xa ? (int64_t)xa_stride : 0;
     hp.xa_m_lo = params->min_motif;
     hp.xa_m_hi = params->max_motif;
-    std::vector<RibbitSeed> seeds(dispatch, dispatch + n_dispatch);
+    rb::SeedVec seeds(dispatch, dispatch + n_dispatch);
     std::vector<int32_t> longest(n_dispatch);
     for (size_t i = 0; i < n_dispatch; ++i) longest[i] = rb::longest_run_host(hp, seeds[i].mlen, seeds[i].start, seeds[i].end);
     std::vector<RibbitAlignJob> out;
@@ -1764,7 +1764,7 @@ int ribbit_host_refine_bed(const RibbitScanParams *params, const RibbitRefinePar
     hp.xa_stride = xa ? (int64_t)xa_stride : 0;
     hp.xa_m_lo = params->min_motif;
     hp.xa_m_hi = params->max_motif;
-    std::vector<RibbitSeed> seeds(dispatch, dispatch + n_dispatch);
+    rb::SeedVec seeds(dispatch, dispatch + n_dispatch);
     std::vector<int32_t> longest(n_dispatch);
     for (size_t i = 0; i < n_dispatch; ++i) longest[i] = rb::longest_run_host(hp, seeds[i].mlen, seeds[i].start, seeds[i].end);
     std::string bed;
@@ -1975,6 +1975,8 @@ void ribbit_debug_small_motif_counters(int64_t out[2]) {
     out[0] = a; out[1] = b;
 }
 
+int32_t ribbit_debug_last_dispatch_ranges(void) { return (int32_t)rb::last_dispatch_ranges(); }
+
 void ribbit_debug_last_merge(int stage, int32_t out[5]) {
     const rb::MergeStats st = rb::last_merge_stats(stage);
     out[0] = (int32_t)st.ranges; out[1] = (int32_t)st.ranges_redone; out[2] = st.redone_in_order ? 1 : 0;
@@ -2068,7 +2070,7 @@ int ribbit_host_scan_from_events(const RibbitScanParams *params, int64_t length,
     for (const RibbitCall &c : calls) rb::perfect_add(sl, c.start, c.end, c.mlen);
     if (!rb::replay_window_events(source(ev_subst, cnt_subst, segs), hp, calls, &why)) return fail(RIBBIT_E_INTERNAL, "substitution events: %s", why.c_str());
     rb::merge_subst_stage_full(sl, calls.data(), calls.size(), rb::merge_threads(0));
-    std::vector<RibbitSeed> dispatch;
+    rb::SeedVec dispatch;
     if (cnt_anchored) {
         if (xa) hp.xa.assign(xa, xa + nm * xa_stride);        // else: recomputed slice by slice from the packed planes
         hp.xa_stride = xa ? (int64_t)xa_stride : 0;
@@ -2078,10 +2080,11 @@ int ribbit_host_scan_from_events(const RibbitScanParams *params, int64_t length,
             return hp.has_xa(shift) ? hp.range_count_xa(shift, start, end) : hp.range_count(shift, start, end);
         };
         if (!rb::replay_window_events(source(ev_anchored, cnt_anchored, segs), hp, calls, &why)) return fail(RIBBIT_E_INTERNAL, "anchored events: %s", why.c_str());
-        rb::merge_anchored_stage_full(sl, calls.data(), calls.size(), rb::merge_threads(0));
-        rb::dispatch_order(sl, dispatch);
+        rb::MergeStats st;
+        rb::merge_anchored_stage_full(sl, calls.data(), calls.size(), rb::merge_threads(0), &st);
+        rb::dispatch_order_ranges(sl, st.cut_pos, rb::merge_threads(0), dispatch);
     }
-    auto give = [](const std::vector<RibbitSeed> &v, RibbitSeed **p, size_t *n) {
+    auto give = [](const rb::SeedVec &v, RibbitSeed **p, size_t *n) {
         *n = v.size();
         *p = (RibbitSeed *)std::malloc(std::max<size_t>(v.size(), 1) * sizeof(RibbitSeed));
         if (*p && !v.empty()) std::memcpy(*p, v.data(), v.size() * sizeof(RibbitSeed));
@@ -2158,12 +2161,13 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
             return hp.has_xa(shift) ? hp.range_count_xa(shift, start, end) : hp.range_count(shift, start, end);
         };
     }
-    std::vector<RibbitSeed> dispatch;
+    rb::SeedVec dispatch;
     if (anchored_stage) {
-        rb::merge_anchored_stage_full(sl, anchored_calls, n_anchored_calls, rb::merge_threads(0));
-        rb::dispatch_order(sl, dispatch);
+        rb::MergeStats st;
+        rb::merge_anchored_stage_full(sl, anchored_calls, n_anchored_calls, rb::merge_threads(0), &st);
+        rb::dispatch_order_ranges(sl, st.cut_pos, rb::merge_threads(0), dispatch);
     }
-    auto give = [](const std::vector<RibbitSeed> &v, RibbitSeed **p, size_t *n) {
+    auto give = [](const rb::SeedVec &v, RibbitSeed **p, size_t *n) {
         *n = v.size();
         *p = (RibbitSeed *)std::malloc(std::max<size_t>(v.size(), 1) * sizeof(RibbitSeed));
         if (*p && !v.empty()) std::memcpy(*p, v.data(), v.size() * sizeof(RibbitSeed));

@@ -6,6 +6,7 @@
 #include <chrono>
 #include <climits>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -170,7 +171,7 @@ struct CallExtrema {
 // seed of the static lists, has every earlier call's interval to its left and every later call's to its right.
 // The coverage bitmap is filled and the running extrema are scanned on the host threads; the search itself looks at
 // the candidates in call order (the first valid one at or after every `per`-th call), as a sequential walk would.
-std::vector<size_t> cut_ranges(const KeptCalls &kc, std::initializer_list<const std::vector<RibbitSeed> *> statics, int64_t length,
+std::vector<size_t> cut_ranges(const KeptCalls &kc, std::initializer_list<const SeedVec *> statics, int64_t length,
                                size_t want_ranges, std::vector<int> &cut_pos, unsigned threads, CallExtrema &ext) {
     const size_t n = kc.n;
     std::vector<size_t> first{0};
@@ -179,8 +180,8 @@ std::vector<size_t> cut_ranges(const KeptCalls &kc, std::initializer_list<const 
     const size_t per = std::max(min_range, (n + want_ranges - 1) / std::max<size_t>(want_ranges, 1));
     if (n < 2 * per) return first;
     Coverage cov(length);
-    for (const std::vector<RibbitSeed> *list : statics) {
-        const std::vector<RibbitSeed> &l = *list;
+    for (const SeedVec *list : statics) {
+        const SeedVec &l = *list;
         parallel_pieces(l.size(), threads, [&](size_t lo, size_t hi, unsigned) { for (size_t i = lo; i < hi; ++i) cov.mark(l[i].start, l[i].end); });
     }
     parallel_pieces(n, threads, [&](size_t lo, size_t hi, unsigned) { for (size_t i = lo; i < hi; ++i) cov.mark(kc.calls[i].start, kc.calls[i].end); });
@@ -213,14 +214,24 @@ void run_ranges(size_t n_ranges, unsigned threads, Work work) {
     for (std::thread &t : pool) t.join();
 }
 
+// the ranges' lists, joined in range order (each without its sentinel)
+template <class States>
+void join_ranges(const States &state, SeedVec &out) {
+    size_t total = 0;
+    for (const auto &r : state) total += r.own.size();
+    out.clear();
+    out.reserve(total);
+    for (size_t k = 0; k < state.size(); ++k) out.insert(out.end(), state[k].own.begin() + (k > 0 ? 1 : 0), state[k].own.end());
+}
+
 const RibbitSeed SENTINEL{-1, -1, 0, RIBBIT_RANK_N};   // stands for everything earlier ranges appended: ends before any interval of this range
 
-std::vector<int32_t> types_of(const std::vector<RibbitSeed> &list) {
+std::vector<int32_t> types_of(const SeedVec &list) {
     std::vector<int32_t> t(list.size());
     for (size_t i = 0; i < list.size(); ++i) t[i] = list[i].type;
     return t;
 }
-void restore_types(std::vector<RibbitSeed> &list, const std::vector<int32_t> &t) {
+void restore_types(SeedVec &list, const std::vector<int32_t> &t) {
     for (size_t i = 0; i < list.size(); ++i) list[i].type = t[i];
 }
 
@@ -307,7 +318,7 @@ void replay_subst_calls(SeedLists &lists, const RibbitCall *calls, size_t n) {
 
 // One range's private state: the list it appends to and the logs that let it be validated and redone.
 struct RangeState {
-    std::vector<RibbitSeed> own;                    // the stage's list, this range's part (own[0] = SENTINEL for ranges > 0)
+    SeedVec own;                    // the stage's list, this range's part (own[0] = SENTINEL for ranges > 0)
     std::vector<ListRefs::TypeWrite> undo;
     std::vector<ListRefs::TypeRead> foreign_reads;
     std::vector<ListRefs::HeadWrite> head_writes;
@@ -383,7 +394,7 @@ void merge_subst_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, 
     std::vector<RangeState> state(nr);
     st.prepare_ms = now_ms() - t0;
     const double t1 = now_ms();
-    std::vector<RibbitSeed> no_anchored;
+    SeedVec no_anchored;
     st.ranges_redone = run_and_validate(nr, threads, first, state, [&](size_t k, RangeState &me) {
         ListRefs l(lists.perfect, me.own, no_anchored, lists.range_count, lists.length, lists.max_motif);
         l.undo = &me.undo;
@@ -405,14 +416,8 @@ void merge_subst_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, 
         subst_in_order(lists, kc);
         st.redone_in_order = true;
     } else {
-        size_t total = 0;
-        for (const RangeState &r : state) total += r.own.size();
-        lists.subst.clear();
-        lists.subst.reserve(total);
-        for (size_t k = 0; k < nr; ++k) {
-            lists.subst.insert(lists.subst.end(), state[k].own.begin() + (k > 0 ? 1 : 0), state[k].own.end());
-            lists.guard_hits += state[k].guard_hits;
-        }
+        join_ranges(state, lists.subst);
+        for (size_t k = 0; k < nr; ++k) lists.guard_hits += state[k].guard_hits;
         SubstReplay<SeedLists> r{lists, state[nr - 1].cursor.perfect};
         r.pending_end = kc.tail_pend;
         for (size_t i = 0; i < kc.n_flush; ++i) r.call(kc.flush[i]);
@@ -458,6 +463,7 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
     std::vector<RangeState> state(nr);
     st.prepare_ms = now_ms() - t0;
     const double t1 = now_ms();
+    st.cut_pos = cut_pos;
     st.ranges_redone = run_and_validate(nr, threads, first, state, [&](size_t k, RangeState &me) {
         ListRefs l(lists.perfect, lists.subst, me.own, lists.range_count, lists.length, lists.max_motif);
         l.head_write_log = &me.head_writes;
@@ -493,14 +499,8 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
         st.redone_in_order = true;
     } else {
         const double tc = now_ms();
-        size_t total = 0;
-        for (const RangeState &r : state) total += r.own.size();
-        lists.anchored.clear();
-        lists.anchored.reserve(total);
-        for (size_t k = 0; k < nr; ++k) {
-            lists.anchored.insert(lists.anchored.end(), state[k].own.begin() + (k > 0 ? 1 : 0), state[k].own.end());
-            lists.guard_hits += state[k].guard_hits;
-        }
+        join_ranges(state, lists.anchored);
+        for (size_t k = 0; k < nr; ++k) lists.guard_hits += state[k].guard_hits;
         st.concat_ms = now_ms() - tc;
         AnchoredReplay<SeedLists> r{lists, state[nr - 1].cursor};
         r.pending_end = kc.tail_pend;
@@ -509,6 +509,74 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
     st.merge_ms = now_ms() - t1;
     tl_last_stats[1] = st;
     if (stats) *stats = st;
+}
+
+namespace { thread_local unsigned tl_last_dispatch_ranges = 0; }
+unsigned last_dispatch_ranges() { return tl_last_dispatch_ranges; }
+
+unsigned dispatch_order_ranges(const SeedLists &sl, const std::vector<int> &cut_pos, unsigned threads, SeedVec &out) {
+    const size_t nr = cut_pos.size();
+    threads = resolve_threads(threads);
+    tl_last_dispatch_ranges = 1;
+    if (nr < 2 || threads < 2) { dispatch_order(sl, out); return 1; }
+    const SeedVec *lists[3] = {&sl.perfect, &sl.subst, &sl.anchored};
+    // split[x][k] = first entry of list x that belongs to range k (bisection on start > cut: valid iff the list splits
+    // cleanly, which the workers check)
+    std::vector<size_t> split[3];
+    for (int x = 0; x < 3; ++x) {
+        const SeedVec &l = *lists[x];
+        split[x].assign(nr + 1, l.size());
+        split[x][0] = 0;
+        for (size_t k = 1; k < nr; ++k) {
+            size_t lo = split[x][k - 1], hi = l.size();
+            while (lo < hi) { const size_t mid = (lo + hi) / 2; if (l[mid].start > cut_pos[k]) hi = mid; else lo = mid + 1; }
+            split[x][k] = lo;
+        }
+    }
+    std::vector<SeedVec> part(nr);
+    std::atomic<bool> out_of_place{false};
+    std::atomic<size_t> next{0};
+    auto loop = [&]() {
+        for (size_t k; (k = next.fetch_add(1)) < nr && !out_of_place;) {
+            const int64_t lo = k > 0 ? (int64_t)cut_pos[k] : -1, hi = k + 1 < nr ? (int64_t)cut_pos[k + 1] : INT64_MAX;
+            SeedLists sub;      // slices of the three lists (copies: the merge reads every entry once anyway)
+            SeedVec *dst[3] = {&sub.perfect, &sub.subst, &sub.anchored};
+            for (int x = 0; x < 3 && !out_of_place; ++x) {
+                const SeedVec &l = *lists[x];
+                const size_t a = split[x][k], b = split[x][k + 1];
+                for (size_t i = a; i < b; ++i)
+                    if (!((int64_t)l[i].start > lo && (int64_t)l[i].start < hi)) { out_of_place = true; break; }
+                dst[x]->assign(l.begin() + (long)a, l.begin() + (long)b);
+            }
+            if (out_of_place) return;
+            dispatch_order(sub, part[k]);
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        const unsigned nt = (unsigned)std::min<size_t>(threads, nr);
+        for (unsigned t = 1; t < nt; ++t) pool.emplace_back(loop);
+        loop();
+        for (std::thread &t : pool) t.join();
+    }
+    if (out_of_place) { dispatch_order(sl, out); return 1; }
+    std::vector<size_t> at(nr + 1, 0);
+    for (size_t k = 0; k < nr; ++k) at[k + 1] = at[k] + part[k].size();
+    out.resize(at[nr]);
+    next = 0;
+    auto copy = [&]() {
+        for (size_t k; (k = next.fetch_add(1)) < nr;)
+            if (!part[k].empty()) std::memcpy(out.data() + at[k], part[k].data(), part[k].size() * sizeof(RibbitSeed));
+    };
+    {
+        std::vector<std::thread> pool;
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, at[nr] / 65536 + 1));
+        for (unsigned t = 1; t < nt; ++t) pool.emplace_back(copy);
+        copy();
+        for (std::thread &t : pool) t.join();
+    }
+    tl_last_dispatch_ranges = (unsigned)nr;
+    return (unsigned)nr;
 }
 
 }  // namespace rb

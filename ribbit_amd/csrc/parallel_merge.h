@@ -24,6 +24,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "ribbit_hip.h"
 #include "seed_lists.h"
 
@@ -49,7 +51,17 @@ struct MergeStats {
     long long head_writes = 0;     // Q8 writes to list heads that would change an entry (any: the stage is redone in order)
     bool first_range_empty = false;
     double prepare_ms = 0.0, merge_ms = 0.0, concat_ms = 0.0;      // concat_ms: the part of merge_ms spent joining the ranges' lists
+    std::vector<int> cut_pos;  // the positions the ranges were cut at (first entry INT32_MIN): uncovered by any call or earlier-stage seed
 };
+
+// dispatch_order (seed_lists.h: the 3-way merge of fasta_utils.cpp:187-224) over the ranges between `cut_pos`: a position
+// that no seed of any list covers, with every seed before it in its list lying to its left and every seed after it to
+// its right, splits the merge into independent halves (all heads left of it are smaller than all heads right of it).
+// Whether the lists split that way at the given positions is CHECKED (split index by bisection, then every entry of
+// every slice against its bounds, on the host threads); if any entry is out of place -- or negative, which the
+// reference's unsigned comparison treats as huge -- the sequential merge runs instead.  Returns the number of ranges used.
+unsigned dispatch_order_ranges(const SeedLists &sl, const std::vector<int> &cut_pos, unsigned threads, SeedVec &out);
+unsigned last_dispatch_ranges();      // of the calling thread's last dispatch_order_ranges (1: the sequential merge ran)
 
 // lists.subst is rebuilt from kc (lists.perfect as the perfect stage left it)
 void merge_subst_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, MergeStats *stats = nullptr);

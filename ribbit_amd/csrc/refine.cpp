@@ -251,7 +251,7 @@ int usable_length_host(const HostPlanes &hp, int start, int end, int m) {
 }
 
 namespace {
-void build_align_jobs_range(const Bases &b, const RibbitRefineParams &prm, const std::vector<RibbitSeed> &dispatch,
+void build_align_jobs_range(const Bases &b, const RibbitRefineParams &prm, const SeedVec &dispatch,
                             const int32_t *longest_runs, const int32_t *best_rows, size_t lo, size_t hi,
                             std::vector<RibbitAlignJob> &jobs, std::string &motif_pool, const SmallMotifTable *small) {
     std::vector<uint32_t> classes;
@@ -298,7 +298,7 @@ void build_align_jobs_range(const Bases &b, const RibbitRefineParams &prm, const
 }
 }  // namespace
 
-void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const std::vector<RibbitSeed> &dispatch,
+void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const SeedVec &dispatch,
                       const int32_t *longest_runs, const int32_t *best_rows, std::vector<RibbitAlignJob> &jobs,
                       std::string &motif_pool, unsigned host_threads, size_t seed_lo, size_t seed_hi, const SmallMotifTable *small) {
     jobs.clear();
@@ -544,7 +544,7 @@ struct Writer {
 }  // namespace
 
 void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
-                   const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
+                   const SeedVec &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
                    const std::string &sequence_id, std::string &bed, unsigned host_threads,
                    const std::vector<RibbitAlignJob> *jobs, const std::vector<SswEnds> *ends, const std::vector<SswPath> *paths,
                    size_t seed_lo, size_t seed_hi, bool *order_dependent, const SmallMotifTable *small) {

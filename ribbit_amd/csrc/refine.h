@@ -13,6 +13,7 @@
 
 #include "host_planes.h"
 #include "ribbit_hip.h"
+#include "seed_lists.h"
 #include "ssw_exact.h"
 
 namespace rb {
@@ -28,7 +29,7 @@ struct SmallMotifTable {
 // longest_runs[i] = longestContinuousMatches of dispatch seed i on its composed plane.
 // best_rows (may be null): for seeds with m > 10, the window start mostFrequentLongerMotif selects
 // (computed by long_motif_rows_kernel), or -1 to compute it on the host.
-void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const std::vector<RibbitSeed> &dispatch,
+void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const SeedVec &dispatch,
                       const int32_t *longest_runs, const int32_t *best_rows, std::vector<RibbitAlignJob> &jobs,
                       std::string &motif_pool, unsigned host_threads = 1, size_t seed_lo = 0, size_t seed_hi = (size_t)-1,
                       const SmallMotifTable *small = nullptr);
@@ -49,7 +50,7 @@ int longest_run_host(const HostPlanes &hp, int mlen, int start, int end);
 // (parse_seed.cpp:318-464) for m > 10, alignment by ssw_exact, CIGAR processing (process_cigar.cpp:126-336),
 // and the BED rows (11 tab-separated columns) appended to `bed`.  sequence = the record's bases.
 void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
-                   const std::vector<RibbitSeed> &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
+                   const SeedVec &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
                    const std::string &sequence_id, std::string &bed, unsigned host_threads = 0,
                    const std::vector<RibbitAlignJob> *jobs = nullptr, const std::vector<SswEnds> *ends = nullptr,
                    const std::vector<SswPath> *paths = nullptr, size_t seed_lo = 0, size_t seed_hi = (size_t)-1,

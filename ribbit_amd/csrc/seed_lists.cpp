@@ -22,7 +22,7 @@ inline Rel relate(int ns, int ne, int os, int oe) {
 // tail position with the merged interval (":97,:106,:118 ... return;"), dropping its pending
 // removals; that is the `continue` of the outer loop here.
 void perfect_add(SeedLists &sl, int seed_start, int seed_end, int mlen) {
-    std::vector<RibbitSeed> &list = sl.perfect;
+    SeedVec &list = sl.perfect;
     std::vector<size_t> drop;
     for (;;) {
         drop.clear();
@@ -116,7 +116,7 @@ inline bool keep_identical(const ListRefs &sl, int start, int end, int nested_ml
 
 // :48-116 -- perfect and substitution seeds that may touch [seed_start, ...), larger end first
 void gather_candidates(const ListRefs &sl, int from_index, int seed_start, std::vector<Cand> &out) {
-    const std::vector<RibbitSeed> &P = sl.perfect, &S = sl.subst;
+    const SeedVec &P = sl.perfect, &S = sl.subst;
     out.clear();
     bool more_p = !P.empty(), more_s = !S.empty();
     long pi = from_index, si = (long)S.size() - 1;
@@ -145,7 +145,7 @@ void gather_candidates(const ListRefs &sl, int from_index, int seed_start, std::
 }  // namespace
 
 int subst_add(ListRefs &sl, int seed_start, int seed_end, int mlen, int from_index, int seed_type) {
-    std::vector<RibbitSeed> &P = sl.perfect, &S = sl.subst;
+    SeedVec &P = sl.perfect, &S = sl.subst;
     std::vector<Cand> cands;
     constexpr int RP = RIBBIT_RANK_P, RQ = RIBBIT_RANK_Q, RS = RIBBIT_RANK_S;
 
@@ -282,7 +282,7 @@ inline const RibbitSeed &seed_of(const ListRefs &sl, Src src, int idx) {
 // take entries while their end reaches seed_start; stop (and mark the list done) at the first end
 // below seed_start or at the front of the list.
 template <typename Push>
-void walk_back(const std::vector<RibbitSeed> &list, long &i, int seed_start, Push push) {
+void walk_back(const SeedVec &list, long &i, int seed_start, Push push) {
     for (;;) {
         const int end = list[i].end;
         if (end >= seed_start) { push(i); --i; }
@@ -295,7 +295,7 @@ void walk_back(const std::vector<RibbitSeed> &list, long &i, int seed_start, Pus
 // from its LAST element, i.e. by ascending end -- with the anchored list walked from its end.
 // Divergence D1: an empty substitution list is treated as exhausted (the reference reads it: UB).
 void merge_all_lists(ListRefs &sl, Cursor2 from, int seed_start, std::vector<Cand3> &out) {
-    const std::vector<RibbitSeed> &P = sl.perfect, &S = sl.subst, &A = sl.anchored;
+    const SeedVec &P = sl.perfect, &S = sl.subst, &A = sl.anchored;
     static thread_local std::vector<Cand3> ps;       // scratch, reused across the millions of calls of a record
     ps.clear();
     bool p_done = P.empty(), s_done = false;
@@ -347,7 +347,7 @@ void merge_all_lists(ListRefs &sl, Cursor2 from, int seed_start, std::vector<Can
 }  // namespace
 
 Cursor2 anchored_add(ListRefs &sl, int seed_start, int seed_end, int mlen, const Cursor2 from, int seed_type) {
-    std::vector<RibbitSeed> &P = sl.perfect, &S = sl.subst, &A = sl.anchored;
+    SeedVec &P = sl.perfect, &S = sl.subst, &A = sl.anchored;
     constexpr int RA = RIBBIT_RANK_A, RC = RIBBIT_RANK_C, RP = RIBBIT_RANK_P, RS = RIBBIT_RANK_S, RQ = RIBBIT_RANK_Q;
     struct Child { int idx, mlen, type; };
     static thread_local std::vector<Cand3> cands;    // scratch, reused across the millions of calls of a record
@@ -479,7 +479,7 @@ Cursor2 anchored_add(ListRefs &sl, int seed_start, int seed_end, int mlen, const
             uint32_t prev_start = 0xffffffffu;
             for (size_t j = 0; j < nonfactor_children.size(); ++j) {
                 const int t = nonfactor_children[j].type;
-                const std::vector<RibbitSeed> *src = t == RP ? &P : t == RS ? &S : nullptr;
+                const SeedVec *src = t == RP ? &P : t == RS ? &S : nullptr;
                 if (src) {
                     if (j < src->size()) { o_start = (*src)[j].start; o_mlen = (*src)[j].mlen; o_end = (*src)[j].end; o_rend = o_end + o_mlen; }
                     else ++sl.guard_hits;
@@ -500,7 +500,7 @@ Cursor2 anchored_add(ListRefs &sl, int seed_start, int seed_end, int mlen, const
             for (const Child &ch : factor_children) { prev_of[ch.mlen] = -1; cov_of[ch.mlen] = 0; has_cov[ch.mlen] = 1; }
             for (size_t j = 0; j < factor_children.size(); ++j) {
                 const int t = factor_children[j].type;
-                const std::vector<RibbitSeed> *src = t == RP ? &P : t == RS ? &S : nullptr;
+                const SeedVec *src = t == RP ? &P : t == RS ? &S : nullptr;
                 if (src) {
                     if (j < src->size()) { o_start = (*src)[j].start; o_mlen = (*src)[j].mlen; o_end = (*src)[j].end; o_rend = o_end + o_mlen; }
                     else ++sl.guard_hits;
@@ -517,7 +517,7 @@ Cursor2 anchored_add(ListRefs &sl, int seed_start, int seed_end, int mlen, const
                 mlen = f; seed_type = RC;                                                    // :509
                 for (size_t j = 0; j < factor_children.size(); ++j) {                        // :511-522, stale start/end written back
                     const int t = factor_children[j].type;
-                    std::vector<RibbitSeed> *dst = t == RP ? &P : t == RS ? &S : nullptr;
+                    SeedVec *dst = t == RP ? &P : t == RS ? &S : nullptr;
                     if (!dst) continue;
                     if (j >= dst->size()) { ++sl.guard_hits; continue; }
                     o_mlen = (*dst)[j].mlen;
@@ -538,10 +538,10 @@ Cursor2 anchored_add(ListRefs &sl, int seed_start, int seed_end, int mlen, const
     }
 }
 
-void dispatch_order(const SeedLists &sl, std::vector<RibbitSeed> &out) {
+void dispatch_order(const SeedLists &sl, SeedVec &out) {
     // fasta_utils.cpp:187-224.  `smallest` is a uint64_t compared with int starts; the picked list
     // persists across iterations when no head is smaller (cannot happen for starts >= 0).
-    const std::vector<RibbitSeed> &P = sl.perfect, &S = sl.subst, &A = sl.anchored;
+    const SeedVec &P = sl.perfect, &S = sl.subst, &A = sl.anchored;
     size_t ip = 0, is = 0, ia = 0;
     int pick = -1;
     out.clear();

@@ -11,6 +11,11 @@
 
 namespace rb {
 
+// (Round 2 tried an allocator whose resize() does not zero, so that the ranges of the parallel merges could fill their
+// slices of the joined list on all threads: the joining halved, 90 -> 45 ms at chromosome size, but the merges proper ran
+// 30-90 ms slower with it -- measured with both builds alternating on one box -- so the lists are plain vectors.)
+using SeedVec = std::vector<RibbitSeed>;
+
 // popcount of plane `shift` over [start, end)  (retainNestedSeed's loop); supplied by the caller
 // so that this file has no device dependency (the API layer passes a GPU query).
 using RangeCount = std::function<int(int shift, int start, int end)>;
@@ -18,7 +23,7 @@ using RangeCount = std::function<int(int shift, int start, int end)>;
 struct SeedLists {
     int64_t length = 0;       // bset_size
     int min_motif = 2, max_motif = 100, min_shift = 1;
-    std::vector<RibbitSeed> perfect, subst, anchored;
+    SeedVec perfect, subst, anchored;
     RangeCount range_count;
     int64_t guard_hits = 0;   // defined-divergence guards
 };
@@ -27,7 +32,7 @@ struct SeedLists {
 // position ranges in parallel (parallel_merge.h), a worker appends to a list of its own while the lists of the
 // earlier stages are shared.  Member names follow SeedLists.
 struct ListRefs {
-    std::vector<RibbitSeed> &perfect, &subst, &anchored;
+    SeedVec &perfect, &subst, &anchored;
     const RangeCount &range_count;
     int64_t length;
     int max_motif;
@@ -53,7 +58,7 @@ struct ListRefs {
     // nearest such seed at its cursor, and whether it is pushed decides which candidate the loop sees last: Q8).
     int range_hi = INT32_MAX;
     const int32_t *initial_types_perfect = nullptr, *initial_types_subst = nullptr;
-    ListRefs(std::vector<RibbitSeed> &p, std::vector<RibbitSeed> &s, std::vector<RibbitSeed> &a, const RangeCount &rc, int64_t len, int mm)
+    ListRefs(SeedVec &p, SeedVec &s, SeedVec &a, const RangeCount &rc, int64_t len, int mm)
         : perfect(p), subst(s), anchored(a), range_count(rc), length(len), max_motif(mm) {}
     explicit ListRefs(SeedLists &sl) : perfect(sl.perfect), subst(sl.subst), anchored(sl.anchored), range_count(sl.range_count), length(sl.length), max_motif(sl.max_motif) {}
 };
@@ -71,7 +76,7 @@ inline int anchored_seedlen_cutoff(int mlen) { return mlen >= 10 ? (int)(0.9 * m
 // last element.  advance(advance(i, a), b) == advance(i, max(a, b)) for any list whose starts do not
 // change in between, so a run of calls that only move the cursor (they fail the length filter right
 // after this loop, :44) can be replaced by one advance with the largest seed_end among them.
-inline int advance_cursor(const std::vector<RibbitSeed> &list, int from, int seed_end) {
+inline int advance_cursor(const SeedVec &list, int from, int seed_end) {
     while ((size_t)from < list.size() && list[from].start <= seed_end && (size_t)from != list.size() - 1) ++from;
     return from;
 }
@@ -100,6 +105,6 @@ inline Cursor2 anchored_add(SeedLists &sl, int seed_start, int seed_end, int mle
 }
 
 // 3-way merge by start + filters of fasta_utils.cpp:187-224: the seeds that reach refinement, in order
-void dispatch_order(const SeedLists &sl, std::vector<RibbitSeed> &out);
+void dispatch_order(const SeedLists &sl, SeedVec &out);
 
 }  // namespace rb

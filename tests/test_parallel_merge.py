@@ -39,11 +39,25 @@ def _check(seq, m_lo, m_hi, tag):
         assert np.array_equal(r["anchored"].view("<i4"), o.seeds(LIST_ANCHORED).view("<i4")), tag
         assert np.array_equal(r["dispatch"].view("<i4"), o.dispatch().view("<i4")), tag
         assert r["guard_hits"] == o.guard_hits(), tag
+    lib = ribbit_amd.load_library()
+    merged = (C.c_int32 * 5)()
+    lib.ribbit_debug_last_merge(1, C.byref(merged))
+    return int(merged[0]), int(lib.ribbit_debug_last_dispatch_ranges())       # ranges of the anchored merge, of the dispatch merge
 
 
 @pytest.mark.parametrize("name,seq,m_lo,m_hi", CASES, ids=[c[0] for c in CASES])
 def test_range_parallel_merges_equal_the_oracles_lists(tiny_ranges, name, seq, m_lo, m_hi):
     _check(seq, m_lo, m_hi, name)
+
+
+def test_the_dispatch_merge_runs_over_the_same_cuts(tiny_ranges):
+    """the 3-way dispatch merge splits at the anchored stage's cuts (checked at run time: every list must split cleanly
+    there, else it runs sequentially): on the simulated records it does use them, and the order equals the oracle's"""
+    used = []
+    for name, seq, m_lo, m_hi in simulated_cases():
+        used.append(_check(seq, m_lo, m_hi, name))
+    assert all(d == m or d == 1 for m, d in used), used          # either all of the stage's ranges or the sequential merge
+    assert sum(1 for m, d in used if m > 1 and d == m) >= len(used) // 2, used
 
 
 @pytest.mark.parametrize("block", range(6))
