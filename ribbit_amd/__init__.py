@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_last_timing_ms", "ribbit_hip_last_event_count",
     "ribbit_hip_subst_calls", "ribbit_hip_seeds_substitutions",
     "ribbit_host_replay_calls", "ribbit_seed_lists_free", "ribbit_host_longest_runs", "ribbit_debug_set_merge_min_range", "ribbit_debug_last_merge",
-    "ribbit_hip_small_motifs", "ribbit_debug_small_motif_counters", "ribbit_debug_last_dispatch_ranges",
+    "ribbit_hip_small_motifs", "ribbit_debug_small_motif_counters", "ribbit_debug_last_dispatch_ranges", "ribbit_debug_alignment_counters",
     "ribbit_hip_anchored_calls", "ribbit_hip_seeds_anchored", "ribbit_hip_dispatch_seeds", "ribbit_hip_guard_hits",
     "ribbit_hip_debug_stream_read",
     "ribbit_refine_params_default", "ribbit_hip_seed_longest_runs", "ribbit_hip_refine_jobs",
@@ -139,6 +139,8 @@ def load_library():
     L.ribbit_debug_last_merge.argtypes = [C.c_int, C.POINTER(C.c_int32 * 5)]
     L.ribbit_debug_last_dispatch_ranges.restype = C.c_int32
     L.ribbit_debug_last_dispatch_ranges.argtypes = []
+    L.ribbit_debug_alignment_counters.restype = None
+    L.ribbit_debug_alignment_counters.argtypes = [C.POINTER(C.c_int64 * 3)]
     L.ribbit_debug_small_motif_counters.restype = None
     L.ribbit_debug_small_motif_counters.argtypes = [C.POINTER(C.c_int64 * 2)]
     L.ribbit_hip_small_motifs.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -285,6 +287,14 @@ def ssw_align(query: bytes, ref: bytes, ref_len: int | None = None, mask_len: in
 def _jobs_with_motifs(jobs, pool: bytes):
     """-> list of (job record, motif string)"""
     return [(j, pool[int(j["motif_offset"]):int(j["motif_offset"]) + int(j["atomicity"])].decode()) for j in jobs]
+
+
+def alignment_counters():
+    """(alignments refinement made, of them with GPU passes, with GPU paths), cumulative"""
+    L = load_library()
+    out = (C.c_int64 * 3)()
+    L.ribbit_debug_alignment_counters(C.byref(out))
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def small_motif_counters():

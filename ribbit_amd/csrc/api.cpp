@@ -1640,12 +1640,16 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
         h->host_ascii_valid = true;
     }
     h->bed.clear();
-    // Optional (RIBBIT_GPU_SSW=1): first-level alignments set up on host threads, the striped passes and the banded path
-    // search of all of them in GPU batches, the host then only writes the CIGAR text (whole alignments for oversized jobs
-    // and the flank recursion).  Off by default, on measurements: one 20-Mbp record gains 40 ms of 566 in
-    // this function and nothing end to end; 400 records of 50 kb with 8 in flight take 2.28 s instead of 1.3-1.45 s, because
-    // every small record's batches queue on the one GPU and stall that record's workers.
-    static const bool gpu_ssw = std::getenv("RIBBIT_GPU_SSW") != nullptr;
+    // First-level alignments set up on host threads, the striped passes and the banded path search of all of them in GPU
+    // batches, the host then only writes the CIGAR text (whole alignments for oversized jobs and the flank recursion).
+    // Used for LARGE records only, on measurements (refinement, host only against this path with the long
+    // class in two slices): 2 Mbp 83 / 141 ms, 5 Mbp 144 / 204, 10 Mbp 287 / 320, 20 Mbp 528 / 492, chromosome-1 size
+    // 6.7 / 5.4 s -- a fixed cost of about 0.1 s per record, then a gain that grows with the record; and 400 records of
+    // 50 kb with 8 in flight take 2.28 s instead of 1.3-1.45 s with it.  The switch is the number of dispatched seeds
+    // (1.4 M at 20 Mbp); RIBBIT_GPU_SSW=0 / =1 forces it off / on.
+    constexpr size_t GPU_SSW_MIN_SEEDS = 2000000;
+    static const char *const gpu_ssw_env = std::getenv("RIBBIT_GPU_SSW");
+    const bool gpu_ssw = gpu_ssw_env ? std::atoi(gpu_ssw_env) != 0 : h->dispatch.size() >= GPU_SSW_MIN_SEEDS;
     unsigned threads = h->host_threads ? h->host_threads : std::min(std::thread::hardware_concurrency(), 16u);
     if (!h->host_threads)
         if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
@@ -1666,11 +1670,13 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
             bool ready = false;
             double t_setup = 0, t_passes = 0, t_paths = 0;
         };
-        // Measured (20 Mbp, 16 threads): the batches take work off the workers that the set-up puts back, so
-        // one slice (no overlap) is the default and RIBBIT_SSW_SLICES / RIBBIT_SSW_LARGE are there to measure with.
-        size_t n_slices = 1;
+        // two slices: the second one's batches run while the workers refine the first (more slices repeat the per-batch
+        // costs: 5.4 s in two, 5.8 s in four at chromosome size); the long class (queries of 513..2048 bases, half of
+        // all alignment time) is what makes the path pay.  RIBBIT_SSW_SLICES / RIBBIT_SSW_LARGE=0 are there to measure with.
+        size_t n_slices = 2;
         if (const char *env = std::getenv("RIBBIT_SSW_SLICES")) n_slices = (size_t)std::max(1, std::atoi(env));
-        static const bool large_class = std::getenv("RIBBIT_SSW_LARGE") != nullptr;      // queries of 513..2048 bases on the GPU too
+        static const char *const large_env = std::getenv("RIBBIT_SSW_LARGE");
+        const bool large_class = large_env ? std::atoi(large_env) != 0 : true;
         n_slices = std::min(n_slices, h->dispatch.size());
         std::vector<Slice> slices(n_slices);
         for (size_t c = 0; c < n_slices; ++c) {
@@ -1967,6 +1973,12 @@ int ribbit_hip_small_motifs(RibbitHandle *h, const RibbitRefineParams *prm, cons
     *records = h->small_records.p;
     *n_records = h->n_small_records;
     return RIBBIT_OK;
+}
+
+void ribbit_debug_alignment_counters(int64_t out[3]) {
+    long a = 0, b = 0, c = 0;
+    rb::alignment_counters(a, b, c);
+    out[0] = a; out[1] = b; out[2] = c;
 }
 
 void ribbit_debug_small_motif_counters(int64_t out[2]) {

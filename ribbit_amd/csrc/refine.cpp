@@ -615,6 +615,8 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
                      n_seeds, threads, g_n_align.load(), g_n_known.load(), g_n_paths.load(), g_n_small_device.load(), g_n_small_host.load(), g_t_align.load() * 1e-9, g_t_small.load() * 1e-9, g_t_long.load() * 1e-9);
 }
 
+void alignment_counters(long &all, long &gpu_passes, long &gpu_paths) { all = g_n_align.load(); gpu_passes = g_n_known.load(); gpu_paths = g_n_paths.load(); }
+
 void small_motif_counters(long &from_device, long &on_host) { from_device = g_n_small_device.load(); on_host = g_n_small_host.load(); }
 
 }  // namespace rb

@@ -37,6 +37,8 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
 
 // cumulative, process-wide: small-motif seeds refine_to_bed took from a SmallMotifTable / ran possibleMotifs for itself
 void small_motif_counters(long &from_device, long &on_host);
+// cumulative, process-wide: alignments refine_to_bed made / of them with the striped passes / with the path from the GPU
+void alignment_counters(long &all, long &gpu_passes, long &gpu_paths);
 
 // seed_sequence_length of parse_seed.cpp:342-349: seed + one motif, cut at the first N
 int usable_length_host(const HostPlanes &hp, int start, int end, int m);

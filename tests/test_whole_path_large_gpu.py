@@ -1,7 +1,8 @@
 """Whole FASTA->BED path on ONE record of 64 Mbp (BASELINE configs[2]'s shape: N blocks, lower case, motifs 2..100;
 RIBBIT_TEST_BASES sets another size) against the oracle pipeline run on the same whole record, byte for byte.
 The oracle needs ~5 s per Mbp on one core (5-6 minutes here), in a spawned process that never touches the GPU; the GPU
-path takes seconds.  A line a minute goes to the terminal and to gpurun_out/ so that the wait is not taken for a hang."""
+path takes seconds (for a record this large it includes the batched GPU alignment path, which is on by default from
+two million dispatched seeds: the test checks that it was taken).  A line a minute goes to the terminal and to gpurun_out/ so that the wait is not taken for a hang."""
 import multiprocessing
 import os
 import time
@@ -22,10 +23,15 @@ def test_whole_path_on_a_64_megabase_record_matches_oracle(capsys):
         record = segments.simulated_record(total, 500)
         assert len(record) >= total
         t0 = time.time()
+        before = ribbit_amd.alignment_counters()
         with ribbit_amd.Scanner(2, 100) as sc:
             sc.load_record(record)
             got = sc.refine_bed("chr")
         gpu_s = time.time() - t0
+        made, passes, paths = (b - a for a, b in zip(before, ribbit_amd.alignment_counters()))
+        if total >= 40_000_000 and "RIBBIT_GPU_SSW" not in os.environ:
+            # a record of this size (millions of dispatched seeds) has its alignments batched on the GPU by default
+            assert passes > 0.9 * made and paths > 0.9 * made, (made, passes, paths)
         del record
         progress = os.path.join(ROOT, "gpurun_out", "large_test_progress.log")
         while not pending.ready():
