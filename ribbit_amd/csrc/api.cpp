@@ -1707,7 +1707,9 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
                 rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sl.jobs, sl.pool,
                                      c == 0 ? threads : feed_threads, sl.lo, sl.hi, &small);
                 const double tp = now_ms();
-                sl.rc = run_ssw_passes(h, sl.jobs.data(), sl.jobs.size(), sl.pool.data(), sl.pool.size(), 15, sl.ends, large_class);
+                static const bool fail_later_slices = std::getenv("RIBBIT_DEBUG_FAIL_BATCHES") != nullptr;      // test hook: see below
+                sl.rc = (fail_later_slices && c > 0) ? fail(RIBBIT_E_NOMEM, "forced by RIBBIT_DEBUG_FAIL_BATCHES")
+                                                     : run_ssw_passes(h, sl.jobs.data(), sl.jobs.size(), sl.pool.data(), sl.pool.size(), 15, sl.ends, large_class);
                 const double tq = now_ms();
                 if (!sl.rc) sl.rc = run_ssw_paths(h, sl.jobs.data(), sl.jobs.size(), sl.ends, sl.paths);
                 if (!sl.rc) {
@@ -1743,12 +1745,20 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
         }
         stop = true;
         feeder.join();
+        bool batches_failed = false;
+        if (rc == RIBBIT_E_NOMEM) {
+            // the batches' buffers did not fit (several large records in flight on one GPU): the alignments of this record
+            // run on the host threads instead, with the same result
+            std::fprintf(stderr, "ribbit_hip_refine_bed: GPU alignment batches skipped for this record (%s)\n", g_last_error.c_str());
+            rc = RIBBIT_OK;
+            batches_failed = true;
+        }
         if (rc) return rc;
         if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs in %zu slices: feeder thread set-up %.1f ms, GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms; workers waited %.1f ms for it\n",
                                   n_jobs, n_slices, t_setup, t_passes, t_paths, t_wait);
         t_jobs += t_wait;
-        done = !order_dependent;
-        if (order_dependent) h->bed.clear();               // an empty query somewhere: the whole record in one call (below)
+        done = !order_dependent && !batches_failed;
+        if (!done) h->bed.clear();                         // an empty query somewhere (or no batches): the whole record in one call (below)
     }
     if (!done) {
         t0 = now_ms();

@@ -126,6 +126,27 @@ def test_bed_is_identical_with_the_striped_passes_on_the_gpu(tmp_path):
         assert ("with GPU paths" in r.stderr and ", 0 with GPU paths)" not in r.stderr.split("[refine]")[-1]) == bool(flag)
 
 
+def test_a_record_whose_alignment_batches_do_not_fit_is_aligned_on_the_host(tmp_path):
+    """when a batch's buffers cannot be allocated (several large records in flight on one GPU) the record's alignments run on
+    the host threads instead: same BED, a note on stderr.  RIBBIT_DEBUG_FAIL_BATCHES makes the second slice fail that way,
+    after the first slice's rows have already been written."""
+    import subprocess
+    from cases import simulated_cases
+    from ribbit_amd.simulate import write_fasta
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fa = tmp_path / "in.fa"
+    write_fasta(str(fa), [("sim", simulated_cases()[1][1])])
+    beds = []
+    for extra in ({"RIBBIT_GPU_SSW": "0"}, {"RIBBIT_GPU_SSW": "1", "RIBBIT_DEBUG_FAIL_BATCHES": "1"}):
+        bed = tmp_path / f"out_{len(beds)}.bed"
+        r = subprocess.run([os.path.join(root, "ribbit_amd", "ribbit-hip"), "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "100"],
+                           capture_output=True, text=True, timeout=900, env=dict(os.environ, **extra))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert ("GPU alignment batches skipped" in r.stderr) == ("RIBBIT_DEBUG_FAIL_BATCHES" in extra)
+        beds.append(bed.read_text())
+    assert beds[0] == beds[1] and beds[0].count("\n") > 100
+
+
 def _check_whole_alignments(pairs, need_paths):
     """passes + banded path search on the GPU (ssw_kernels.hip, ssw_path.hip), CIGAR text on the host: everything
     Aligner::Align returns must equal the reference library's"""
