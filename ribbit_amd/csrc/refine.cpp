@@ -335,11 +335,13 @@ namespace {
 // RIBBIT_PROFILE=1: wall-clock split of the refinement stages on stderr (summed over the worker threads)
 std::atomic<long long> g_t_align{0}, g_t_small{0}, g_t_long{0};       // nanoseconds
 std::atomic<long> g_n_align{0}, g_n_known{0}, g_n_paths{0}, g_n_small_device{0}, g_n_small_host{0};
+std::atomic<long> g_n_flank{0};
+std::atomic<long long> g_t_flank{0}, g_t_whole_first{0};      // profile: flank-recursion alignments; whole first-level alignments on the host
 struct Stopwatch {
     std::atomic<long long> *acc;
     std::chrono::steady_clock::time_point t0;
     explicit Stopwatch(std::atomic<long long> *a) : acc(a), t0(std::chrono::steady_clock::now()) {}
-    ~Stopwatch() { acc->fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed); }
+    ~Stopwatch() { if (acc) acc->fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed); }
 };
 
 struct CigarOp { int len; char op; };
@@ -478,6 +480,8 @@ struct Writer {
         SswResult res;
         {
             Stopwatch sw(&g_t_align);
+            Stopwatch sw2(known ? nullptr : (query_start < 0 ? &g_t_flank : &g_t_whole_first));
+            if (query_start < 0) ++g_n_flank;
             ++g_n_align;
             if (known && known_path) { ++g_n_known; ++g_n_paths; ssw_finish_with_path(query.data(), (int)query.size(), ref.data(), ppr_len, *known, *known_path, res); }
             else if (known) { ++g_n_known; ssw_finish(query.data(), (int)query.size(), ref.data(), ppr_len, *known, res); }
@@ -611,8 +615,8 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
         bed += w.os.str();
     }
     if (std::getenv("RIBBIT_PROFILE"))
-        std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld (%ld with GPU passes, %ld with GPU paths)  small-motif seeds %ld from the GPU / %ld on the host  (summed over threads) align %.2fs  small-motif discovery %.2fs  long-motif consensus %.2fs\n",
-                     n_seeds, threads, g_n_align.load(), g_n_known.load(), g_n_paths.load(), g_n_small_device.load(), g_n_small_host.load(), g_t_align.load() * 1e-9, g_t_small.load() * 1e-9, g_t_long.load() * 1e-9);
+        std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld (%ld with GPU passes, %ld with GPU paths)  small-motif seeds %ld from the GPU / %ld on the host  (summed over threads) align %.2fs (of it %.2fs in %ld flank-recursion alignments, %.2fs in first-level alignments done whole on the host)  small-motif discovery %.2fs  long-motif consensus %.2fs\n",
+                     n_seeds, threads, g_n_align.load(), g_n_known.load(), g_n_paths.load(), g_n_small_device.load(), g_n_small_host.load(), g_t_align.load() * 1e-9, g_t_flank.load() * 1e-9, g_n_flank.load(), g_t_whole_first.load() * 1e-9, g_t_small.load() * 1e-9, g_t_long.load() * 1e-9);
 }
 
 void alignment_counters(long &all, long &gpu_passes, long &gpu_paths) { all = g_n_align.load(); gpu_passes = g_n_known.load(); gpu_paths = g_n_paths.load(); }
