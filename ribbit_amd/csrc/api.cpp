@@ -160,6 +160,7 @@ struct RibbitHandle {
     PinnedBuf<uint32_t> h_ws_[2];
     PinnedBuf<uint32_t> h_xa;          // host copy of the composed planes (rb::HostPlanes::xa_view points here)
     hipEvent_t ev_xa = nullptr;        // the copy of the composed planes has landed
+    hipEvent_t ev_ssw = nullptr;       // orders the longest alignment class (on the copy stream) against the compute stream
     bool xa_copy_pending = false;
     int64_t last_streaks = 0, last_calls = 0, last_edge_calls = 0;
     rb::CallVec perfect_calls;
@@ -1121,6 +1122,7 @@ int ribbit_hip_open(const RibbitScanParams *params, int device, RibbitHandle **o
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&h->ev_xa, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&h->ev_ssw, hipEventDisableTiming);
     // The upload stream is created by the first upload that uses it.  Measured (bench.py, three handles on one shared
     // compute stream, same box, alternating runs): with an unused upload stream per handle a step takes 0.267 ms, without
     // 0.245 ms (round 1: 0.243), while the scan kernel's own time is unchanged.  Presumably the extra streams change which
@@ -1160,6 +1162,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     for (int k = 0; k < 2; ++k) { h->h_calls_[k].release(); h->h_flush_[k].release(); h->h_pend_[k].release(); h->h_ws_[k].release(); }
     h->h_xa.release();
     if (h->ev_xa) (void)hipEventDestroy(h->ev_xa);
+    if (h->ev_ssw) (void)hipEventDestroy(h->ev_ssw);
     if (h->ev_up) (void)hipEventDestroy(h->ev_up);
     if (h->ev_busy) (void)hipEventDestroy(h->ev_busy);
     for (int i = 0; i < 4; ++i) if (h->ev_stage[i / 2][i % 2]) (void)hipEventDestroy(h->ev_stage[i / 2][i % 2]);
@@ -1349,27 +1352,30 @@ static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n,
     if (!h->dev_ascii_src) return fail(RIBBIT_E_STATE, "the record's bases are not resident on the device");
     int rc;
     if ((rc = bind_device(h))) return rc;
-    // three size classes, each sorted by work (largest first) so that the alignments of a wavefront are alike
+    // four size classes, each sorted by work (largest first) so that the alignments of a wavefront are alike.  The last one
+    // (queries of 2049..4096 bases: a thousand jobs in a 64-Mbp record, and a third of all its alignment cells) runs on the
+    // handle's copy stream beside the others: one such alignment occupies its wavefront for tens of milliseconds.
     const bool no_huge = !large_class;
-    std::vector<uint64_t> keyed[3];
+    std::vector<uint64_t> keyed[4];
     for (size_t j = 0; j < n; ++j) {
         const RibbitAlignJob &jb = jobs[j];
         int cls;
         if (jb.query_length <= rb::SSW_SMALL_Q && jb.ppr_length <= rb::SSW_SMALL_R) cls = 0;
         else if (jb.query_length <= rb::SSW_BIG_Q && jb.ppr_length <= rb::SSW_BIG_R) cls = 1;
         else if (!no_huge && jb.query_length <= rb::SSW_HUGE_Q && jb.ppr_length <= rb::SSW_HUGE_R) cls = 2;
+        else if (!no_huge && jb.query_length <= rb::SSW_GIANT_Q && jb.ppr_length <= rb::SSW_GIANT_R) cls = 3;
         else { ends[j].flag = -1; continue; }
-        const uint64_t work = (uint64_t)std::max(jb.query_length, 0) * (uint64_t)std::max(jb.ppr_length, 0);      // < 2^23
+        const uint64_t work = (uint64_t)std::max(jb.query_length, 0) * (uint64_t)std::max(jb.ppr_length, 0);      // < 2^25
         keyed[cls].push_back(((0xffffffffull - work) << 32) | (uint64_t)j);
     }
     std::vector<int32_t> order;
-    size_t class_count[3];
-    for (int cls = 2; cls >= 0; --cls) {
+    size_t class_count[4];
+    for (int cls = 3; cls >= 0; --cls) {
         std::sort(keyed[cls].begin(), keyed[cls].end());
         class_count[cls] = keyed[cls].size();
         for (uint64_t k : keyed[cls]) order.push_back((int32_t)(k & 0xffffffffu));
     }
-    const size_t n_huge = class_count[2], n_big = class_count[1], n_small = class_count[0];
+    const size_t n_giant = class_count[3], n_huge = class_count[2], n_big = class_count[1], n_small = class_count[0];
     if (order.empty()) return RIBBIT_OK;
     if ((rc = h->d_ssw_jobs.ensure(n * 9))) return rc;
     if ((rc = h->d_ssw_out.ensure(n * 8))) return rc;
@@ -1379,9 +1385,19 @@ static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n,
     HIP_TRY(hipMemcpyAsync(h->d_ssw_order.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     if (pool_len) HIP_TRY(hipMemcpyAsync(h->d_ssw_pool.p, pool, pool_len, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_ssw_out.p, 0xff, n * 8 * sizeof(int32_t), h->stream));      // flag -1 unless a kernel writes the record
-    rb::launch_ssw_passes(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_order.p + n_huge + n_big, (int)n_small,
-                          h->d_ssw_order.p + n_huge, (int)n_big, h->d_ssw_order.p, (int)n_huge, mask_len, h->d_ssw_out.p, h->stream);
+    if (n_giant) {
+        HIP_TRY(hipEventRecord(h->ev_ssw, h->stream));
+        HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->ev_ssw, 0));
+        rb::launch_ssw_passes_wave(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_order.p, (int)n_giant, mask_len,
+                                   rb::SSW_GIANT_Q, rb::SSW_GIANT_R, h->d_ssw_out.p, h->copy_stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(h->ev_ssw, h->copy_stream));
+    }
+    const int32_t *rest = h->d_ssw_order.p + n_giant;
+    rb::launch_ssw_passes(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, rest + n_huge + n_big, (int)n_small,
+                          rest + n_huge, (int)n_big, rest, (int)n_huge, mask_len, h->d_ssw_out.p, h->stream);
     HIP_TRY(hipGetLastError());
+    if (n_giant) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_ssw, 0));
     HIP_TRY(hipMemcpyAsync(ends.data(), h->d_ssw_out.p, n * sizeof(rb::SswEnds), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return RIBBIT_OK;

@@ -142,7 +142,8 @@ void launch_long_motif_rows(const uint8_t *sym, int64_t length, const void *jobs
 // query = record[query_start, +query_length), reference = the job's motif repeated to ppr_length.  Jobs are launched in
 // three size classes (order_small / order_big / order_huge: job indices, each list sorted by size); out[8*job .. +8) = score,
 // ref_end, query_end, score2, ref_end2, ref_begin, query_begin, flag -- flag -1: too large for its class, not computed.
-constexpr int SSW_SMALL_Q = 128, SSW_SMALL_R = 256, SSW_BIG_Q = 512, SSW_BIG_R = 1024, SSW_HUGE_Q = 2048, SSW_HUGE_R = 4096;
+constexpr int SSW_SMALL_Q = 128, SSW_SMALL_R = 256, SSW_BIG_Q = 512, SSW_BIG_R = 1024, SSW_HUGE_Q = 2048, SSW_HUGE_R = 4096,
+              SSW_GIANT_Q = 4096, SSW_GIANT_R = 8192;      // 61.6 KB of LDS per alignment: the most one workgroup gets by default
 // ssw_wave.hip: the same two passes, one wavefront per alignment (queries of 129..qcap bases, reference up to rcap)
 void launch_ssw_passes_wave(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs, const int32_t *order, int n,
                             int mask_len, int qcap, int rcap, int32_t *out, hipStream_t stream);

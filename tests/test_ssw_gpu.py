@@ -34,7 +34,7 @@ def _check_batch(pairs, mask_len=15):
     n_gpu = 0
     for k, (query, motif, ppr_len) in enumerate(pairs):
         if got[k]["flag"] == -1:
-            assert len(query) > 2048 or ppr_len > 4096, (k, len(query), ppr_len)
+            assert len(query) > 4096 or ppr_len > 8192, (k, len(query), ppr_len)
             continue
         n_gpu += 1
         ref = motif * (ppr_len // len(motif) + 2)
@@ -79,7 +79,7 @@ def test_random_pairs_and_unknown_bases_match_reference_library():
 def test_long_alignments_take_the_16bit_path_and_oversized_jobs_are_left_to_the_host():
     rs = np.random.RandomState(7)
     pairs = []
-    for n in (130, 140, 200, 300, 400, 500, 512, 513, 600, 1500, 2048, 2049, 2500):
+    for n in (130, 140, 200, 300, 400, 500, 512, 513, 600, 1500, 2048, 2049, 2500, 4096, 4097, 5000):
         motif = _rand(rs, int(rs.randint(2, 12)))
         pure = (motif * (n // len(motif) + 2))[:n]
         query = _mutate(rs, pure, 0.05)[:n]
@@ -218,13 +218,13 @@ def test_wave_kernel_on_long_queries_of_every_kind():
     equal the reference library's"""
     rs = np.random.RandomState(4242)
     pairs = []
-    for n in list(range(129, 150)) + [159, 160, 161, 191, 192, 193, 255, 256, 257, 511, 512, 513, 640, 1023, 1024, 1025, 2047, 2048]:
+    for n in list(range(129, 150)) + [159, 160, 161, 191, 192, 193, 255, 256, 257, 511, 512, 513, 640, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 4095, 4096]:
         motif = _rand(rs, int(rs.randint(1, 40)))
         pure = (motif * (n // len(motif) + 2))[:n]
         for rate in (0.0, 0.2, 0.45):
             q = _mutate(rs, pure, rate)[:n]
             if len(q) > 128:
-                pairs.append((q, motif, min(4096, len(q) + len(motif) + int(0.15 * len(q)))))
+                pairs.append((q, motif, min(8192, len(q) + len(motif) + int(0.15 * len(q)))))
     for _ in range(150):                                   # unrelated query and reference: scores of a few dozen, many lazy-F rounds
         q = _rand(rs, int(rs.randint(129, 700)), b"ACGTN" if rs.random_sample() < 0.3 else b"ACGT")
         ref = _rand(rs, int(rs.randint(20, 900)))
