@@ -3,11 +3,13 @@
 // between reading a record and writing its BED rows goes through the C ABI of libribbit_hip.so.
 //
 //   ribbit-hip -i in.fa [-o out.bed] [-m 2] [-M 100] [-p 0.85] [-l N|file] [--min-units N|file] [--perfect-units N|file]
+//              [--devices 0,1,...] [--jobs N]
 //
 // Records are independent (ribbit.cpp:269-280 handles them one after the other); here up to --jobs of them are in
-// flight at once, each on its own handle / HIP streams, so that the upload and GPU scans of one record overlap the
-// host merges and refinement of the others (long-read inputs: thousands of 10-100 kb records).  Output order is the
-// input order.  The file is read by ribbit_fasta_* (block reads, line bodies copied once into page-locked buffers that
+// flight at once PER GPU, each on its own handle / HIP streams, so that the upload and GPU scans of one record overlap
+// the host merges and refinement of the others (long-read inputs: thousands of 10-100 kb records); with --devices the
+// records are dealt over several GPUs, one handle set per device (partitioning by record: no halo, no
+// exchange).  Output order is the input order.  The file is read by ribbit_fasta_* (block reads, line bodies copied once into page-locked buffers that
 // the GPU uploads from asynchronously and refinement reads in place) instead of getline + string +=.
 //
 // Reproduced quirks: -p is accepted and ignored (Q1); without -o the BED rows go to
@@ -42,7 +44,8 @@ struct Options {
     bool has_min_length = false, has_min_units = false, has_perfect_units = false;
     std::string min_length, min_units, perfect_units;
     int device = 0;
-    int jobs = 0;                                 // records in flight; 0 = automatic
+    std::vector<int> devices;                     // --devices / RIBBIT_DEVICES: GPUs the records are dealt over (empty: `device` alone)
+    int jobs = 0;                                 // records in flight PER DEVICE; 0 = automatic
 };
 
 const char *kHelp =
@@ -58,8 +61,11 @@ const char *kHelp =
     "                                with the motif size and the unit cutoff. Default: 2\n"
     "  --perfect-units arg           The minimum number of complete units of the repeat. Integer, or a tab\n"
     "                                separated file with the motif size and the unit cutoff. Default: 2\n"
-    "  --jobs arg                    (ribbit-hip) FASTA records processed side by side. Default: automatic\n"
-    "  --device arg                  (ribbit-hip) GPU ordinal. Default: 0\n";
+    "  --jobs arg                    (ribbit-hip) FASTA records processed side by side on each GPU. Default: automatic\n"
+    "  --device arg                  (ribbit-hip) GPU ordinal. Default: 0\n"
+    "  --devices arg                 (ribbit-hip) GPU ordinals, comma separated (or RIBBIT_DEVICES): the records of the\n"
+    "                                FASTA are dealt over these GPUs, the longest of the look-ahead first; BED rows\n"
+    "                                keep the input order\n";
 
 [[noreturn]] void die(const std::string &msg) {        // argument errors: main thread, before any worker exists
     std::cerr << "ribbit-hip: " << msg << "\n";
@@ -70,11 +76,24 @@ const char *kHelp =
 // handles and returns 1 (exiting from a worker would run static destructors under live threads)
 struct PathError { std::string what; };
 
+bool parse_device_list(const std::string &value, std::vector<int> &out) {
+    out.clear();
+    size_t at = 0;
+    while (at <= value.size()) {
+        const size_t comma = std::min(value.find(',', at), value.size());
+        const std::string item = value.substr(at, comma - at);
+        if (item.empty() || !std::all_of(item.begin(), item.end(), [](unsigned char c) { return std::isdigit(c); })) return false;
+        out.push_back(std::atoi(item.c_str()));
+        at = comma + 1;
+    }
+    return !out.empty();
+}
+
 // returns 0 for --help (the caller exits 1, as the reference does), 1 on success
 int parse_arguments(int argc, char **argv, Options &o) {
     static const std::map<std::string, std::string> longs = {
         {"help", "h"}, {"input-file", "i"}, {"output-file", "o"}, {"min-motif-length", "m"}, {"max-motif-length", "M"},
-        {"purity", "p"}, {"min-length", "l"}, {"min-units", "U"}, {"perfect-units", "P"}, {"device", "D"}, {"jobs", "J"}};
+        {"purity", "p"}, {"min-length", "l"}, {"min-units", "U"}, {"perfect-units", "P"}, {"device", "D"}, {"jobs", "J"}, {"devices", "G"}};
     bool help = false;
     for (int a = 1; a < argc; ++a) {
         std::string arg = argv[a], key, value;
@@ -108,6 +127,7 @@ int parse_arguments(int argc, char **argv, Options &o) {
         else if (key == "P") { o.has_perfect_units = true; o.perfect_units = value; }
         else if (key == "D") o.device = std::atoi(value.c_str());
         else if (key == "J") o.jobs = std::atoi(value.c_str());
+        else if (key == "G") { if (!parse_device_list(value, o.devices)) die("--devices wants a comma separated list of GPU ordinals, got '" + value + "'"); }
     }
     if (help) { std::cerr << kHelp << "\n"; return 0; }                       // ribbit.cpp:114-117
     if (o.fasta.empty()) { std::cerr << "ERROR: Please specify an input fasta file!\n"; return 0; }   // :122-126
@@ -227,18 +247,31 @@ int main(int argc, char **argv) {
 
     RibbitScanParams scan;
     ribbit_scan_params_default(&scan, opt.min_motif, opt.max_motif);
+    // GPUs: --devices, else RIBBIT_DEVICES, else --device alone.  Records are independent (ribbit.cpp:269-280 handles them one
+    // after the other), so several GPUs simply take different records; a device may be listed twice (two handle sets on it).
+    std::vector<int> devices = opt.devices;
+    if (devices.empty())
+        if (const char *env = std::getenv("RIBBIT_DEVICES"))
+            if (!parse_device_list(env, devices)) die(std::string("RIBBIT_DEVICES wants a comma separated list of GPU ordinals, got '") + env + "'");
+    if (devices.empty()) devices.push_back(opt.device);
+    const int ndev = (int)devices.size();
     RibbitHandle *h = nullptr;
-    if (ribbit_hip_open(&scan, opt.device, &h) != RIBBIT_OK) die(std::string("GPU path failed: ") + ribbit_hip_last_error());
+    if (ribbit_hip_open(&scan, devices[0], &h) != RIBBIT_OK) die(std::string("GPU path failed: ") + ribbit_hip_last_error());
 
-    // ---- record pipeline: the reader (this thread) parses records; `jobs` workers process them on their own
-    // handles; results are written in input order.  A record weighs ceil(length / 4 Mbp) of the `jobs` tokens (at
-    // most all of them), so many reads run side by side while a chromosome has the machine to itself.
-    unsigned cores = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+    // ---- record pipeline: the reader (this thread) parses records; `jobs` workers per GPU process them on their own
+    // handles; results are written in input order.  A record weighs ceil(length / 4 Mbp) of its GPU's `jobs` tokens (at
+    // most all of them), so many reads run side by side while a chromosome has one GPU and its share of the host threads
+    // to itself.  A free worker takes the LONGEST record of the look-ahead window (the longest-first dealing of
+    // independent units over devices, done as the records stream in), but never passes over the oldest record more than
+    // 2 x workers times, so the output never waits on a starved record.
+    unsigned cores = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u * (unsigned)ndev));
     if (const char *env = std::getenv("RIBBIT_THREADS")) cores = (unsigned)std::max(1, std::atoi(env));
-    int jobs = (int)std::max(1u, std::min(8u, cores / 2));
+    const unsigned dev_cores = std::max(1u, cores / (unsigned)ndev);      // host threads behind one GPU
+    int jobs = (int)std::max(1u, std::min(8u, dev_cores / 2));
     if (const char *env = std::getenv("RIBBIT_JOBS")) jobs = std::max(1, std::atoi(env));
     if (opt.jobs > 0) jobs = opt.jobs;
     jobs = std::min(jobs, 64);
+    const int workers = jobs * ndev;
     struct Record { size_t index; std::string name; const char *bases; int64_t length; };
     struct Result { std::string bed, log; };
     std::mutex mu;
@@ -249,7 +282,10 @@ int main(int argc, char **argv) {
     bool reader_done = false;
     bool failed = false;            // some record's GPU path failed: everybody drains
     std::string failure;
-    int tokens = jobs;
+    std::vector<int> tokens((size_t)ndev, jobs);
+    int front_passed_over = 0;      // how often the oldest queued record has been passed over for a longer one
+    std::vector<int64_t> dev_bases((size_t)ndev, 0);      // RIBBIT_PROFILE: bases each GPU has taken
+    std::vector<size_t> dev_records((size_t)ndev, 0);
     RibbitFastaReader *reader = nullptr;
     if (ribbit_fasta_open(opt.fasta.c_str(), 1, &reader) != RIBBIT_OK) {
         // the reference's ifstream on a missing file simply yields no lines: one empty, unnamed record (Q4)
@@ -264,24 +300,32 @@ int main(int argc, char **argv) {
             ++next_out;
         }
     };
-    auto worker = [&](RibbitHandle *wh) {
+    auto worker = [&](RibbitHandle *wh, int dev) {
         for (;;) {
             Record rec;
             int weight;
             {
                 std::unique_lock<std::mutex> lk(mu);
+                size_t pick = 0;
                 for (;;) {
                     if (!queue.empty()) {
-                        weight = (int)std::min<size_t>((size_t)jobs, (size_t)queue.front().length / 4000000 + 1);
-                        if (tokens >= weight) break;
+                        pick = 0;
+                        if (front_passed_over < 2 * workers)
+                            for (size_t i = 1; i < queue.size() && i < (size_t)workers; ++i)
+                                if (queue[i].length > queue[pick].length) pick = i;
+                        weight = (int)std::min<size_t>((size_t)jobs, (size_t)queue[pick].length / 4000000 + 1);
+                        if (tokens[(size_t)dev] >= weight) break;
                     } else if (reader_done) {
                         return;
                     }
                     cv.wait(lk);
                 }
-                rec = std::move(queue.front());
-                queue.pop_front();
-                tokens -= weight;
+                front_passed_over = pick == 0 ? 0 : front_passed_over + 1;
+                rec = std::move(queue[pick]);
+                queue.erase(queue.begin() + (std::ptrdiff_t)pick);
+                tokens[(size_t)dev] -= weight;
+                dev_bases[(size_t)dev] += rec.length;
+                ++dev_records[(size_t)dev];
             }
             cv.notify_all();
             std::ostringstream bed, log;
@@ -292,7 +336,7 @@ int main(int argc, char **argv) {
                 { std::lock_guard<std::mutex> lk(mu); skip = failed; }
                 if (!skip) {
                     try {
-                        check(ribbit_hip_set_host_threads(wh, (int)std::max(1u, cores * (unsigned)weight / (unsigned)jobs)));
+                        check(ribbit_hip_set_host_threads(wh, (int)std::max(1u, dev_cores * (unsigned)weight / (unsigned)jobs)));
                         log << "Processing sequence " << rec.name << "\n";
                         process_sequence(wh, prm, rec.name, rec.bases, rec.length, bed, log);
                     } catch (const PathError &e) { ok = false; why = e.what; }
@@ -303,20 +347,23 @@ int main(int argc, char **argv) {
                 std::lock_guard<std::mutex> lk(mu);
                 if (!ok && !failed) { failed = true; failure = why; }
                 done[rec.index] = Result{bed.str(), log.str()};
-                tokens += weight;
+                tokens[(size_t)dev] += weight;
                 if (!failed) flush_ready();
             }
             cv.notify_all();
         }
     };
     std::vector<RibbitHandle *> handles{h};
-    for (int j = 1; j < jobs; ++j) {
+    std::vector<int> handle_dev{0};
+    for (int j = 1; j < workers; ++j) {
         RibbitHandle *extra = nullptr;
-        if (ribbit_hip_open(&scan, opt.device, &extra) != RIBBIT_OK) { failed = true; failure = std::string("GPU path failed: ") + ribbit_hip_last_error(); break; }
+        const int dev = j % ndev;              // worker j serves GPU j mod ndev: every GPU gets `jobs` of them
+        if (ribbit_hip_open(&scan, devices[(size_t)dev], &extra) != RIBBIT_OK) { failed = true; failure = std::string("GPU path failed: ") + ribbit_hip_last_error(); break; }
         handles.push_back(extra);
+        handle_dev.push_back(dev);
     }
     std::vector<std::thread> pool;
-    for (RibbitHandle *wh : handles) pool.emplace_back(worker, wh);
+    for (size_t j = 0; j < handles.size(); ++j) pool.emplace_back(worker, handles[j], handle_dev[j]);
 
     // ribbit.cpp:269-279 -- records as the reference's getline loop delimits them; :280 -- the last record is processed
     // unconditionally and WITHOUT the "Processing sequence" line, also for an empty file (Q4): it bypasses the pipeline
@@ -334,7 +381,7 @@ int main(int argc, char **argv) {
         if (got == 0) break;
         if (is_last) { last_name = name; last_bases = bases; last_length = length; break; }
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return queue.size() < (size_t)(2 * jobs) || failed; });       // bounded look-ahead
+        cv.wait(lk, [&] { return queue.size() < (size_t)(2 * workers) || failed; });       // bounded look-ahead
         if (failed) break;
         queue.push_back(Record{n_records++, name, bases, length});
         cv.notify_all();
@@ -361,6 +408,9 @@ int main(int argc, char **argv) {
     for (size_t j = 1; j < handles.size(); ++j) ribbit_hip_close(handles[j]);
     ribbit_hip_close(h);
     if (reader) ribbit_fasta_close(reader);
+    if (std::getenv("RIBBIT_PROFILE") && ndev > 1)
+        for (int d = 0; d < ndev; ++d)
+            std::cerr << "[devices] slot " << d << " (GPU " << devices[(size_t)d] << "): " << dev_records[(size_t)d] << " records, " << dev_bases[(size_t)d] << " bases\n";
     if (std::getenv("RIBBIT_PROFILE"))
         std::cerr << "[stages, ms over all records] load " << g_stage_ms[0] << "  perfect " << g_stage_ms[1] << "  substitutions "
                   << g_stage_ms[2] << "  anchored " << g_stage_ms[3] << "  dispatch " << g_stage_ms[4] << "  refine+BED " << g_stage_ms[5] << "\n";

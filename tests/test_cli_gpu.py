@@ -45,6 +45,30 @@ def test_cli_multi_record_fasta(tmp_path):
     assert bed.read_text() == _oracle_bed(records, 2, 30)
 
 
+def test_cli_records_dealt_over_several_devices(tmp_path):
+    """ribbit.cpp:269-280 handles the records one after the other; --devices deals them over GPUs (here GPU 0 listed
+    twice: two handle sets, the longest record of the look-ahead first) and the BED keeps the input order."""
+    sims = simulated_cases()
+    records = [(f"rec{i}", sims[i % 2][1][i * 7000:i * 7000 + 9000 + 4000 * (i % 5)]) for i in range(12)]
+    records.insert(3, ("long one", sims[1][1][:150_000]))
+    fa, bed, bed2 = tmp_path / "in.fa", tmp_path / "out.bed", tmp_path / "out2.bed"
+    write_fasta(str(fa), records)
+    env = dict(os.environ, RIBBIT_PROFILE="1")
+    r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "30", "--devices", "0,0", "--jobs", "2"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = _oracle_bed(records, 2, 30)
+    assert bed.read_text() == want
+    dealt = [l for l in r.stderr.split("\n") if l.startswith("[devices] slot")]
+    assert len(dealt) == 2 and all(" 0 records" not in l for l in dealt), r.stderr[-1500:]
+    # the same list through the environment; an unusable list is refused
+    r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed2), "-m", "2", "-M", "30"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, RIBBIT_DEVICES="0,0,0"))
+    assert r.returncode == 0 and bed2.read_text() == want
+    r = subprocess.run([BIN, "-i", str(fa), "--devices", "0,x"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "--devices" in r.stderr
+
+
 def test_cli_long_reads_at_M_500(tmp_path):
     """BASELINE.json configs[4]: many short records (simulated long reads), -m 2 -M 500."""
     big = large_motif_cases()[0][1]
