@@ -3,8 +3,8 @@
 
 One "step" = one pass of the hot path over one record that is already resident in HBM as ASCII:
 pack kernel (fasta_utils.cpp:78-115) + perfect shift-XOR scan kernel over m=2..100
-(fasta_utils.cpp:117-122 + parse_perfect_shiftxor.cpp:173-223) + event read-back + host pairing
-into runs.  Workload = BASELINE.json configs[1]: 100 Mbp synthetic FASTA, -m 2 -M 100, perfect scan.
+(fasta_utils.cpp:117-122 + parse_perfect_shiftxor.cpp:173-223) + the pairing kernels that turn its START / END
+events into run records on the device + one D2H copy of those records (16 B each).  Workload = BASELINE.json configs[1]: 100 Mbp synthetic FASTA, -m 2 -M 100, perfect scan.
 
 Next to that line's headline (configs[1]) rank 0 of an N = 1 run also reports, in the same JSON object:
   verified          the GPU's perfect-stage calls on the first 20 Mbp equal the CPU oracle's (BASELINE: "BED diff==0")

@@ -354,8 +354,7 @@ int collect_events(RibbitHandle *h, int which) {
     if (nm * ntile > 0xfffffff0u) return fail(RIBBIT_E_ARG, "record too long for %zu motif sizes", nm);
     if ((rc = h->d_pair_table.ensure(nm * ntile))) return rc;
     if ((rc = h->d_pair_status.ensure(rb::PAIR_STATUS_WORDS))) return rc;
-    rb::launch_chunk_table(h->d_dense.p, h->d_counters.p, m_lo, (uint32_t)nm, (uint32_t)ntile, tile_bases, h->d_pair_table.p, h->d_pair_status.p, h->stream);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(rb::launch_chunk_table(h->d_dense.p, h->d_counters.p, m_lo, (uint32_t)nm, (uint32_t)ntile, tile_bases, h->d_pair_table.p, h->d_pair_status.p, h->stream));
     h->chunk_table.resize(nm * ntile);
     h->table_ntile = ntile;
     uint32_t table_status = 0;
@@ -430,9 +429,8 @@ int perfect_enqueue(RibbitHandle *h, size_t cap) {
     // own post stream: on a compute stream shared by several handles the next record's pack and scan start right
     // behind this scan instead of waiting out the pairing chain's launch gaps.
     HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->ev[3], 0));
-    rb::launch_pair_runs(h->d_events.p, h->d_counters.p, pr, h->d_pair_table.p, h->d_run_base.p, h->d_pair_partial.p,
-                         h->d_dense.p, (uint32_t)(cap / 2), h->d_halves.p, (uint32_t)(2 * (size_t)pr.nm), h->d_pair_status.p, h->copy_stream);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(rb::launch_pair_runs(h->d_events.p, h->d_counters.p, pr, h->d_pair_table.p, h->d_run_base.p, h->d_pair_partial.p,
+                                 h->d_dense.p, (uint32_t)(cap / 2), h->d_halves.p, (uint32_t)(2 * (size_t)pr.nm), h->d_pair_status.p, h->copy_stream));
     rb::launch_pair_publish(h->d_counters.p, h->d_pair_status.p, h->h_pub_dev, h->copy_stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_ready, h->copy_stream));
@@ -623,9 +621,8 @@ int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks) {
         HIP_TRY(hipEventRecord(h->ev[3], h->stream));
         HIP_TRY(hipEventRecord(h->ev_stage[which - 1][1], h->stream));
         h->have_stage_timing[which - 1] = true;
-        rb::launch_pair_runs(h->d_events.p, h->d_counters.p, pr, h->d_pair_table.p, h->d_run_base.p, h->d_pair_partial.p,
-                             h->d_dense.p, (uint32_t)(cap / 2), h->d_halves.p, (uint32_t)(2 * (size_t)pr.nm), h->d_pair_status.p, h->stream);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(rb::launch_pair_runs(h->d_events.p, h->d_counters.p, pr, h->d_pair_table.p, h->d_run_base.p, h->d_pair_partial.p,
+                                     h->d_dense.p, (uint32_t)(cap / 2), h->d_halves.p, (uint32_t)(2 * (size_t)pr.nm), h->d_pair_status.p, h->stream));
         rb::launch_pair_publish(h->d_counters.p, h->d_pair_status.p, h->h_pub_dev, h->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1632,20 +1629,32 @@ int ribbit_host_longest_runs(const RibbitScanParams *params, int64_t length, con
     return RIBBIT_OK;
 }
 
+static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const char *sequence_id, const char **text, size_t *len);
+
 int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const char *sequence_id,
                           const char **text, size_t *len) {
+    try {
+        return refine_bed_impl(h, prm, sequence_id, text, len);
+    } catch (const std::bad_alloc &) {           // nothing may unwind through the C boundary
+        return fail(RIBBIT_E_NOMEM, "out of host memory in refinement");
+    }
+}
+
+static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const char *sequence_id, const char **text, size_t *len) {
     if (!h || !prm || !sequence_id || !text || !len) return fail(RIBBIT_E_ARG, "null argument");
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
     h->best_rows_valid = false;
     h->small_valid = false;
-    static double t_rows = 0, t_text = 0, t_jobs = 0;
+    // cumulative over every handle of the process (ribbit-hip runs up to 64 workers through here at once): microseconds in atomics
+    static std::atomic<int64_t> t_rows_us{0}, t_text_us{0}, t_jobs_us{0};
+    auto add_ms = [](std::atomic<int64_t> &acc, double ms) { acc.fetch_add((int64_t)(ms * 1000.0), std::memory_order_relaxed); };
     static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
     double t0 = now_ms();
     int rc = build_best_rows(h, *prm);
     if (rc) return rc;
     if ((rc = build_small_motifs(h, *prm))) return rc;
     const rb::SmallMotifTable small{h->small_head.p, h->small_records.p};
-    t_rows += now_ms() - t0;
+    add_ms(t_rows_us, now_ms() - t0);
     t0 = now_ms();
     if (!h->host_bases && !h->host_ascii_valid) {      // bases not on the host in memory we may keep reading: fetch them once
         h->host_ascii.resize((size_t)h->length);
@@ -1716,9 +1725,11 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
         std::condition_variable cv;
         std::atomic<bool> stop{false};
         const unsigned feed_threads = std::max(1u, threads / 4);
-        std::thread feeder([&]() {
-            for (size_t c = 0; c < n_slices && !stop; ++c) {
-                Slice &sl = slices[c];
+        // a slice whose set-up runs out of host memory takes the same way out as batches that do not fit the device:
+        // RIBBIT_E_NOMEM, and the record is aligned on the host threads
+        auto feed = [&](size_t c) {
+            Slice &sl = slices[c];
+            try {
                 const double tj = now_ms();
                 rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sl.jobs, sl.pool,
                                      c == 0 ? threads : feed_threads, sl.lo, sl.hi, &small);
@@ -1738,11 +1749,25 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
                     sl.error = g_last_error;
                 }
                 sl.t_setup = tp - tj; sl.t_passes = tq - tp; sl.t_paths = now_ms() - tq;
-                { std::lock_guard<std::mutex> lk(mu); sl.ready = true; }
+            } catch (const std::bad_alloc &) {
+                sl.rc = RIBBIT_E_NOMEM;
+                sl.error = "out of host memory while setting up a slice's alignment batches";
+            }
+        };
+        std::thread feeder([&]() {
+            for (size_t c = 0; c < n_slices && !stop; ++c) {
+                feed(c);
+                { std::lock_guard<std::mutex> lk(mu); slices[c].ready = true; }
                 cv.notify_all();
-                if (sl.rc) break;
+                if (slices[c].rc) break;
             }
         });
+        // whatever happens on this thread from here on (refine_to_bed may throw std::bad_alloc at chromosome size), the
+        // feeder is stopped and joined before the frame goes: a joinable std::thread's destructor ends the process
+        struct JoinGuard {
+            std::atomic<bool> &stop; std::thread &t;
+            ~JoinGuard() { stop = true; if (t.joinable()) t.join(); }
+        } join_guard{stop, feeder};
         bool order_dependent = false;
         double t_wait = 0, t_setup = 0, t_passes = 0, t_paths = 0;
         size_t n_jobs = 0;
@@ -1772,7 +1797,7 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
         if (rc) return rc;
         if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs in %zu slices: feeder thread set-up %.1f ms, GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms; workers waited %.1f ms for it\n",
                                   n_jobs, n_slices, t_setup, t_passes, t_paths, t_wait);
-        t_jobs += t_wait;
+        add_ms(t_jobs_us, t_wait);
         done = !order_dependent && !batches_failed;
         if (!done) h->bed.clear();                         // an empty query somewhere (or no batches): the whole record in one call (below)
     }
@@ -1781,8 +1806,9 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
         rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sequence_id, h->bed,
                           h->host_threads, nullptr, nullptr, nullptr, 0, (size_t)-1, nullptr, &small);
     }
-    t_text += now_ms() - t0;
-    if (profile) std::fprintf(stderr, "[refine_bed] cumulative: GPU scans of the seeds %.1f ms, alignment set-up + GPU striped passes %.1f ms, host refinement + BED %.1f ms\n", t_rows, t_jobs, t_text);
+    add_ms(t_text_us, now_ms() - t0);
+    if (profile) std::fprintf(stderr, "[refine_bed] cumulative: GPU scans of the seeds %.1f ms, alignment set-up + GPU striped passes %.1f ms, host refinement + BED %.1f ms\n",
+                              t_rows_us.load() / 1000.0, t_jobs_us.load() / 1000.0, t_text_us.load() / 1000.0);
     *text = h->bed.c_str();
     *len = h->bed.size();
     return RIBBIT_OK;
@@ -1978,7 +2004,10 @@ int ribbit_hip_debug_pair_events(RibbitHandle *h, const uint64_t *events, size_t
     do {
         if (n && hipMemcpy(d_ev.p, events, n * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) { ret = fail(RIBBIT_E_DEVICE, "copy failed"); break; }
         if (hipMemcpy(d_cnt.p, counters.data(), counters.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) { ret = fail(RIBBIT_E_DEVICE, "copy failed"); break; }
-        rb::launch_pair_runs(d_ev.p, d_cnt.p, pr, d_table.p, d_base.p, d_part.p, d_runs.p, (uint32_t)(cap / 2), d_half.p, 2 * pr.nm, d_status.p, h->stream);
+        if (rb::launch_pair_runs(d_ev.p, d_cnt.p, pr, d_table.p, d_base.p, d_part.p, d_runs.p, (uint32_t)(cap / 2), d_half.p, 2 * pr.nm, d_status.p, h->stream) != hipSuccess) {
+            ret = fail(RIBBIT_E_DEVICE, "pairing kernels could not be launched");
+            break;
+        }
         if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy(status.data(), d_status.p, status.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
             ret = fail(RIBBIT_E_DEVICE, "pairing kernels failed");
             break;

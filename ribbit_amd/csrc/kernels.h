@@ -56,17 +56,17 @@ struct PairLaunch {
     int64_t own_lo, own_hi, pos_offset;
 };
 // halves (half_cap >= 2*nm records) receives the runs cut by the own range, status[PAIR_HALVES] their number.
-void launch_pair_runs(const uint64_t *events, const uint32_t *counters, const PairLaunch &pl, void *table,
-                      uint32_t *run_base, uint32_t *partial, void *runs, uint32_t run_cap, void *halves,
-                      uint32_t half_cap, uint32_t *status, hipStream_t stream);
+hipError_t launch_pair_runs(const uint64_t *events, const uint32_t *counters, const PairLaunch &pl, void *table,
+                            uint32_t *run_base, uint32_t *partial, void *runs, uint32_t run_cap, void *halves,
+                            uint32_t half_cap, uint32_t *status, hipStream_t stream);
 
 // host_words (page-locked, device-visible): [0, EV_SHARDS) the region counters, then PAIR_STATUS_WORDS status words
 void launch_pair_publish(const uint32_t *counters, const uint32_t *status, uint32_t *host_words, hipStream_t stream);
 
 // After launch_compact_events: table[(motif - m_lo) * ntile + tile] = {first event index + 1, index past the last event}
 // of that (motif, tile) chunk of `dense` (both 0: no chunk); *status != 0: malformed stream.
-void launch_chunk_table(const uint64_t *dense, const uint32_t *counters, uint32_t m_lo, uint32_t nm, uint32_t ntile,
-                        uint32_t tile_bases, void *table, uint32_t *status, hipStream_t stream);
+hipError_t launch_chunk_table(const uint64_t *dense, const uint32_t *counters, uint32_t m_lo, uint32_t nm, uint32_t ntile,
+                              uint32_t tile_bases, void *table, uint32_t *status, hipStream_t stream);
 
 // ---- window stages on the device (window_stage.hip): streaks -> addSeed calls -------------------------------
 // counters of launch_window_calls (WS_WORDS words, zeroed by the caller)

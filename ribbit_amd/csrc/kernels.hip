@@ -957,12 +957,14 @@ __global__ __launch_bounds__(256) void chunk_table_kernel(const uint64_t *__rest
     }
 }
 
-void launch_chunk_table(const uint64_t *dense, const uint32_t *counters, uint32_t m_lo, uint32_t nm, uint32_t ntile,
-                        uint32_t tile_bases, void *table, uint32_t *status, hipStream_t stream) {
-    (void)hipMemsetAsync(table, 0, (size_t)nm * ntile * sizeof(uint2), stream);
-    (void)hipMemsetAsync(status, 0, sizeof(uint32_t), stream);
+hipError_t launch_chunk_table(const uint64_t *dense, const uint32_t *counters, uint32_t m_lo, uint32_t nm, uint32_t ntile,
+                              uint32_t tile_bases, void *table, uint32_t *status, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(table, 0, (size_t)nm * ntile * sizeof(uint2), stream);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(status, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(chunk_table_kernel, dim3(4096), dim3(256), 0, stream, dense, counters, m_lo, nm, ntile, tile_bases,
                        (uint2 *)table, status);
+    return hipGetLastError();
 }
 
 void launch_compact_events(const uint64_t *events, uint32_t ev_cap, uint32_t *counters, uint64_t *dense,
@@ -1185,14 +1187,15 @@ void launch_pair_publish(const uint32_t *counters, const uint32_t *status, uint3
     hipLaunchKernelGGL(pair_publish_kernel, dim3(1), dim3(128), 0, stream, counters, status, host_words);
 }
 
-void launch_pair_runs(const uint64_t *events, const uint32_t *counters, const PairLaunch &pl, void *table,
-                      uint32_t *run_base, uint32_t *partial, void *runs, uint32_t run_cap, void *halves,
-                      uint32_t half_cap, uint32_t *status, hipStream_t stream) {
+hipError_t launch_pair_runs(const uint64_t *events, const uint32_t *counters, const PairLaunch &pl, void *table,
+                            uint32_t *run_base, uint32_t *partial, void *runs, uint32_t run_cap, void *halves,
+                            uint32_t half_cap, uint32_t *status, hipStream_t stream) {
     const uint32_t entries = pl.nm * pl.ntile;
     const uint32_t nblocks = (entries + (uint32_t)SCAN_BLOCK - 1u) / (uint32_t)SCAN_BLOCK;
     const uint32_t per_region = std::min<uint32_t>(std::max<uint32_t>((pl.region_cap + 255u) / 256u, 1u), 64u);
-    (void)hipMemsetAsync(table, 0, (size_t)entries * sizeof(ChunkEntry), stream);
-    (void)hipMemsetAsync(status, 0, PAIR_STATUS_WORDS * sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(table, 0, (size_t)entries * sizeof(ChunkEntry), stream);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(status, 0, PAIR_STATUS_WORDS * sizeof(uint32_t), stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(pair_chunk_bounds_kernel, dim3(per_region, EV_SHARDS), dim3(256), 0, stream, events, counters, pl,
                        (ChunkEntry *)table, status);
     hipLaunchKernelGGL(pair_chunk_starts_kernel, dim3(nblocks), dim3(256), 0, stream, (const ChunkEntry *)table, events,
@@ -1202,6 +1205,7 @@ void launch_pair_runs(const uint64_t *events, const uint32_t *counters, const Pa
     hipLaunchKernelGGL(pair_runs_kernel, dim3(per_region, EV_SHARDS), dim3(256), 0, stream, events, counters, pl,
                        (const ChunkEntry *)table, (const uint32_t *)run_base, (RunRecord *)runs, run_cap,
                        (RunRecord *)halves, half_cap, status);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------- plane query (a5, a13)

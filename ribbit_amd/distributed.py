@@ -123,37 +123,53 @@ class DeviceGather:
     def gather(self, runs, n_runs: int, halves, n_halves: int, dtype):
         """runs / halves: device pointers (int) of n_runs / n_halves 16-byte records, or uint8 tensors on self.dev holding
         them.  -> on dst: ([runs of rank 0, runs of rank 1, ...], [halves ...]) as numpy views of page-locked memory that
-        stay valid until the next call; elsewhere (None, None)"""
+        stay valid until the next call; elsewhere (None, None).
+
+        Both ends post their point-to-point operations through ONE mechanism, dist.batch_isend_irecv (a coalesced group on
+        the process group's own communicator): a plain dist.send on one side against a batched irecv on the other would use
+        two different RCCL communicators and never meet.  Nothing is copied on the sending side: the records are sent from
+        where the pairing kernels wrote them (two messages, runs then halves, matched in order), and the stream is fenced
+        before the call returns so that the handle may reuse its buffer."""
         rec = 16
         as_bytes = lambda x, n: x[:n * rec] if isinstance(x, torch.Tensor) else device_bytes(x, n * rec, self.dev)
         self.counts[0], self.counts[1] = n_runs, n_halves
         gathered = [torch.zeros_like(self.counts) for _ in range(self.world)]
-        dist.all_gather(gathered, self.counts)
+        dist.all_gather(gathered, self.counts)            # also creates the world communicator the grouped operations use
         counts = torch.stack(gathered).cpu().numpy()
-        # a copy torch owns (D2D, a few MB): the handle may reuse its buffer before an asynchronous send has read it
-        mine = torch.cat([as_bytes(runs, n_runs), as_bytes(halves, n_halves)])
-        if self.dev.type == "cuda":
-            torch.cuda.current_stream(self.dev).synchronize()
         sizes = [(int(c[0]) + int(c[1])) * rec for c in counts]
-        if self.rank != self.dst:
-            if sizes[self.rank]:
-                dist.send(mine, self.dst)
-            return None, None
-        total = sum(sizes)
-        self._room(total)
-        offs = np.concatenate(([0], np.cumsum(sizes)))
         ops = []
-        for r in range(self.world):
-            if r == self.dst or sizes[r] == 0:
-                continue
-            ops.append(dist.P2POp(dist.irecv, self.recv[int(offs[r]):int(offs[r + 1])], r))
-        if sizes[self.dst]:
-            self.recv[int(offs[self.dst]):int(offs[self.dst + 1])].copy_(mine)
+        total, offs = 0, None
+        if self.rank != self.dst:
+            # the order of a pair's messages is the contract: runs first, then halves; empty messages are posted by neither side
+            if n_runs:
+                ops.append(dist.P2POp(dist.isend, as_bytes(runs, n_runs), self.dst))
+            if n_halves:
+                ops.append(dist.P2POp(dist.isend, as_bytes(halves, n_halves), self.dst))
+        else:
+            total = sum(sizes)
+            self._room(total)
+            offs = np.concatenate(([0], np.cumsum(sizes)))
+            for r in range(self.world):
+                a, nr, nh = int(offs[r]), int(counts[r][0]) * rec, int(counts[r][1]) * rec
+                if r == self.dst:
+                    if nr:
+                        self.recv[a:a + nr].copy_(as_bytes(runs, n_runs))
+                    if nh:
+                        self.recv[a + nr:a + nr + nh].copy_(as_bytes(halves, n_halves))
+                    continue
+                if nr:
+                    ops.append(dist.P2POp(dist.irecv, self.recv[a:a + nr], r))
+                if nh:
+                    ops.append(dist.P2POp(dist.irecv, self.recv[a + nr:a + nr + nh], r))
+        self.last_ops = [(op.op.__name__, int(op.peer)) for op in ops]      # what this rank posted (tests)
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
-        self.host[:total].copy_(self.recv[:total], non_blocking=True)
+        if self.rank == self.dst:
+            self.host[:total].copy_(self.recv[:total], non_blocking=True)
         if self.dev.type == "cuda":
-            torch.cuda.current_stream(self.dev).synchronize()
+            torch.cuda.current_stream(self.dev).synchronize()      # sends have read the handle's buffer; the records are on dst's host
+        if self.rank != self.dst:
+            return None, None
         flat = self.host[:total].numpy()
         out_runs, out_halves = [], []
         for r in range(self.world):

@@ -69,6 +69,26 @@ def test_cli_records_dealt_over_several_devices(tmp_path):
     assert r.returncode == 1 and "--devices" in r.stderr
 
 
+@pytest.mark.parametrize("label,m_lo,m_hi", [("edge_cases", 2, 12), ("fuzz_batch", 2, 40)])
+def test_cli_with_every_alignment_forced_onto_the_gpu(tmp_path, label, m_lo, m_hi):
+    """RIBBIT_GPU_SSW=1: the alignments of EVERY record go through the GPU batches (by default only records with two
+    million dispatched seeds do).  Edge cases (empty-ish records, N blocks, runs at both record ends) and one batch of
+    fuzz records, BED against the oracle pipeline."""
+    if label == "edge_cases":
+        records = [(n, s) for n, s, _, _ in edge_cases() if len(s) > 0]
+    else:
+        from fuzz import fuzz_case
+        records = [(f"fz{seed}", fuzz_case(seed)[0]) for seed in range(31500, 31530)]
+        records = [(n, s.replace(b"\n", b"")) for n, s in records if len(s) > 0]
+    fa, bed = tmp_path / "in.fa", tmp_path / "out.bed"
+    write_fasta(str(fa), records)
+    r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed), "-m", str(m_lo), "-M", str(m_hi)], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, RIBBIT_GPU_SSW="1", RIBBIT_PROFILE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert bed.read_text() == _oracle_bed(records, m_lo, m_hi)
+    assert "alignment jobs in" in r.stderr, "no record took the GPU alignment path"
+
+
 def test_cli_long_reads_at_M_500(tmp_path):
     """BASELINE.json configs[4]: many short records (simulated long reads), -m 2 -M 500."""
     big = large_motif_cases()[0][1]

@@ -237,3 +237,39 @@ def test_wave_kernel_on_long_queries_of_every_kind():
             pairs.append((q, motif, int(rs.choice([40, len(q) // 2, len(q) + 50, 2 * len(q)]))))
     assert _check_batch(pairs) == len(pairs)
     _check_whole_alignments(pairs, need_paths=len(pairs) // 2)
+
+
+def test_two_batches_of_different_size_on_one_handle():
+    """Regression for a crash of round 2 (feeder thread of ribbit_hip_refine_bed): the path search's result slots are reused
+    from batch to batch, and a second, smaller batch read a path-operation count the first batch had left in a slot it did not
+    write itself (jobs without a path: score 0, or beyond the distance filter).  One handle, a large batch, then a smaller one
+    in another order that contains such jobs: every record of both must equal the reference library's."""
+    rs = np.random.RandomState(20509)
+    big = []
+    for _ in range(700):
+        m = int(rs.randint(1, 30))
+        motif = _rand(rs, m)
+        pure = (motif * 42)[int(rs.randint(0, m)):][:m * int(rs.randint(2, 40))]
+        query = _mutate(rs, pure, float(rs.choice([0.0, 0.05, 0.2])))
+        if query:
+            big.append((query, motif, len(query) + m + int(0.15 * len(query))))
+    small = [big[k] for k in rs.permutation(len(big))[:90]]
+    # jobs that end without a path: nothing in common with the reference (score 0 -> one soft clip)
+    for _ in range(25):
+        small.insert(int(rs.randint(0, len(small))), (b"A" * int(rs.randint(1, 60)), b"C" * int(rs.randint(1, 9)), 40))
+    with ribbit_amd.Scanner(2, 8) as sc:
+        for pairs in (big, small):
+            record, jobs, pool = _batch(pairs)
+            sc.load_record(record)
+            got, on_gpu = sc.ssw_align_jobs(jobs, pool)
+            for k, (query, motif, ppr_len) in enumerate(pairs):
+                ref = motif * (ppr_len // len(motif) + 2)
+                want, want_cigar = ref_align(query, ref, ppr_len)
+                res, cigar = got[k]
+                if want["sw_score"] == 0:
+                    assert cigar == f"{len(query)}S", (k, cigar)
+                    continue
+                assert cigar == want_cigar, (k, cigar, want_cigar, int(on_gpu[k]))
+                for f in ("sw_score", "ref_begin", "ref_end", "query_begin", "query_end", "mismatches", "flag"):
+                    assert res[f] == want[f], (k, f, res, want)
+            assert int((on_gpu == 2).sum()) >= len(pairs) // 2
