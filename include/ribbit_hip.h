@@ -414,6 +414,66 @@ int ribbit_hip_scan_perfect_wait(RibbitHandle *h);
  * of a chunk-sharded record, gathered to the rank that runs the host merge) instead of through host memory. */
 int ribbit_hip_scan_perfect_end_device(RibbitHandle *h, const void **dev_runs, size_t *n, const void **dev_halves, size_t *n_halves);
 
+/*
+ * ---- chunk-sharded operation, window stages: only the calls that reach a merge leave a GPU ---------------------
+ * The substitution / anchored stage of ONE CHUNK of a longer record, on the device end to end: the loaded record is the
+ * chunk plus halos (a "piece", starting pos_offset bases into a record of record_length bases); the window scan, the
+ * pairing of its pass-streaks, the per-motif window state machine (parse_substitute_shiftxor.cpp:430-574,
+ * parse_anchored_shiftxor.cpp:580-723), the stage's length filter and the call order all run on this GPU, exactly as
+ * for a whole record, and the chunk keeps the addSeed calls whose SCAN POSITION it owns: own_lo <= pos - pos_offset <
+ * own_hi (piece coordinates; the chunks' own ranges partition 0..record_length, the last one includes record_length,
+ * the position of the end-of-sequence calls).  Results are in record coordinates; concatenated over the chunks in order
+ * they are the record's kept calls in the reference's call order -- 16 bytes per kept call is all that travels.
+ *
+ * Exactness.  A call is a function of the sequence between the start of its group of pass-streaks and the first
+ * evaluated window behind it -- bounded by the locus, not by a constant.  The piece must reach
+ *   right: 4 * (max_motif + 2) + 16 bases beyond own_hi (unless it ends where the record ends): checked, RIBBIT_E_ARG;
+ *   left:  far enough that (a) an evaluated window lies between the first exact position (2 * (max_motif + 2) + 8 bases
+ *          into the piece) + 16 and own_lo - 8, and (b) no owned call's group starts within 8 positions of that first exact
+ *          position.  Both are CHECKED on every call: *inexact = 1 means a repeat or a block of N reaches further left than
+ *          the halo (nothing else can) and the caller loads the chunk again with a longer left halo (the results of such a
+ *          call must not be used).  A piece that starts where the record starts (pos_offset == 0) is always exact.
+ * calls / pend / flush: handle-owned page-locked memory, valid until the next call for the same stage on this handle;
+ * dev_calls / dev_pend: the same arrays in device memory (for RCCL), valid until the next scan on the handle.
+ * pend[i] (NULL: none in this chunk): for a kept call made at an N or right behind a blocked stretch, the largest end of
+ * any of THIS chunk's calls before it (-1 otherwise); tail_pend: the largest end of any call of this chunk (-1: none).
+ * Across chunks the bound of such a call is the larger of pend[i] and the earlier chunks' tail_pend
+ * (ribbit_host_merge_chunks does that).  flush: the end-of-sequence calls, last chunk only.
+ */
+typedef struct RibbitChunkCalls {
+    const RibbitCall *calls; size_t n;
+    const int32_t *pend;
+    int32_t tail_pend;
+    int32_t inexact;
+    const RibbitCall *flush; size_t n_flush;
+    const void *dev_calls, *dev_pend;
+    int64_t streaks;          /* pass-streaks the piece's scan found (diagnostic) */
+} RibbitChunkCalls;
+int ribbit_hip_stage_calls_chunk(RibbitHandle *h, int stage /* RIBBIT_STAGE_SUBST | RIBBIT_STAGE_ANCHORED */, int64_t own_lo, int64_t own_hi,
+                                 int64_t pos_offset, int64_t record_length, RibbitChunkCalls *out);
+
+/* Words [word_lo, word_hi) of every composed plane XA_m of the loaded piece into out + motif_index * out_stride: a chunk
+ * writes its own words straight into its place in the record's planes (e.g. a page-locked segment every rank of the node
+ * maps) -- ribbit_hip_xa_words with a destination stride. */
+int ribbit_hip_xa_words_strided(RibbitHandle *h, int64_t word_lo, int64_t word_hi, uint32_t *out, int64_t out_stride);
+
+/* Host-only: the merging rank's half of the chunk-sharded path.  parts[0..nparts) in chunk order: the perfect stage's run
+ * records and halves of every chunk (ribbit_hip_scan_perfect_chunk; place holders are skipped, halves paired across
+ * chunks) and its kept calls of both window stages (ribbit_hip_stage_calls_chunk; only the host pointers are read).
+ * Planes cover the whole record (see ribbit_host_replay_calls); xa is READ IN PLACE (3 GB for a chromosome), it must stay
+ * valid during the call.  Runs addSeedToSeedPositionsPerfect / ...Substitutions / ...Anchored + mergeAllLists
+ * (parse_perfect_shiftxor.cpp:47-142, parse_substitute_shiftxor.cpp:18-388, parse_anchored_shiftxor.cpp:113-534,
+ * merge_types.cpp:11-189) and the dispatch merge of fasta_utils.cpp:187-224 exactly as for one GPU. */
+typedef struct RibbitChunkPart {
+    const RibbitRun *runs; size_t n_runs;
+    const RibbitRun *halves; size_t n_halves;
+    RibbitChunkCalls subst, anchored;
+} RibbitChunkPart;
+int ribbit_host_merge_chunks(const RibbitScanParams *params, int64_t length,
+                             const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
+                             const uint32_t *xa, size_t xa_stride, const RibbitChunkPart *parts, size_t nparts,
+                             RibbitSeedLists *out);
+
 /* Test hook: run the device-side pairing on a caller-made event stream of a record of `length` bases,
  * as if one scan had left it in one region.  *flags = 0 for a well-formed stream, otherwise the PAIR_* bits of
  * device_planes.h (1 malformed event, 2 duplicate chunk, 4 starts and ends do not alternate, 8 unterminated run,

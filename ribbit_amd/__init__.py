@@ -51,6 +51,7 @@ ABI_SYMBOLS = [
     "ribbit_host_perfect_runs_from_events", "ribbit_runs_free", "ribbit_hip_perfect_runs_partial",
     "ribbit_hip_scan_perfect_chunk", "ribbit_hip_host_register", "ribbit_hip_host_unregister",
     "ribbit_hip_set_host_threads", "ribbit_hip_ssw_passes", "ribbit_hip_ssw_align_jobs", "ribbit_hip_set_timing", "ribbit_hip_debug_set_event_capacity", "ribbit_hip_debug_pair_events", "ribbit_hip_scan_perfect_begin", "ribbit_hip_scan_perfect_end", "ribbit_hip_scan_perfect_wait", "ribbit_hip_scan_perfect_end_device",
+    "ribbit_hip_stage_calls_chunk", "ribbit_hip_xa_words_strided", "ribbit_host_merge_chunks",
 ]
 
 
@@ -81,6 +82,21 @@ class SeedLists(C.Structure):
     _fields_ = [("perfect", C.c_void_p), ("n_perfect", C.c_size_t), ("subst", C.c_void_p), ("n_subst", C.c_size_t),
                 ("anchored", C.c_void_p), ("n_anchored", C.c_size_t), ("dispatch", C.c_void_p), ("n_dispatch", C.c_size_t),
                 ("guard_hits", C.c_int64)]
+
+
+class ChunkCalls(C.Structure):
+    """RibbitChunkCalls: what one window stage of one chunk of a longer record keeps (ribbit_hip_stage_calls_chunk)."""
+    _fields_ = [("calls", C.c_void_p), ("n", C.c_size_t), ("pend", C.c_void_p), ("tail_pend", C.c_int32), ("inexact", C.c_int32),
+                ("flush", C.c_void_p), ("n_flush", C.c_size_t), ("dev_calls", C.c_void_p), ("dev_pend", C.c_void_p), ("streaks", C.c_int64)]
+
+
+class ChunkPart(C.Structure):
+    """RibbitChunkPart: one chunk's contribution to ribbit_host_merge_chunks."""
+    _fields_ = [("runs", C.c_void_p), ("n_runs", C.c_size_t), ("halves", C.c_void_p), ("n_halves", C.c_size_t),
+                ("subst", ChunkCalls), ("anchored", ChunkCalls)]
+
+
+STAGE_PERFECT, STAGE_SUBST, STAGE_ANCHORED = 0, 1, 2
 
 
 def library_path() -> str:
@@ -191,6 +207,10 @@ def load_library():
     L.ribbit_runs_free.restype = None
     L.ribbit_runs_free.argtypes = [vp]
     L.ribbit_ssw_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, C.POINTER(Alignment), C.c_char_p, C.c_size_t]
+    L.ribbit_hip_stage_calls_chunk.argtypes = [vp, C.c_int, i64, i64, i64, i64, C.POINTER(ChunkCalls)]
+    L.ribbit_hip_xa_words_strided.argtypes = [vp, i64, i64, vp, i64]
+    L.ribbit_host_merge_chunks.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(ChunkPart), C.c_size_t,
+                                           C.POINTER(SeedLists)]
     L.ribbit_hip_debug_stream_read.argtypes = [vp, i64, C.POINTER(i64)]
     L.ribbit_hip_last_event_count.restype = i64
     L.ribbit_hip_last_event_count.argtypes = [vp]
@@ -264,6 +284,51 @@ def host_replay_calls(min_motif: int, max_motif: int, sequence: bytes, perfect_c
                                     ac.ctypes.data if anchored_calls is not None else None, len(ac), C.byref(out))
     if rc != 0:
         raise RibbitHipError(f"ribbit_host_replay_calls error {rc}: {L.ribbit_hip_last_error().decode()}")
+    try:
+        return {"perfect": _copy(out.perfect, out.n_perfect, SEED_DT), "subst": _copy(out.subst, out.n_subst, SEED_DT),
+                "anchored": _copy(out.anchored, out.n_anchored, SEED_DT), "dispatch": _copy(out.dispatch, out.n_dispatch, SEED_DT),
+                "guard_hits": int(out.guard_hits)}
+    finally:
+        L.ribbit_seed_lists_free(C.byref(out))
+
+
+def host_merge_chunks(min_motif: int, max_motif: int, length: int, hi, lo, brk, xa, xa_stride: int, parts):
+    """ribbit_host_merge_chunks: the merging rank's half of the chunk-sharded path.  parts (chunk order) = dicts with
+    RUN_DT arrays `runs`, `halves` and, per window stage s in ("subst", "anchored"), `<s>_calls` (CALL_DT), `<s>_pend`
+    (int32 per call, or None), `<s>_tail_pend` (int), `<s>_flush` (CALL_DT).  -> dict of the record's seed lists."""
+    L = load_library()
+    params = ScanParams()
+    L.ribbit_scan_params_default(C.byref(params), min_motif, max_motif)
+    hi, lo, brk = (np.ascontiguousarray(a, dtype="<u4") for a in (hi, lo, brk))
+    keep = []                                        # arrays the C structs point into
+
+    def arr(a, dt):
+        a = np.ascontiguousarray(a if a is not None else np.zeros(0, dt), dtype=dt)
+        keep.append(a)
+        return a
+
+    cparts = (ChunkPart * max(len(parts), 1))()
+    for k, p in enumerate(parts):
+        runs, halves = arr(p["runs"], RUN_DT), arr(p["halves"], RUN_DT)
+        cparts[k].runs, cparts[k].n_runs = runs.ctypes.data, len(runs)
+        cparts[k].halves, cparts[k].n_halves = halves.ctypes.data, len(halves)
+        for stage in ("subst", "anchored"):
+            cc = getattr(cparts[k], stage)
+            calls, flush = arr(p[f"{stage}_calls"], CALL_DT), arr(p[f"{stage}_flush"], CALL_DT)
+            cc.calls, cc.n = calls.ctypes.data, len(calls)
+            cc.flush, cc.n_flush = flush.ctypes.data, len(flush)
+            pend = p.get(f"{stage}_pend")
+            if pend is not None and len(calls):
+                pend = arr(pend, "<i4")
+                assert len(pend) == len(calls)
+                cc.pend = pend.ctypes.data
+            cc.tail_pend = int(p[f"{stage}_tail_pend"])
+            cc.inexact = int(p.get(f"{stage}_inexact", 0))
+    out = SeedLists()
+    rc = L.ribbit_host_merge_chunks(C.byref(params), length, hi.ctypes.data, lo.ctypes.data, brk.ctypes.data, len(hi),
+                                    xa.ctypes.data if xa is not None else None, xa_stride, cparts, len(parts), C.byref(out))
+    if rc != 0:
+        raise RibbitHipError(f"ribbit_host_merge_chunks error {rc}: {L.ribbit_hip_last_error().decode()}")
     try:
         return {"perfect": _copy(out.perfect, out.n_perfect, SEED_DT), "subst": _copy(out.subst, out.n_subst, SEED_DT),
                 "anchored": _copy(out.anchored, out.n_anchored, SEED_DT), "dispatch": _copy(out.dispatch, out.n_dispatch, SEED_DT),
@@ -772,6 +837,22 @@ class Scanner:
 
     def host_unregister(self, address: int) -> None:
         self._check(self._L.ribbit_hip_host_unregister(address))
+
+    def stage_calls_chunk(self, stage: int, own_lo: int, own_hi: int, pos_offset: int, record_length: int) -> dict:
+        """ribbit_hip_stage_calls_chunk: the kept calls of one window stage (STAGE_SUBST / STAGE_ANCHORED) of the loaded
+        piece, in record coordinates -> dict(calls, pend (or None), tail_pend, flush, inexact, streaks) (copies)"""
+        cc = ChunkCalls()
+        self._check(self._L.ribbit_hip_stage_calls_chunk(self._h, stage, own_lo, min(own_hi, (1 << 62)), pos_offset, record_length, C.byref(cc)))
+        return {"calls": _copy(cc.calls, cc.n, CALL_DT), "pend": _copy(cc.pend, cc.n, np.dtype("<i4")) if cc.pend else None,
+                "tail_pend": int(cc.tail_pend), "flush": _copy(cc.flush, cc.n_flush, CALL_DT), "inexact": bool(cc.inexact),
+                "streaks": int(cc.streaks)}
+
+    def xa_words_into(self, word_lo: int, word_hi: int, out: np.ndarray, out_word: int) -> None:
+        """ribbit_hip_xa_words_strided: this piece's words [word_lo, word_hi) of every composed plane into out[:, out_word:...]
+        (out: (motifs, stride) uint32, C-contiguous -- e.g. the record's planes in a segment every rank maps)"""
+        assert out.dtype == np.dtype("<u4") and out.flags.c_contiguous and out.ndim == 2
+        assert out_word >= 0 and out_word + (word_hi - word_lo) <= out.shape[1]
+        self._check(self._L.ribbit_hip_xa_words_strided(self._h, word_lo, word_hi, out.ctypes.data + 4 * out_word, out.shape[1]))
 
     def xa_words(self, word_lo: int, word_hi: int):
         nm = self.params.max_motif - self.params.min_motif + 1

@@ -70,7 +70,8 @@ hipError_t launch_chunk_table(const uint64_t *dense, const uint32_t *counters, u
 
 // ---- window stages on the device (window_stage.hip): streaks -> addSeed calls -------------------------------
 // counters of launch_window_calls (WS_WORDS words, zeroed by the caller)
-enum : uint32_t { WS_N_MAIN = 0, WS_N_EDGE = 1, WS_FLAGS = 2, WS_MAX_END = 3 /* largest end + 1 of an in-loop call */, WS_WORDS = 8 };
+enum : uint32_t { WS_N_MAIN = 0, WS_N_EDGE = 1, WS_FLAGS = 2, WS_MAX_END = 3 /* largest end + 1 of an in-loop call */,
+                  WS_INEXACT = 4 /* != 0: an owned call's group reaches the piece's artificial left end (chunk mode) */, WS_WORDS = 8 };
 enum : uint32_t {
     WS_TWO_FLUSH = 1,    // two end-of-sequence calls for one motif
     WS_BAD_MOTIF = 2,    // streak with a motif outside the launch
@@ -98,6 +99,11 @@ struct WindowCallsLaunch {
     RibbitCall *flush;                 // [nm], zeroed by the caller: the end-of-sequence call of each motif
     uint32_t *bitmap;                  // [n_words + 1], zeroed by the caller
     uint32_t *counters;                // [WS_WORDS], zeroed by the caller
+    // chunk mode (the loaded record is a chunk of a longer record plus halos): only calls made at scan positions
+    // own_lo <= pos < own_hi are this chunk's; z_lo: first position whose streak events are exact (0: the piece starts
+    // where the record starts); keep_flush: the piece ends where the record ends.  Whole record: 0, 0xffffffff, 0, 1.
+    uint32_t own_lo = 0, own_hi = 0xffffffffu, z_lo = 0;
+    int keep_flush = 1;
 };
 void launch_window_calls(const WindowCallsLaunch &w, hipStream_t stream);
 hipError_t launch_sort_calls(uint64_t *keys_in, uint64_t *vals_in, uint64_t *keys_out, uint64_t *vals_out, uint32_t n, int key_bits,
@@ -105,9 +111,10 @@ hipError_t launch_sort_calls(uint64_t *keys_in, uint64_t *vals_in, uint64_t *key
 // bounds of the kept edge calls (edge list sorted by key) -> pend[index in the sorted main list]
 hipError_t launch_edge_bounds(const uint64_t *edge_keys, const uint64_t *edge_vals, uint32_t n_edge, uint32_t *edge_tmp, uint32_t *edge_end1,
                               const uint32_t *bitmap, uint32_t *word_tmp, uint32_t *last_word1, uint32_t n_words, const uint64_t *main_keys,
-                              uint32_t n_main, int32_t *pend, uint32_t *counters, void *scratch, size_t scratch_bytes,
+                              uint32_t n_main, int32_t *pend, uint32_t *counters, int32_t pos_offset, void *scratch, size_t scratch_bytes,
                               hipStream_t stream);
-void launch_assemble_calls(const uint64_t *keys, const uint64_t *vals, uint32_t n, RibbitCall *out, hipStream_t stream);
+// pos_offset: added to every coordinate (a chunk's piece coordinates -> record coordinates)
+void launch_assemble_calls(const uint64_t *keys, const uint64_t *vals, uint32_t n, RibbitCall *out, int32_t pos_offset, hipStream_t stream);
 // bytes of scratch the rocPRIM scans / sorts above need for these sizes
 size_t window_stage_scratch_bytes(size_t n_streaks, size_t n_words, size_t n_calls, size_t n_edge, int key_bits);
 

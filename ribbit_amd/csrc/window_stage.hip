@@ -124,6 +124,14 @@ struct EmitArgs {
     RibbitCall *flush;            // [nm], mlen == 0: none
     uint32_t *bitmap;             // positions at which an ordinary call was made
     uint32_t *counters;           // WS_* below
+    // The loaded record may be one PIECE (chunk + halos) of a longer record that several GPUs scan: a call belongs to the
+    // chunk that owns its scan position, own_lo <= pos < own_hi (a whole record: 0, 0xffffffff).  Calls of the halos are
+    // the neighbours' and leave no trace here (no list entry, no bitmap bit, no bound).  z_lo != 0: streak events before
+    // position z_lo are artefacts of the piece's artificial left end, so an owned call whose group starts within 8
+    // positions of it may be a longer group cut short: WS_INEXACT tells the caller to load a longer left halo.
+    // keep_flush: the piece ends where the record ends, so the end-of-sequence calls are this chunk's.
+    uint32_t own_lo, own_hi, z_lo;
+    int keep_flush;
 };
 
 __device__ __forceinline__ uint64_t call_key(uint32_t pos, uint32_t mlen) { return ((uint64_t)pos << 10) | mlen; }
@@ -179,13 +187,17 @@ __global__ __launch_bounds__(256) void window_calls_kernel(EmitArgs a) {
                 }
                 if (have && to_flush) {
                     const uint32_t mi = mlen - a.m_lo;
-                    if (mi < a.nm) {
+                    if (!a.keep_flush) {
+                        // no evaluated window left in a piece that ends before the record does: the call is made beyond the piece
+                    } else if (mi < a.nm) {
                         // at most one per motif: an open streak and an unreported group cannot both be left over
                         if (atomicExch(&a.flush[mi].mlen, (int32_t)mlen) != 0) atomicOr(&a.counters[WS_FLAGS], (uint32_t)WS_TWO_FLUSH);
                         a.flush[mi].pos = a.length; a.flush[mi].start = (int32_t)start; a.flush[mi].end = (int32_t)end;
+                        if (a.z_lo && start < a.z_lo + 8u) atomicOr(&a.counters[WS_INEXACT], 1u);
                     } else atomicOr(&a.counters[WS_FLAGS], (uint32_t)WS_BAD_MOTIF);
-                } else if (have) {
+                } else if (have && pos >= a.own_lo && pos < a.own_hi) {
                     in_loop = true;
+                    if (a.z_lo && start < a.z_lo + 8u) atomicOr(&a.counters[WS_INEXACT], 1u);
                     const uint32_t mi = mlen - a.m_lo;
                     kept = a.full || (mi < a.nm && (int32_t)(end - start) >= a.min_span[mi]);
                     if (!a.full) {
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(256) void edge_bounds_kernel(const uint64_t *__rest
                                                           const uint32_t *__restrict__ end1_before, uint32_t n_edge,
                                                           const uint32_t *__restrict__ bitmap, const uint32_t *__restrict__ last_word1,
                                                           const uint64_t *__restrict__ main_keys, uint32_t n_main,
-                                                          int32_t *__restrict__ pend, uint32_t *__restrict__ counters) {
+                                                          int32_t *__restrict__ pend, uint32_t *__restrict__ counters, int32_t pos_offset) {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= n_edge) return;
     const uint64_t val = edge_vals[j];
@@ -284,15 +296,15 @@ __global__ __launch_bounds__(256) void edge_bounds_kernel(const uint64_t *__rest
         if (main_keys[mid] < key) lo = mid + 1u; else hi = mid;
     }
     if (lo >= n_main || main_keys[lo] != key) { atomicOr(&counters[WS_FLAGS], (uint32_t)WS_EDGE_LOST); return; }
-    pend[lo] = bound;
+    pend[lo] = bound < 0 ? bound : bound + pos_offset;      // piece coordinates -> record coordinates
 }
 
 __global__ __launch_bounds__(256) void assemble_calls_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ vals,
-                                                             uint32_t n, RibbitCall *__restrict__ out) {
+                                                             uint32_t n, RibbitCall *__restrict__ out, int32_t pos_offset) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = keys[i], v = vals[i];
-    out[i] = RibbitCall{(int32_t)(k >> 10), (int32_t)(k & 1023u), (int32_t)(v >> 32), (int32_t)(uint32_t)v};
+    out[i] = RibbitCall{(int32_t)(k >> 10) + pos_offset, (int32_t)(k & 1023u), (int32_t)(v >> 32) + pos_offset, (int32_t)(uint32_t)v + pos_offset};
 }
 
 }  // namespace
@@ -340,6 +352,7 @@ void launch_window_calls(const WindowCallsLaunch &w, hipStream_t stream) {
     a.keys = w.keys; a.vals = w.vals; a.cap = w.cap;
     a.edge_keys = w.edge_keys; a.edge_vals = w.edge_vals; a.edge_cap = w.edge_cap;
     a.flush = w.flush; a.bitmap = w.bitmap; a.counters = w.counters;
+    a.own_lo = w.own_lo; a.own_hi = w.own_hi; a.z_lo = w.z_lo; a.keep_flush = w.keep_flush;
     hipLaunchKernelGGL(window_calls_kernel, dim3((w.n_streaks + (uint32_t)EMIT_TILE - 1u) / (uint32_t)EMIT_TILE), dim3(256), 0, stream, a);
 }
 
@@ -351,7 +364,7 @@ hipError_t launch_sort_calls(uint64_t *keys_in, uint64_t *vals_in, uint64_t *key
 
 hipError_t launch_edge_bounds(const uint64_t *edge_keys, const uint64_t *edge_vals, uint32_t n_edge, uint32_t *edge_tmp, uint32_t *edge_end1,
                               const uint32_t *bitmap, uint32_t *word_tmp, uint32_t *last_word1, uint32_t n_words, const uint64_t *main_keys,
-                              uint32_t n_main, int32_t *pend, uint32_t *counters, void *scratch, size_t scratch_bytes,
+                              uint32_t n_main, int32_t *pend, uint32_t *counters, int32_t pos_offset, void *scratch, size_t scratch_bytes,
                               hipStream_t stream) {
     if (n_edge == 0) return hipSuccess;
     hipLaunchKernelGGL(edge_ends_kernel, dim3((n_edge + 255u) / 256u), dim3(256), 0, stream, edge_vals, n_edge, edge_tmp);
@@ -361,13 +374,13 @@ hipError_t launch_edge_bounds(const uint64_t *edge_keys, const uint64_t *edge_va
     e = rocprim::inclusive_scan(scratch, scratch_bytes, word_tmp, last_word1, (size_t)n_words, MaxOp32(), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(edge_bounds_kernel, dim3((n_edge + 255u) / 256u), dim3(256), 0, stream, edge_keys, edge_vals, edge_end1, n_edge,
-                       bitmap, last_word1, main_keys, n_main, pend, counters);
+                       bitmap, last_word1, main_keys, n_main, pend, counters, pos_offset);
     return hipSuccess;
 }
 
-void launch_assemble_calls(const uint64_t *keys, const uint64_t *vals, uint32_t n, RibbitCall *out, hipStream_t stream) {
+void launch_assemble_calls(const uint64_t *keys, const uint64_t *vals, uint32_t n, RibbitCall *out, int32_t pos_offset, hipStream_t stream) {
     if (n == 0) return;
-    hipLaunchKernelGGL(assemble_calls_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, keys, vals, n, out);
+    hipLaunchKernelGGL(assemble_calls_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, keys, vals, n, out, pos_offset);
 }
 
 }  // namespace rb

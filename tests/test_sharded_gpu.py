@@ -1,39 +1,78 @@
-"""GPU test of chunk-sharding: one GPU plays every rank in turn (loads chunk + halos, exports the events
-and plane words it owns); the merged result must equal the oracle's lists for any number of parts."""
+"""GPU tests of chunk-sharding: one GPU plays every rank in turn (loads chunk + halos, runs the device side of all three
+stages on the piece, keeps the calls whose scan position it owns and its own plane words); the merge of what the chunks
+kept must equal the oracle's lists -- and the BED its pipeline's -- for any number of parts."""
 import numpy as np
 import pytest
 
 import ribbit_amd
 from cases import edge_cases, simulated_cases
 from oracle_lib import LIST_ANCHORED, LIST_PERFECT, LIST_SUBST, Oracle
-from ribbit_amd import sharded
+from ribbit_amd import STAGE_ANCHORED, STAGE_SUBST, sharded
 
 pytestmark = pytest.mark.gpu
 CASES = [c for c in edge_cases() if len(c[1]) >= 64] + simulated_cases()
 
 
 @pytest.mark.parametrize("name,seq,m_lo,m_hi", CASES, ids=[c[0] for c in CASES])
-@pytest.mark.parametrize("nparts", [2, 5])
+@pytest.mark.parametrize("nparts", [2, 4, 7])
 def test_chunk_sharded_scan_matches_oracle(name, seq, m_lo, m_hi, nparts):
     with Oracle(seq, m_lo, m_hi) as o:
         o.run_all()
         want = {"perfect": o.seeds(LIST_PERFECT), "subst": o.seeds(LIST_SUBST), "anchored": o.seeds(LIST_ANCHORED),
                 "dispatch": o.dispatch()}
+        want_bed = o.refine_bed(name)
     with ribbit_amd.Scanner(m_lo, m_hi) as sc:
         parts = [sharded.scan_part(sc, seq, plan) for plan in sharded.plan_chunks(len(seq), nparts, m_hi)]
     got = sharded.merge_parts(m_lo, m_hi, len(seq), parts)
     for k in want:
         assert np.array_equal(got[k].view("<i4"), want[k].view("<i4")), k
+    # nothing but 16 bytes per kept call (and 4 per call of a chunk that holds a call made at an N) leaves a chunk for
+    # the window stages: no event, no streak record
+    for p in parts:
+        b = sharded.part_bytes(p)
+        assert b["window_call_bytes"] == 16 * b["kept_window_calls"]
+        assert b["records"] <= 20 * b["kept_window_calls"] + 16 * (b["perfect_runs"] + len(p["halves"]) + len(p["subst_flush"]) + len(p["anchored_flush"]))
+    hi, lo, brk, xa, stride = got["planes"]
+    assert ribbit_amd.host_refine_bed(m_lo, m_hi, seq, xa, stride, got["dispatch"], name).split("\n") == want_bed.split("\n")
 
 
-def test_parts_own_disjoint_ranges_and_every_event_once():
-    name, seq, m_lo, m_hi = simulated_cases()[1]
+def test_every_call_is_kept_by_exactly_one_chunk_and_a_short_halo_is_noticed():
+    """the chunks' kept calls back to back ARE the record's kept calls (same order, same cursor bounds where they matter);
+    a piece whose left halo is shorter than the repeat that straddles its cut says so instead of returning a cut group"""
+    name, seq, m_lo, m_hi = [c for c in edge_cases() if c[0] == "long_run_cross_tiles"][0]
+    seq = seq + simulated_cases()[1][1][:80_000]
+    L = len(seq)
     with ribbit_amd.Scanner(m_lo, m_hi) as sc:
         sc.load_record(seq)
-        whole, _ = sc.stage_events(1, 0, len(seq) + 1, 0)
-        parts = [sharded.scan_part(sc, seq, plan, anchored=False) for plan in sharded.plan_chunks(len(seq), 4, m_hi)]
-    union = np.sort(np.concatenate([p["ev1"] for p in parts]))
-    assert np.array_equal(union, np.sort(whole))
+        whole = {st: sc.stage_calls_chunk(st, 0, L + 1, 0, L) for st in (STAGE_SUBST, STAGE_ANCHORED)}
+        assert not any(w["inexact"] for w in whole.values())
+        plans = sharded.plan_chunks(L, 5, m_hi, left_halo=0)          # the smallest halo the kernels' reach allows
+        # chunk 1 starts inside the 40-kb repeat: with the minimal halo its first group is cut, and it must say so
+        own_lo, own_hi, load_lo, load_hi = plans[1]
+        sc.load_record(seq[load_lo:load_hi])
+        cut = sc.stage_calls_chunk(STAGE_ANCHORED, own_lo - load_lo, own_hi - load_lo, load_lo, L)
+        assert cut["inexact"]
+        parts = [sharded.scan_part(sc, seq, plan) for plan in plans]
+    assert max(p["halo_grown"] for p in parts) >= 1 and parts[0]["halo_grown"] == 0
+    for st, key in ((STAGE_SUBST, "subst"), (STAGE_ANCHORED, "anchored")):
+        calls = np.concatenate([p[f"{key}_calls"] for p in parts])
+        assert np.array_equal(calls.view("<i4"), whole[st]["calls"].view("<i4")), key
+        flush = np.concatenate([p[f"{key}_flush"] for p in parts])
+        assert np.array_equal(flush.view("<i4"), whole[st]["flush"].view("<i4")), key
+        assert max(p[f"{key}_tail_pend"] for p in parts) == whole[st]["tail_pend"]
+
+
+def test_chunk_geometry_is_checked():
+    name, seq, m_lo, m_hi = simulated_cases()[1]
+    L = len(seq)
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc:
+        sc.load_record(seq[1000:60_000])
+        with pytest.raises(ribbit_amd.RibbitHipError, match="beyond the chunk"):
+            sc.stage_calls_chunk(STAGE_SUBST, 2000, 59_000 - 1000, 1000, L)           # right halo too short
+        with pytest.raises(ribbit_amd.RibbitHipError, match="before the chunk"):
+            sc.stage_calls_chunk(STAGE_SUBST, 10, 30_000, 1000, L)                     # left halo shorter than the kernels' reach
+        with pytest.raises(ribbit_amd.RibbitHipError, match="geometry"):
+            sc.stage_calls_chunk(STAGE_SUBST, 2000, 30_000, L, L)                      # piece beyond the record
 
 
 @pytest.mark.parametrize("nparts", [4, 7])      # cuts at 30 kb resp. 17/34 kb: inside the 40-kb repeat
