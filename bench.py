@@ -16,6 +16,10 @@ Next to that line's headline (configs[1]) rank 0 of an N = 1 run also reports, i
                     seed 4, N blocks) through perfect + substitution + anchored scans, merges, dispatch, refinement
                     and BED text, with per-kernel times and a roofline block for each scan kernel
   cpu_baseline      the oracle's perfect stage on 20 Mbp, one core (CPU model and core count stated)
+and an N > 1 run reports
+  full_path_sharded one record of N x 10 Mbp chunk-sharded over the ranks through perfect + substitution + anchored
+                    stages: device stages per rank, 16 bytes per kept call to rank 0, merges there; checked against rank
+                    0's own scan of the whole record; bytes every rank sent
 
 N > 1: one process per GPU (torch.distributed, backend nccl == RCCL).  `python bench.py --gpus N` without a launcher
 starts `python -m torch.distributed.run --nproc-per-node N` itself (before anything touches a GPU) and exits with its
@@ -260,6 +264,61 @@ def full_path_sample(sc, seq: bytes, bases: int):
             "scans_and_merges_s": t1 - t0, "refinement_and_bed_s": t2 - t1, "seeds": int(len(perfect) + len(subst) + len(anchored)),
             "dispatched": int(len(dispatch)), "bed_rows": bed.count("\n"),
             "what": "FASTA record -> BED text, -m 2 -M 100: three scans + seed merges + dispatch + refinement (host-bound)"}
+
+
+def sharded_full_path(ribbit_amd, dist, torch, sc, seq: bytes, bases: int, rank: int, world: int, xdev, dev):
+    """N > 1: BASELINE.json configs[3]'s shape on a bounded record -- ONE record of world x `bases` chunk-sharded over the
+    ranks, the whole P+S+A path: every rank runs the device side of the three stages on its chunk (scan kernels, pairing,
+    window state machines, length filters, call order) and keeps the calls whose scan position it owns; 16 bytes per kept
+    call and the rank's plane words travel to rank 0 (gather-v over the collective backend: RCCL on GPUs), which runs the
+    three merges and the dispatch merge once (ribbit_amd.sharded).  Rank 0 then scans the whole record on its own GPU and
+    checks that the sharded lists are identical.  One pass, outside the headline's timed region."""
+    import numpy as np
+    from ribbit_amd import sharded
+    from ribbit_amd.distributed import allgather_array
+    chunks = allgather_array(np.frombuffer(seq[:bases], dtype=np.uint8).copy(), xdev)     # every rank can fetch any halo
+    record = b"".join(c.tobytes() for c in chunks)
+    L = len(record)
+    plan = sharded.plan_chunks(L, world, M_HI)[rank]
+
+    def sync():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    part = sharded.scan_part(sc, record, plan)
+    torch.cuda.synchronize()
+    t_scan = time.perf_counter() - t0
+    sync()
+    t1 = time.perf_counter()
+    gathered = sharded.gather_parts(part, xdev)
+    sync()
+    t_exchange = time.perf_counter() - t1
+    t = torch.tensor([t_scan], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    sent = sharded.part_bytes(part)
+    all_sent = [None] * world
+    dist.all_gather_object(all_sent, dict(sent, halo_grown=part["halo_grown"], left_halo=part["left_halo"]))
+    if rank != 0:
+        return None
+    t2 = time.perf_counter()
+    lists = sharded.merge_parts(M_LO, M_HI, L, gathered)
+    t_merge = time.perf_counter() - t2
+    sc.load_record(record)
+    perfect, subst, anchored = sc.processShiftXORsAnchored()
+    dispatch = sc.dispatch_seeds()
+    same = all(np.array_equal(lists[k].view("<i4"), w.view("<i4")) for k, w in
+               (("perfect", perfect), ("subst", subst), ("anchored", anchored), ("dispatch", dispatch)))
+    total = float(t.item()) + t_exchange + t_merge
+    return {"bases": L, "bases_per_gpu": bases, "seconds": total, "value": L / total / 1e9, "unit": "Gbases/s",
+            "scan_seconds_max_over_ranks": float(t.item()), "exchange_seconds": t_exchange, "merge_seconds_rank0": t_merge,
+            "identical_to_single_gpu_scan": bool(same),
+            "seeds": {"perfect": int(len(lists["perfect"])), "substitution": int(len(lists["subst"])), "anchored": int(len(lists["anchored"]))},
+            "dispatched": int(len(lists["dispatch"])), "sent_per_rank": all_sent,
+            "what": "one record chunk-sharded over the ranks, perfect + substitution + anchored stages: per-rank device stages (scan, pairing, "
+                    "window state machines, filters), gather-v of 16-byte run records and kept calls + the ranks' plane words to rank 0, "
+                    "merges and dispatch order on rank 0; refinement not included"}
 
 
 def main():
@@ -574,6 +633,11 @@ def main():
     headline_ng = used_transport == "shm"
     headline_dg = used_transport == "rccl" and device_gather
 
+    sharded_leg = None
+    if world > 1 and args.full_path_bases > 0:
+        teardown()
+        sharded_leg = sharded_full_path(ribbit_amd, dist, torch, sc, seq, min(args.full_path_bases, args.bases), rank, world, xdev, dev)
+
     if rank == 0:
         traffic = n_valu = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -615,6 +679,8 @@ def main():
             out["exchange"].update(other)
             if rccl_error:
                 out["exchange"]["rccl_error"] = rccl_error
+            if sharded_leg is not None:
+                out["full_path_sharded"] = sharded_leg
         if n_valu:
             # the honest limiter: wave-instructions per launch from the committed SQ_INSTS_VALU pass, the share of
             # v_alignbit among them from profiles/isa_mix.json, against the issue rates measured on this part by

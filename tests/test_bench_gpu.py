@@ -84,3 +84,10 @@ def test_two_ranks_on_one_gpu_reproduce_the_unsharded_runs(exchange):
         assert ("node-shared" in d["config"]["parallelism"]) == (ex["headline"] == "shm")
     else:
         assert ("node-shared" in d["config"]["parallelism"]) == (exchange == "shm")
+    # the full P+S+A path of the chunk-sharded record (BASELINE.json configs[3]'s shape): identical to rank 0's own scan of
+    # the whole record, and nothing but 16 bytes per kept call leaves a rank for the window stages
+    fp = d["full_path_sharded"]
+    assert fp["identical_to_single_gpu_scan"] is True and fp["bases"] == 2 * 2_000_000 and fp["seeds"]["anchored"] > 0
+    assert len(fp["sent_per_rank"]) == 2
+    for sent in fp["sent_per_rank"]:
+        assert sent["window_call_bytes"] == 16 * sent["kept_window_calls"] and sent["planes"] > 0

@@ -68,7 +68,7 @@ def test_chunk_geometry_is_checked():
     with ribbit_amd.Scanner(m_lo, m_hi) as sc:
         sc.load_record(seq[1000:60_000])
         with pytest.raises(ribbit_amd.RibbitHipError, match="beyond the chunk"):
-            sc.stage_calls_chunk(STAGE_SUBST, 2000, 59_000 - 1000, 1000, L)           # right halo too short
+            sc.stage_calls_chunk(STAGE_SUBST, 2000, 58_900, 1000, L)                  # right halo too short
         with pytest.raises(ribbit_amd.RibbitHipError, match="before the chunk"):
             sc.stage_calls_chunk(STAGE_SUBST, 10, 30_000, 1000, L)                     # left halo shorter than the kernels' reach
         with pytest.raises(ribbit_amd.RibbitHipError, match="geometry"):
