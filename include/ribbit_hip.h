@@ -354,9 +354,10 @@ void ribbit_seed_lists_free(RibbitSeedLists *lists);
  * Every scan kernel's output is a stream of events whose values depend on the sequence only within a
  * bounded distance (perfect: 32 + M+2 bases to the right, 33 to the left; window scans: 8 + M+2 / 1;
  * anchored: 4*(M+2) + 16 / 2*(M+2) + 8).  A rank therefore loads its chunk plus halos as a record of
- * its own, scans it, and keeps only the events whose position lies in the range it owns; the ranks'
- * events are exchanged (all-gather-v over RCCL) and one host replays pairing, state machines and the
- * order-dependent merges on the union exactly as for a single GPU.
+ * its own and runs the whole device side of every stage on it -- scan, pairing of the events, window state
+ * machines, length filters -- keeping the run records and the addSeed calls it owns; those sparse 16-byte
+ * records are gathered (gather-v over RCCL) and one host runs the order-dependent merges on them exactly
+ * as for a single GPU (ribbit_hip_scan_perfect_chunk, ribbit_hip_stage_calls_chunk, ribbit_host_merge_chunks).
  *
  * Events are 64-bit: bits 0-31 position, 32-47 motif length, 48-51 kind (0 START, 1 END closed by a
  * mismatch / failing window, 2 END at an N, 3 END at the end of the loaded record).
@@ -365,12 +366,6 @@ void ribbit_seed_lists_free(RibbitSeedLists *lists);
 #define RIBBIT_EVENT_MLEN(e) ((uint32_t)((e) >> 32) & 0xffffu)
 #define RIBBIT_EVENT_KIND(e) ((uint32_t)((e) >> 48) & 0xfu)
 enum { RIBBIT_STAGE_PERFECT = 0, RIBBIT_STAGE_SUBST = 1, RIBBIT_STAGE_ANCHORED = 2 };
-
-/* Run stage's scan kernel on the loaded (sub)record and return the events with local position in
- * [own_lo, own_hi), motif-major and position-ordered, positions shifted by pos_offset.
- * per_motif_counts receives max_motif-min_motif+1 counts.  Handle-owned memory. */
-int ribbit_hip_stage_events(RibbitHandle *h, int stage, int64_t own_lo, int64_t own_hi, int64_t pos_offset,
-                            const uint64_t **events, size_t *n, const uint64_t **per_motif_counts);
 
 /* Perfect stage of one chunk: scan, keep the events owned ([own_lo, own_hi) local, shifted by pos_offset) and
  * pair them locally.  runs = complete runs; halves = the unmatched events at the chunk's edges (a motif's
@@ -532,17 +527,6 @@ int ribbit_hip_host_unregister(void *p);
 /* Words [word_lo, word_hi) of every composed plane XA_m (after the anchored stage's kernel ran),
  * motif-major, into out[(max_motif-min_motif+1) * (word_hi-word_lo)]. */
 int ribbit_hip_xa_words(RibbitHandle *h, int64_t word_lo, int64_t word_hi, uint32_t *out);
-
-/* Host-only: the whole path from gathered events.  ev_* hold nparts parts back to back (each part
- * motif-major), cnt_*[part * nm + motif_index] their per-motif counts; parts must own increasing,
- * disjoint position ranges.  Planes cover the whole record (see ribbit_host_replay_calls). */
-int ribbit_host_scan_from_events(const RibbitScanParams *params, int64_t length,
-                                 const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
-                                 const uint32_t *xa, size_t xa_stride, size_t nparts,
-                                 const uint64_t *ev_perfect, const uint64_t *cnt_perfect,
-                                 const uint64_t *ev_subst, const uint64_t *cnt_subst,
-                                 const uint64_t *ev_anchored, const uint64_t *cnt_anchored,
-                                 RibbitSeedLists *out);
 
 /* Host-only: pair gathered perfect-stage events into runs (sorted by motif, start); *runs is malloc'ed
  * (release with ribbit_runs_free). */

@@ -14,7 +14,7 @@ import sys
 import numpy as np
 
 __all__ = ["RibbitHipError", "ScanParams", "Scanner", "library_path", "load_library", "host_replay_calls", "pack_planes", "pack_bit_planes",
-           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "ENDS_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "host_refine_bed", "host_scan_from_events", "host_perfect_runs_from_events", "pair_halves", "ssw_align", "merge_chunk_runs", "join_run_halves",
+           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "ENDS_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "host_refine_bed", "host_merge_chunks", "host_perfect_runs_from_events", "pair_halves", "ssw_align", "merge_chunk_runs", "join_run_halves",
            "RUN_NOT_OWNED", "RUN_HALF_START", "RUN_HALF_END"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "ribbit_refine_params_default", "ribbit_hip_seed_longest_runs", "ribbit_hip_refine_jobs",
     "ribbit_host_refine_jobs", "ribbit_refine_jobs_free", "ribbit_ssw_align",
     "ribbit_hip_refine_bed", "ribbit_host_refine_bed", "ribbit_text_free",
-    "ribbit_hip_stage_events", "ribbit_hip_xa_words", "ribbit_host_scan_from_events",
+    "ribbit_hip_xa_words",
     "ribbit_host_perfect_runs_from_events", "ribbit_runs_free", "ribbit_hip_perfect_runs_partial",
     "ribbit_hip_scan_perfect_chunk", "ribbit_hip_host_register", "ribbit_hip_host_unregister",
     "ribbit_hip_set_host_threads", "ribbit_hip_ssw_passes", "ribbit_hip_ssw_align_jobs", "ribbit_hip_set_timing", "ribbit_hip_debug_set_event_capacity", "ribbit_hip_debug_pair_events", "ribbit_hip_scan_perfect_begin", "ribbit_hip_scan_perfect_end", "ribbit_hip_scan_perfect_wait", "ribbit_hip_scan_perfect_end_device",
@@ -183,7 +183,6 @@ def load_library():
                                          vp, C.c_size_t, vp, C.c_size_t, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.ribbit_text_free.restype = None
     L.ribbit_text_free.argtypes = [vp]
-    L.ribbit_hip_stage_events.argtypes = [vp, C.c_int, i64, i64, i64, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
     L.ribbit_hip_xa_words.argtypes = [vp, i64, i64, vp]
     L.ribbit_hip_perfect_runs_partial.argtypes = [vp, i64, i64, i64, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.ribbit_hip_scan_perfect_chunk.argtypes = [vp, i64, i64, i64, vp, C.c_size_t, vp, C.c_size_t,
@@ -201,8 +200,6 @@ def load_library():
                                               C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.ribbit_hip_scan_perfect_wait.argtypes = [vp]
     L.ribbit_hip_scan_perfect_end_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp), C.POINTER(C.c_size_t)]
-    L.ribbit_host_scan_from_events.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t,
-                                               vp, vp, vp, vp, vp, vp, C.POINTER(SeedLists)]
     L.ribbit_host_perfect_runs_from_events.argtypes = [C.POINTER(ScanParams), C.c_size_t, vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.ribbit_runs_free.restype = None
     L.ribbit_runs_free.argtypes = [vp]
@@ -430,35 +427,6 @@ def host_refine_bed(min_motif: int, max_motif: int, sequence: bytes, xa, xa_stri
         return C.string_at(text.value, n.value).decode()
     finally:
         L.ribbit_text_free(text)
-
-
-def host_scan_from_events(min_motif: int, max_motif: int, length: int, hi, lo, brk, xa, xa_stride: int, parts):
-    """ribbit_host_scan_from_events.  parts = list of dicts with uint64 arrays ev0/ev1/ev2 and cnt0/cnt1/cnt2
-    (perfect, substitution, anchored; ev2/cnt2 may be None everywhere).  Returns the dict of seed lists."""
-    L = load_library()
-    params = ScanParams()
-    L.ribbit_scan_params_default(C.byref(params), min_motif, max_motif)
-    def cat(key):
-        if any(p.get(key) is None for p in parts):
-            return None
-        arrs = [np.ascontiguousarray(p[key], dtype="<u8") for p in parts]
-        return np.concatenate(arrs) if arrs else np.zeros(0, "<u8")
-    bufs = {k: cat(k) for k in ("ev0", "cnt0", "ev1", "cnt1", "ev2", "cnt2")}
-    ptr = lambda a: a.ctypes.data if a is not None else None
-    hi, lo, brk = (np.ascontiguousarray(a, dtype="<u4") for a in (hi, lo, brk))
-    out = SeedLists()
-    rc = L.ribbit_host_scan_from_events(C.byref(params), length, hi.ctypes.data, lo.ctypes.data, brk.ctypes.data, len(hi),
-                                        xa.ctypes.data if xa is not None else None, xa_stride, len(parts),
-                                        ptr(bufs["ev0"]), ptr(bufs["cnt0"]), ptr(bufs["ev1"]), ptr(bufs["cnt1"]),
-                                        ptr(bufs["ev2"]), ptr(bufs["cnt2"]), C.byref(out))
-    if rc != 0:
-        raise RibbitHipError(f"ribbit_host_scan_from_events error {rc}: {L.ribbit_hip_last_error().decode()}")
-    try:
-        return {"perfect": _copy(out.perfect, out.n_perfect, SEED_DT), "subst": _copy(out.subst, out.n_subst, SEED_DT),
-                "anchored": _copy(out.anchored, out.n_anchored, SEED_DT), "dispatch": _copy(out.dispatch, out.n_dispatch, SEED_DT),
-                "guard_hits": int(out.guard_hits)}
-    finally:
-        L.ribbit_seed_lists_free(C.byref(out))
 
 
 def host_perfect_runs_from_events(min_motif: int, max_motif: int, event_parts, count_parts):
@@ -737,13 +705,6 @@ class Scanner:
         return int(self._L.ribbit_hip_guard_hits(self._h))
 
     # chunk-sharded operation --------------------------------------------------------------
-    def stage_events(self, stage: int, own_lo: int, own_hi: int, pos_offset: int = 0):
-        """-> (uint64 events in [own_lo, own_hi), shifted by pos_offset, motif-major; per-motif counts)"""
-        ev, n, cnt = C.c_void_p(), C.c_size_t(), C.c_void_p()
-        self._check(self._L.ribbit_hip_stage_events(self._h, stage, own_lo, own_hi, pos_offset, C.byref(ev), C.byref(n), C.byref(cnt)))
-        nm = self.params.max_motif - self.params.min_motif + 1
-        return _copy(ev.value, n.value, np.dtype("<u8")), _copy(cnt.value, nm, np.dtype("<u8"))
-
     def perfect_runs_partial(self, own_lo: int, own_hi: int, pos_offset: int = 0):
         """-> (complete runs of this chunk, unmatched edge events as uint64)"""
         r, nr, hv, nh = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()

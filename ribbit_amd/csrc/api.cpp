@@ -1,7 +1,7 @@
 // api.cpp -- extern "C" boundary of libribbit_hip.so (see include/ribbit_hip.h).
 // Device memory, streams and HIP-event timing live here; kernels are in kernels.hip, the
-// per-motif window state machine in window_fsm.cpp and the sequential seed-list merges in
-// seed_lists.cpp.  There is no CPU fallback for any scan anywhere in this library.
+// per-motif window state machines in window_stage.hip (device) and the sequential seed-list merges in
+// seed_lists.cpp / parallel_merge.cpp.  There is no CPU fallback for any scan anywhere in this library.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -27,7 +27,6 @@
 #include "ssw_exact.h"
 #include "ribbit_hip.h"
 #include "seed_lists.h"
-#include "window_fsm.h"
 
 namespace {
 
@@ -1891,39 +1890,6 @@ int ribbit_ssw_align(const char *query, int32_t query_len, const char *ref, int3
 
 int64_t ribbit_hip_guard_hits(const RibbitHandle *h) { return h ? h->lists.guard_hits : 0; }
 
-int ribbit_hip_stage_events(RibbitHandle *h, int stage, int64_t own_lo, int64_t own_hi, int64_t pos_offset,
-                            const uint64_t **events, size_t *n, const uint64_t **per_motif_counts) {
-    if (!h || !events || !n || !per_motif_counts) return fail(RIBBIT_E_ARG, "null argument");
-    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
-    if (stage < 0 || stage > 2) return fail(RIBBIT_E_ARG, "stage must be 0, 1 or 2");
-    int rc;
-    if (stage == 2) {
-        if (h->params.max_motif > rb::ANCHORED_MAX_MOTIF)
-            return fail(RIBBIT_E_ARG, "the anchored stage of this build supports max_motif <= %d", rb::ANCHORED_MAX_MOTIF);
-        const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
-        h->xa_stride = ((h->length / 32 + 1) + 7) / 8 * 8 + 16;
-        if ((rc = h->d_xa.ensure(nm * (size_t)h->xa_stride))) return rc;
-    }
-    if ((rc = collect_events(h, stage))) return rc;
-    h->runs_valid = h->calls_valid = h->subst_calls_valid = h->anchored_calls_valid = false;   // the event buffer is shared
-    const rb::EventSource src = event_source(h);
-    h->export_events.clear();
-    h->export_counts.assign(src.nm, 0);
-    for (size_t mi = 0; mi < src.nm; ++mi) {
-        for (rb::MotifCursor c(src, mi); !c.done(); c.next()) {
-            const uint64_t e = c.peek();
-            const int64_t pos = rb::ev_pos(e);
-            if (pos < own_lo || pos >= own_hi) continue;
-            h->export_events.push_back(rb::ev_pack((uint32_t)(pos + pos_offset), rb::ev_mlen(e), rb::ev_kind(e)));
-            ++h->export_counts[mi];
-        }
-    }
-    *events = h->export_events.data();
-    *n = h->export_events.size();
-    *per_motif_counts = h->export_counts.data();
-    return RIBBIT_OK;
-}
-
 int ribbit_hip_perfect_runs_partial(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset,
                                     const RibbitRun **runs, size_t *n_runs, const uint64_t **halves, size_t *n_halves) {
     if (!h || !runs || !n_runs || !halves || !n_halves) return fail(RIBBIT_E_ARG, "null argument");
@@ -2345,82 +2311,6 @@ int ribbit_host_merge_chunks(const RibbitScanParams *params, int64_t length,
         ribbit_seed_lists_free(out);
         return fail(RIBBIT_E_NOMEM, "out of host memory in the merge of the chunks");
     }
-    return RIBBIT_OK;
-}
-
-int ribbit_host_scan_from_events(const RibbitScanParams *params, int64_t length,
-                                 const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
-                                 const uint32_t *xa, size_t xa_stride, size_t nparts,
-                                 const uint64_t *ev_perfect, const uint64_t *cnt_perfect,
-                                 const uint64_t *ev_subst, const uint64_t *cnt_subst,
-                                 const uint64_t *ev_anchored, const uint64_t *cnt_anchored,
-                                 RibbitSeedLists *out) {
-    if (!params || !out || !cnt_perfect || !cnt_subst || (length > 0 && (!hi || !lo || !brk))) return fail(RIBBIT_E_ARG, "null argument");
-    const size_t need = (size_t)(length / 32 + 1) + (size_t)(params->max_motif + 2) / 32 + 2;
-    if (nwords < need) return fail(RIBBIT_E_ARG, "planes too short: %zu words, need %zu", nwords, need);
-    if (cnt_anchored && xa && xa_stride < (size_t)(length / 32 + 1)) return fail(RIBBIT_E_ARG, "composed planes (xa) too short");
-    std::memset(out, 0, sizeof *out);
-    const size_t nm = (size_t)(params->max_motif - params->min_motif + 1);
-    rb::HostPlanes hp;
-    hp.resize(length, nwords);
-    std::memcpy(hp.hi.data(), hi, nwords * sizeof(uint32_t));
-    std::memcpy(hp.lo.data(), lo, nwords * sizeof(uint32_t));
-    std::memcpy(hp.brk.data(), brk, nwords * sizeof(uint32_t));
-    hp.index_breaks();
-    // segment table of one stage: [motif][part] -> {offset, count} into the gathered buffer
-    auto source = [&](const uint64_t *ev, const uint64_t *cnt, std::vector<rb::Seg> &segs) {
-        segs.assign(nm * nparts, rb::Seg{0, 0});
-        uint64_t off = 0;
-        for (size_t p = 0; p < nparts; ++p)
-            for (size_t mi = 0; mi < nm; ++mi) {
-                segs[mi * nparts + p] = rb::Seg{(uint32_t)off, (uint32_t)cnt[p * nm + mi]};
-                off += cnt[p * nm + mi];
-            }
-        rb::EventSource src;
-        src.ev = ev; src.segs = segs.data(); src.segs_per_motif = nparts; src.nm = nm; src.m_lo = params->min_motif;
-        return src;
-    };
-    rb::SeedLists sl;
-    sl.length = length;
-    sl.min_motif = params->min_motif;
-    sl.max_motif = params->max_motif;
-    sl.min_shift = (params->min_motif > 2) ? params->min_motif - 2 : 1;
-    sl.range_count = [&hp](int shift, int start, int end) { return hp.range_count(shift, start, end); };
-    std::vector<rb::Seg> segs;
-    std::string why;
-    std::vector<RibbitRun> runs;
-    rb::CallVec calls;
-    if (!rb::pair_perfect_runs(source(ev_perfect, cnt_perfect, segs), runs, &why)) return fail(RIBBIT_E_INTERNAL, "perfect events: %s", why.c_str());
-    rb::perfect_calls_from_runs(runs.data(), runs.size(), length, sl.min_shift, calls);
-    for (const RibbitCall &c : calls) rb::perfect_add(sl, c.start, c.end, c.mlen);
-    if (!rb::replay_window_events(source(ev_subst, cnt_subst, segs), hp, calls, &why)) return fail(RIBBIT_E_INTERNAL, "substitution events: %s", why.c_str());
-    rb::merge_subst_stage_full(sl, calls.data(), calls.size(), rb::merge_threads(0));
-    rb::SeedVec dispatch;
-    if (cnt_anchored) {
-        if (xa) hp.xa.assign(xa, xa + nm * xa_stride);        // else: recomputed slice by slice from the packed planes
-        hp.xa_stride = xa ? (int64_t)xa_stride : 0;
-        hp.xa_m_lo = params->min_motif;
-        hp.xa_m_hi = params->max_motif;
-        sl.range_count = [&hp](int shift, int start, int end) {
-            return hp.has_xa(shift) ? hp.range_count_xa(shift, start, end) : hp.range_count(shift, start, end);
-        };
-        if (!rb::replay_window_events(source(ev_anchored, cnt_anchored, segs), hp, calls, &why)) return fail(RIBBIT_E_INTERNAL, "anchored events: %s", why.c_str());
-        rb::MergeStats st;
-        rb::merge_anchored_stage_full(sl, calls.data(), calls.size(), rb::merge_threads(0), &st);
-        rb::dispatch_order_ranges(sl, st.cut_pos, rb::merge_threads(0), dispatch);
-    }
-    auto give = [](const rb::SeedVec &v, RibbitSeed **p, size_t *n) {
-        *n = v.size();
-        *p = (RibbitSeed *)std::malloc(std::max<size_t>(v.size(), 1) * sizeof(RibbitSeed));
-        if (*p && !v.empty()) std::memcpy(*p, v.data(), v.size() * sizeof(RibbitSeed));
-        return *p != nullptr;
-    };
-    if (!give(sl.perfect, &out->perfect, &out->n_perfect) || !give(sl.subst, &out->subst, &out->n_subst) ||
-        !give(sl.anchored, &out->anchored, &out->n_anchored) || !give(dispatch, &out->dispatch, &out->n_dispatch)) {
-        ribbit_seed_lists_free(out);
-        return fail(RIBBIT_E_NOMEM, "out of host memory");
-    }
-    out->guard_hits = sl.guard_hits;
     return RIBBIT_OK;
 }
 

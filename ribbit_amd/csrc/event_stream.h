@@ -57,11 +57,4 @@ bool pair_perfect_runs_partial(const EventSource &src, int64_t own_lo, int64_t o
 // parse_perfect_shiftxor.cpp:175-223: runs -> the addSeed calls the perfect scanner makes, in its order
 void perfect_calls_from_runs(const RibbitRun *runs, size_t n_runs, int64_t length, int min_shift, CallVec &calls);
 
-// Replay of the per-motif window state machines (window_fsm.h), tile by tile, producing the call list in the
-// reference's call order (scan position major, motif minor, end-of-sequence flush last) without a global
-// sort.  O(events + calls).
-// (The single-GPU path runs these state machines on the device, window_stage.hip, and filters the calls there; this host
-// replay serves ribbit_host_scan_from_events, where rank 0 merges the events of several chunks.)
-bool replay_window_events(const EventSource &src, const HostPlanes &hp, CallVec &calls, std::string *why, unsigned host_threads = 0);
-
 }  // namespace rb

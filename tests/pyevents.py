@@ -1,5 +1,5 @@
 """Test-side numpy restatement of what the scan kernels emit (device events), built from the oracle's planes:
-used to drive the product's host pipeline (ribbit_host_scan_from_events) on CPU, incl. the chunk-sharded
+used to build the perfect-stage run records of the chunk-sharded CPU tests (tests/test_sharded.py) and in the streak tests; incl. the chunk-sharded
 exchange under gloo.  Test-only."""
 import numpy as np
 
