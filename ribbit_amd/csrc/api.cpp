@@ -150,7 +150,9 @@ struct RibbitHandle {
     DevBuf<uint32_t> d_eval, d_first_rev, d_word_tmp, d_last_word, d_bitmap, d_edge_tmp, d_edge_end1, d_ws_counters;
     bool eval_valid = false;              // d_eval / d_first_rev belong to the loaded record
     DevBuf<uint64_t> d_group, d_sort_keys, d_sort_vals, d_edge_keys, d_edge_vals, d_edge_keys2, d_edge_vals2;
-    DevBuf<int32_t> d_min_span, d_pend;
+    DevBuf<int32_t> d_min_span, d_pend, d_tj;
+    DevBuf<uint32_t> d_dropmap;           // group filter of the anchored scan: ends of the groups it dropped
+    bool dropmap_valid = false;           // the last anchored scan ran with the filter
     DevBuf<RibbitCall> d_flush;
     DevBuf<uint8_t> d_scratch;
     // results of the substitution [0] and anchored [1] stage, page-locked: both stages' kernels run before either merge
@@ -323,7 +325,7 @@ int collect_events(RibbitHandle *h, int which) {
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
         if (which == 0) rb::launch_scan_perfect(pl, pp, h->d_events.p, h->d_counters.p, h->stream);
         else if (which == 1) rb::launch_scan_window(pl, pp, 1, h->d_events.p, h->d_counters.p, h->stream);
-        else rb::launch_scan_anchored(pl, pp, h->d_xa.p, h->xa_stride, h->d_events.p, h->d_counters.p, h->stream);
+        else rb::launch_scan_anchored(pl, pp, h->d_xa.p, h->xa_stride, h->d_events.p, h->d_counters.p, nullptr, nullptr, h->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[3], h->stream));
         rb::launch_compact_events(h->d_events.p, pp.ev_cap, h->d_counters.p, h->d_dense.p, h->stream);
@@ -570,7 +572,9 @@ int advance_to_perfect(RibbitHandle *h) {
 // ---- window stages on the device ---------------------------------------------------------------------
 // scan kernel -> pass-streak START / END events (left in their regions) -> pairing kernels -> one 16-byte record per
 // streak, motif-major by start, in d_dense.  which: 1 window scan (1 mismatch), 2 fused anchored scan.
-int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks) {
+// filter (anchored scan only): groups of pass-streaks whose call cannot pass min_span leave no events (kernels.hip, "group
+// filter"); their ends are left in h->d_dropmap for window_stage_device.
+int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks, int (*filter_min_span)(int) = nullptr) {
     int rc;
     if ((rc = bind_device(h))) return rc;
     if (h->copy_pending && (rc = perfect_wait(h))) return rc;      // d_dense / d_events are shared with the perfect stage
@@ -600,10 +604,25 @@ int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks) {
     if (h->debug_first_cap) cap = h->debug_first_cap;
     const rb::DevicePlanes pl = h->planes();
     uint64_t produced = 0;
+    const bool filter = which == 2 && filter_min_span != nullptr && std::getenv("RIBBIT_NO_GROUP_FILTER") == nullptr;
+    const size_t drop_words = (size_t)(h->length / 32 + 1) + 1024;
+    h->dropmap_valid = false;
+    if (filter) {
+        // positions a group must span for its call to be able to pass: the call's length is the group's span + 7
+        std::vector<int32_t> tj(pr.nm);
+        for (uint32_t mi = 0; mi < pr.nm; ++mi) {
+            const int t = std::min(filter_min_span((int)(pr.m_lo + mi)), rb::GROUP_FILTER_MAX + 7) - 7;
+            tj[mi] = t > 1 ? t : 0;
+        }
+        if ((rc = h->d_tj.ensure(pr.nm)) || (rc = h->d_dropmap.ensure(drop_words))) return rc;
+        HIP_TRY(hipMemcpyAsync(h->d_tj.p, tj.data(), pr.nm * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));       // tj is a local
+    }
     for (int attempt = 0;; ++attempt) {
         cap = std::min<size_t>((cap + rb::EV_SHARDS - 1) / rb::EV_SHARDS * rb::EV_SHARDS, 0xffffff00u);
         if ((rc = h->d_events.ensure(cap))) return rc;
         if ((rc = h->d_dense.ensure(cap))) return rc;          // cap / 2 streak records of 16 bytes
+        if (filter) HIP_TRY(hipMemsetAsync(h->d_dropmap.p, 0, drop_words * sizeof(uint32_t), h->stream));
         HIP_TRY(hipEventRecord(h->ev[4], h->stream));
         if (!h->counters_clean) HIP_TRY(hipMemsetAsync(h->d_counters.p, 0, rb::EV_COUNTER_WORDS * sizeof(uint32_t), h->stream));
         h->counters_clean = false;
@@ -615,7 +634,8 @@ int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks) {
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
         HIP_TRY(hipEventRecord(h->ev_stage[which - 1][0], h->stream));
         if (which == 1) rb::launch_scan_window(pl, pp, 1, h->d_events.p, h->d_counters.p, h->stream);
-        else rb::launch_scan_anchored(pl, pp, h->d_xa.p, h->xa_stride, h->d_events.p, h->d_counters.p, h->stream);
+        else rb::launch_scan_anchored(pl, pp, h->d_xa.p, h->xa_stride, h->d_events.p, h->d_counters.p, filter ? h->d_tj.p : nullptr,
+                                      filter ? h->d_dropmap.p : nullptr, h->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[3], h->stream));
         HIP_TRY(hipEventRecord(h->ev_stage[which - 1][1], h->stream));
@@ -646,6 +666,7 @@ int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks) {
     if (h->h_pub.p[rb::EV_SHARDS + rb::PAIR_HALVES]) return fail(RIBBIT_E_INTERNAL, "streak cut by the own range of a whole record");
     *n_streaks = n;
     h->last_streaks = n;
+    h->dropmap_valid = filter;
     return RIBBIT_OK;
 }
 
@@ -671,7 +692,7 @@ int window_stage_device(RibbitHandle *h, int which, bool full, int (*min_span)(i
     PinnedBuf<uint32_t> &h_ws = h->h_ws_[which - 1];
     static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
     const double t_scan = now_ms();
-    if ((rc = scan_and_pair_streaks(h, which, &n))) return rc;
+    if ((rc = scan_and_pair_streaks(h, which, &n, full ? nullptr : min_span))) return rc;
     const double t0 = now_ms();
     const uint32_t nm = (uint32_t)(h->params.max_motif - h->params.min_motif + 1);
     const uint32_t n_words = (uint32_t)(h->length / 32 + 1);
@@ -722,6 +743,11 @@ int window_stage_device(RibbitHandle *h, int which, bool full, int (*min_span)(i
         if (cw) { w.own_lo = cw->own_lo; w.own_hi = cw->own_hi; w.z_lo = cw->z_lo; w.keep_flush = cw->keep_flush ? 1 : 0; }
         rb::launch_window_calls(w, h->stream);
         HIP_TRY(hipGetLastError());
+        if (h->dropmap_valid && !full) {
+            rb::launch_merge_dropmap(h->d_dropmap.p, (uint32_t)((size_t)(h->length / 32 + 1) + 1024), n_words, w.own_lo, w.own_hi, h->d_bitmap.p,
+                                     h->d_ws_counters.p, h->stream);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipMemcpyAsync(h_ws.p, h->d_ws_counters.p, rb::WS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(h_flush.p, h->d_flush.p, nm * sizeof(RibbitCall), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));

@@ -34,8 +34,13 @@ void launch_scan_window(const DevicePlanes &pl, const PerfectLaunch &pp, int all
 // fasta_utils.cpp:143-161 + the window scan of processShiftXORsAnchored (:580-679), fused.
 // xa (may be null) receives the composed planes XA_m, motif-major, xa_stride words per motif.
 // Tiles are anchored_tile_words(anchored_halo_lanes(pp.m_hi)) wide.  Requires pp.m_hi <= ANCHORED_MAX_MOTIF.
+// tj_table (may be null: no filter): per motif of the launch, the number of positions a group of pass-streaks must span for
+// its call to be able to pass the stage's length filter (<= GROUP_FILTER_MAX; 0: keep every group); groups that cannot,
+// and are not kept for another reason (see the kernel), emit no events and leave their end bit in dropmap (words
+// 0 .. L/32, zeroed by the caller) instead.
+constexpr int GROUP_FILTER_MAX = 16;
 void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint32_t *xa, int64_t xa_stride,
-                          uint64_t *events, uint32_t *counters, hipStream_t stream);
+                          uint64_t *events, uint32_t *counters, const int32_t *tj_table, uint32_t *dropmap, hipStream_t stream);
 
 // Gathers the used part of every region into `dense` (same capacity) in shard order and writes
 // counters[EV_SUMMARY] = total events, counters[EV_SUMMARY+1] = 1 if any region overflowed.
@@ -106,6 +111,10 @@ struct WindowCallsLaunch {
     int keep_flush = 1;
 };
 void launch_window_calls(const WindowCallsLaunch &w, hipStream_t stream);
+// after launch_window_calls (compact mode): folds the calls of the groups the anchored scan's filter dropped (dropmap: bit e =
+// such a group ends at e; drop_words words) into bitmap[0 .. n_words] and counters[WS_MAX_END], own range only
+void launch_merge_dropmap(const uint32_t *dropmap, uint32_t drop_words, uint32_t n_words, uint32_t own_lo, uint32_t own_hi, uint32_t *bitmap,
+                          uint32_t *counters, hipStream_t stream);
 hipError_t launch_sort_calls(uint64_t *keys_in, uint64_t *vals_in, uint64_t *keys_out, uint64_t *vals_out, uint32_t n, int key_bits,
                              void *scratch, size_t scratch_bytes, hipStream_t stream);
 // bounds of the kept edge calls (edge list sorted by key) -> pend[index in the sorted main list]

@@ -632,10 +632,26 @@ void launch_scan_window(const DevicePlanes &pl, const PerfectLaunch &pp, int all
 // register ring of the last five anchor words and the last three mismatch words.
 constexpr int RUN_SAT = 1 << 20;
 
-__global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, PerfectLaunch pp, int motifs_per_block, int hl,
+//
+// Group filter (round 3).  The window state machine downstream turns every GROUP of pass-streaks (streaks separated by at
+// most 7 failing windows, window_stage.hip) into one addSeed call of length (group end + 7 - group start), and nine such
+// calls in ten fail the stage's length filter (parse_anchored_shiftxor.cpp:572-573) -- yet every streak of every group used
+// to leave the kernel as two 8-byte events (29 of the 42 bytes per base this kernel wrote, two thirds of its time).  Groups
+// are runs of J = closing of the pass bits over gaps <= 7 (6 funnel steps), and a group's length is that of its J run, so
+// the filter is an opening of J with the span `tj` the call must reach (min(cut-off, 23) - 7 <= 16 positions: 8 more steps):
+// streaks of groups that cannot pass leave no event.  Kept regardless are groups that end at an N, at the end of the
+// record, or right before a blocked stretch (the calls of those are made out of turn, "edge" calls downstream): rare, found
+// by a flood from their end marks on a wave-uniform branch.  What a dropped group would have contributed besides its call --
+// a bit in the map of positions at which ordinary calls are made, the largest end of any call -- is a function of where
+// it ends, so its end bit goes to `dropmap` (one OR per lane word and wave at the end of the motif loop).
+// Every decision is a function of absolute positions inside a lane's view (its own words, one word to the left, 24 bits of
+// the right neighbour's first word), so all lanes and tiles agree on every group.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_anchored_kernel(DevicePlanes pl, PerfectLaunch pp, int motifs_per_block, int hl,
                                                             uint32_t *__restrict__ xa, int64_t xa_stride,
                                                             uint64_t *__restrict__ events,
-                                                            uint32_t *__restrict__ counters) {
+                                                            uint32_t *__restrict__ counters,
+                                                            const int32_t *__restrict__ tj_table,
+                                                            uint32_t *__restrict__ dropmap) {
     __shared__ uint32_t s_hi[64 * K + LDS_EXTRA];
     __shared__ uint32_t s_lo[64 * K + LDS_EXTRA];
     __shared__ uint32_t s_brk[64 * K + 8];
@@ -654,7 +670,7 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
         s_hi[i] = pl.hi[first + i];
         s_lo[i] = pl.lo[first + i];
     }
-    for (int i = threadIdx.x; i < 64 * K + 2; i += 256) s_brk[i] = pl.brk[first + i];
+    for (int i = threadIdx.x; i < 64 * K + 3; i += 256) s_brk[i] = pl.brk[first + i];
     __syncthreads();
 
     const int nmb = bm_hi - bm_lo + 1;
@@ -666,20 +682,26 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
     const int lb = lane * K;
     const bool own_lane = lane >= hl && lane < 64 - hl;
     uint32_t H[K + 2], Lo[K + 2];
-    uint32_t EVAL[K + 1];
+    uint32_t EVAL[K + 2];   // words k = -1 .. K: window starting here holds no break
     {
-        uint32_t B[K + 2];
+        uint32_t B[K + 3];
 #pragma unroll
-        for (int j = 0; j < K + 2; j++) { H[j] = s_hi[lb + j]; Lo[j] = s_lo[lb + j]; B[j] = s_brk[lb + j]; }
+        for (int j = 0; j < K + 2; j++) { H[j] = s_hi[lb + j]; Lo[j] = s_lo[lb + j]; }
 #pragma unroll
-        for (int j = 0; j < K + 1; j++) B[j] |= funnel(B[j + 1], B[j], 1);
-        B[K + 1] |= B[K + 1] >> 1;
+        for (int j = 0; j < K + 3; j++) B[j] = s_brk[lb + j];
 #pragma unroll
-        for (int j = 0; j < K + 1; j++) B[j] |= funnel(B[j + 1], B[j], 2);
-        B[K + 1] |= B[K + 1] >> 2;
+        for (int j = 0; j < K + 2; j++) B[j] |= funnel(B[j + 1], B[j], 1);
+        B[K + 2] |= B[K + 2] >> 1;
 #pragma unroll
-        for (int j = 0; j < K + 1; j++) EVAL[j] = ~(B[j] | funnel(B[j + 1], B[j], 4));
+        for (int j = 0; j < K + 2; j++) B[j] |= funnel(B[j + 1], B[j], 2);
+        B[K + 2] |= B[K + 2] >> 2;
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) EVAL[j] = ~(B[j] | funnel(B[j + 1], B[j], 4));
     }
+    // END positions of the groups the filter dropped, OR-ed over this wave's motifs (own words only)
+    uint32_t DROP[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) DROP[k] = 0;
 
     const int64_t w_own0 = tile_base + (int64_t)(lane - hl) * K;    // global index of this lane's word k = 0
     const uint32_t word0 = (uint32_t)w_own0;
@@ -861,7 +883,7 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
             B1[j] = B1[j] | sb | (A1[j] & sa);
             A1[j] = A1[j] | sa;
         }
-        uint32_t PASS[K + 1];
+        uint32_t PASS[K + 2];   // words k = -1 .. K (the last one is the right neighbour's first own word)
 #pragma unroll
         for (int j = 0; j < K + 1; j++) {          // span 8: at least three mismatches fail the window
             const uint32_t sa = funnel(A1[j + 1], A1[j], 4);
@@ -870,13 +892,119 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
             const uint32_t bad = C1[j] | sc | (B1[j] & sa) | (A1[j] & sb);
             PASS[j] = EVAL[j] & ~bad;
         }
+        // ---- group filter: SV bit q = the group that position q belongs to may pass the length filter, or is one of the
+        // groups that are kept regardless (words k = -1 .. K-1; only bit 31 of word -1 is used)
+        const int tj = tj_table ? tj_table[m - pp.m_lo] : 0;          // wave-uniform; 0: every group is kept
+        uint32_t SV[K + 1];
+        if (tj > 0) {
+            PASS[K + 1] = (uint32_t)__shfl_down((int)PASS[1], 1);     // exact in bits 0..23, which is as far as anything below looks
+            uint32_t J[K + 2], W[K + 2];
+            // closing over gaps <= 7: dilate towards higher positions by 7, erode back
+#pragma unroll
+            for (int j = K + 1; j >= 1; j--) J[j] = PASS[j] | funnel(PASS[j], PASS[j - 1], 31);
+            J[0] = PASS[0] | (PASS[0] << 1);
+#pragma unroll
+            for (int j = K + 1; j >= 1; j--) J[j] = J[j] | funnel(J[j], J[j - 1], 30);
+            J[0] = J[0] | (J[0] << 2);
+#pragma unroll
+            for (int j = K + 1; j >= 1; j--) J[j] = J[j] | funnel(J[j], J[j - 1], 28);
+            J[0] = J[0] | (J[0] << 4);
+#pragma unroll
+            for (int j = 0; j < K + 1; j++) J[j] = J[j] & funnel(J[j + 1], J[j], 1);
+            J[K + 1] = J[K + 1] & (J[K + 1] >> 1);
+#pragma unroll
+            for (int j = 0; j < K + 1; j++) J[j] = J[j] & funnel(J[j + 1], J[j], 2);
+            J[K + 1] = J[K + 1] & (J[K + 1] >> 2);
+#pragma unroll
+            for (int j = 0; j < K + 1; j++) J[j] = J[j] & funnel(J[j + 1], J[j], 4);
+            J[K + 1] = J[K + 1] & (J[K + 1] >> 4);
+            // the closing only ever adds bits between pass bits; where it ran out of neighbours (top of word K, bottom of
+            // word -1) it lost some: put the pass bits back so that J covers PASS everywhere
+#pragma unroll
+            for (int j = 0; j < K + 2; j++) J[j] |= PASS[j];
+            // opening with span tj (<= 16): W = erosion anchored at the low end, then dilated back
+#pragma unroll
+            for (int j = 0; j < K + 2; j++) W[j] = J[j];
+            {
+                int span = 1;
+#pragma unroll
+                for (int step = 0; step < 4; step++) {
+                    const int sh = min(span, tj - span);          // wave-uniform
+                    if (sh > 0) {
+#pragma unroll
+                        for (int j = 0; j < K + 1; j++) W[j] = W[j] & funnel(W[j + 1], W[j], (uint32_t)sh);
+                        W[K + 1] = W[K + 1] & (W[K + 1] >> sh);
+                        span += sh;
+                    }
+                }
+                span = 1;
+#pragma unroll
+                for (int step = 0; step < 4; step++) {
+                    const int sh = min(span, tj - span);
+                    if (sh > 0) {
+#pragma unroll
+                        for (int j = K + 1; j >= 1; j--) W[j] = W[j] | funnel(W[j], W[j - 1], (uint32_t)(32 - sh));
+                        W[0] = W[0] | (W[0] << sh);
+                        span += sh;
+                    }
+                }
+            }
+            // groups kept regardless of their length: the group's end E (first position after its J run) is not an evaluated
+            // window (an N or the end of the record closes its last streak), or the window E + 8 is not (its call is made out
+            // of turn).  Short ones among them (< tj <= 16 positions) are found by a flood from E - 1 down the run.
+            auto special_ends = [&](int j) {          // special group ends in word j - 1
+                const uint32_t jprev = j > 0 ? funnel(J[j], J[j - 1], 31) : (J[0] << 1);            // bit b = J at b - 1
+                const uint32_t ev8 = j < K + 1 ? funnel(EVAL[j + 1], EVAL[j], 8) : (EVAL[K + 1] >> 8);      // bit b = EVAL at b + 8
+                const uint32_t g = ~J[j] & jprev & ~(EVAL[j] & ev8);
+                // a group that reaches an own position ends at or beyond the first own position (j = 0: none); ends more than 16
+                // positions beyond the last one cannot belong to a group shorter than tj that reaches it (and J is not exact there)
+                return j == 0 ? 0u : (j == K + 1 ? (g & 0x0000ffffu) : g);
+            };
+            uint32_t special = 0;
+#pragma unroll
+            for (int j = 1; j < K + 2; j++) special |= special_ends(j);
+            if (__ballot(special != 0) != 0ull) {
+                // G := positions of J runs within 16 below a special end
+                uint32_t G[K + 2], JL[K + 2];
+#pragma unroll
+                for (int j = 0; j < K + 2; j++) { JL[j] = J[j]; G[j] = special_ends(j); }
+#pragma unroll
+                for (int j = 0; j < K + 1; j++) G[j] = funnel(G[j + 1], G[j], 1) & J[j];        // E - 1, inside the run
+                G[K + 1] = (G[K + 1] >> 1) & J[K + 1];
+#pragma unroll
+                for (int sh = 1; sh <= 8; sh <<= 1) {
+                    // G |= (G >> sh) & JL, JL[q] = J all ones over q .. q + sh - 1 (... up to the source bit)
+#pragma unroll
+                    for (int j = 0; j < K + 1; j++) G[j] |= funnel(G[j + 1], G[j], (uint32_t)sh) & JL[j];
+                    G[K + 1] |= (G[K + 1] >> sh) & JL[K + 1];
+#pragma unroll
+                    for (int j = 0; j < K + 1; j++) JL[j] = JL[j] & funnel(JL[j + 1], JL[j], (uint32_t)sh);
+                    JL[K + 1] = JL[K + 1] & (JL[K + 1] >> sh);
+                }
+#pragma unroll
+                for (int j = 0; j < K + 1; j++) W[j] |= G[j];
+            }
+#pragma unroll
+            for (int j = 0; j < K + 1; j++) SV[j] = W[j];
+            // ends of the dropped groups (own positions): what their calls would have contributed downstream
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const uint32_t jprev = funnel(J[k + 1], J[k], 31);
+                const uint32_t svprev = funnel(W[k + 1], W[k], 31);
+                DROP[k] |= own_lane ? (~J[k + 1] & jprev & ~svprev) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < K + 1; j++) SV[j] = 0xffffffffu;
+        }
         uint32_t ST[K], EN[K];
         uint32_t any = 0;
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const uint32_t prev = funnel(PASS[k + 1], PASS[k], 31);
-            ST[k] = own_lane ? (PASS[k + 1] & ~prev) : 0u;
-            EN[k] = own_lane ? (~PASS[k + 1] & prev) : 0u;
+            const uint32_t svprev = funnel(SV[k + 1], SV[k], 31);
+            ST[k] = own_lane ? (PASS[k + 1] & ~prev & SV[k + 1]) : 0u;
+            EN[k] = own_lane ? (~PASS[k + 1] & prev & svprev) : 0u;
             any |= ST[k] | EN[k];
         }
         if (__ballot(any != 0) != 0ull) {
@@ -894,10 +1022,15 @@ __global__ __launch_bounds__(256) void scan_anchored_kernel(DevicePlanes pl, Per
         if (s + 4 <= s_last) step(std::integral_constant<int, 4>{}, s + 4);
     }
     sink_flush(sink, stage, staged, lane);
+    if (dropmap != nullptr && own_lane) {
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            if (DROP[k] && w_own0 + k >= 0) atomicOr(&dropmap[w_own0 + k], DROP[k]);
+    }
 }
 
 void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint32_t *xa, int64_t xa_stride,
-                          uint64_t *events, uint32_t *counters, hipStream_t stream) {
+                          uint64_t *events, uint32_t *counters, const int32_t *tj_table, uint32_t *dropmap, hipStream_t stream) {
     const int nm = pp.m_hi - pp.m_lo + 1;
     const int64_t nwords = pl.length / 32 + 1;
     const int hl = anchored_halo_lanes(pp.m_hi);
@@ -911,7 +1044,7 @@ void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint3
     gy = (nm + motifs_per_block - 1) / motifs_per_block;
     dim3 grid((unsigned)ntiles, (unsigned)gy);
     hipLaunchKernelGGL(scan_anchored_kernel, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, hl, xa, xa_stride, events,
-                       counters);
+                       counters, tj_table, dropmap);
 }
 
 // ------------------------------------------------------------------------ event compaction

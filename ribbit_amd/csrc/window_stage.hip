@@ -299,6 +299,37 @@ __global__ __launch_bounds__(256) void edge_bounds_kernel(const uint64_t *__rest
     pend[lo] = bound < 0 ? bound : bound + pos_offset;      // piece coordinates -> record coordinates
 }
 
+// The anchored scan's group filter (kernels.hip) drops the groups whose call cannot pass the length filter before they
+// become events; what such a call would have left here is a bit in the map of ordinary call positions (it is made at
+// end-of-group + 15: its window e + 8 is evaluated, else the group had been kept) and a candidate for the largest end
+// (end-of-group + 7).  dropmap bit e = a dropped group ends at e.  Calls outside the own range are a neighbour's.
+__global__ __launch_bounds__(256) void merge_dropmap_kernel(const uint32_t *__restrict__ dropmap, uint32_t drop_words, uint32_t n_words,
+                                                            uint32_t own_lo, uint32_t own_hi, uint32_t *__restrict__ bitmap,
+                                                            uint32_t *__restrict__ counters) {
+    __shared__ uint32_t s_top;
+    if (threadIdx.x == 0) s_top = 0;
+    __syncthreads();
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    uint32_t top = 0;
+    if (w <= n_words) {
+        const uint32_t hi = w < drop_words ? dropmap[w] : 0u, lo = (w > 0 && w - 1u < drop_words) ? dropmap[w - 1u] : 0u;
+        uint32_t bits = (hi << 15) | (lo >> 17);                      // bit p <- a group ending at p - 15
+        const uint64_t base = (uint64_t)w << 5;
+        if (base + 32u <= own_lo || base >= own_hi) bits = 0;
+        else {
+            if (base < own_lo) bits &= 0xffffffffu << (own_lo - (uint32_t)base);
+            if (base + 32u > own_hi) bits &= 0xffffffffu >> ((uint32_t)(base + 32u) - own_hi);
+        }
+        if (bits) {
+            bitmap[w] |= bits;
+            top = (w << 5) + 31u - (uint32_t)__builtin_clz(bits) - 7u;      // end + 1 of the call made at that position
+        }
+    }
+    if (top) atomicMax(&s_top, top);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_top) atomicMax(&counters[WS_MAX_END], s_top);
+}
+
 __global__ __launch_bounds__(256) void assemble_calls_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ vals,
                                                              uint32_t n, RibbitCall *__restrict__ out, int32_t pos_offset) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -354,6 +385,12 @@ void launch_window_calls(const WindowCallsLaunch &w, hipStream_t stream) {
     a.flush = w.flush; a.bitmap = w.bitmap; a.counters = w.counters;
     a.own_lo = w.own_lo; a.own_hi = w.own_hi; a.z_lo = w.z_lo; a.keep_flush = w.keep_flush;
     hipLaunchKernelGGL(window_calls_kernel, dim3((w.n_streaks + (uint32_t)EMIT_TILE - 1u) / (uint32_t)EMIT_TILE), dim3(256), 0, stream, a);
+}
+
+void launch_merge_dropmap(const uint32_t *dropmap, uint32_t drop_words, uint32_t n_words, uint32_t own_lo, uint32_t own_hi, uint32_t *bitmap,
+                          uint32_t *counters, hipStream_t stream) {
+    hipLaunchKernelGGL(merge_dropmap_kernel, dim3((n_words + 256u) / 256u), dim3(256), 0, stream, dropmap, drop_words, n_words, own_lo, own_hi,
+                       bitmap, counters);
 }
 
 hipError_t launch_sort_calls(uint64_t *keys_in, uint64_t *vals_in, uint64_t *keys_out, uint64_t *vals_out, uint32_t n, int key_bits,

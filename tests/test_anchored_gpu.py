@@ -86,3 +86,56 @@ def test_seed_lists_without_asking_for_the_call_list_first(name, seq, m_lo, m_hi
         assert sc.guard_hits() == o.guard_hits()
         # and the full list is still available afterwards
         assert np.array_equal(sc.anchored_calls().view("<i4"), o.calls(LIST_ANCHORED).view("<i4"))
+
+
+ANCHORED_SPAN = lambda m: int(0.9 * m) if m >= 10 else (m if m > 6 else 10)           # parse_anchored_shiftxor.cpp:572-573
+
+
+@pytest.mark.parametrize("name,seq,m_lo,m_hi", ALL, ids=[c[0] for c in ALL])
+def test_group_filter_of_the_scan_keeps_exactly_what_the_merge_needs(name, seq, m_lo, m_hi):
+    """The compact form of the stage (what the product's merges consume): the scan kernel's group filter drops the groups of
+    pass-streaks whose call cannot pass the length filter before they become events.  The kept calls, the end-of-sequence
+    calls, the largest end of any call and the cursor bounds must be what the oracle's full call list implies -- and exactly
+    what the same path gives with the filter switched off."""
+    from ribbit_amd import STAGE_ANCHORED
+    L = len(seq)
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc, Oracle(seq, m_lo, m_hi) as o:
+        o.run_all()
+        full = o.calls(LIST_ANCHORED)
+        sc.load_record(seq)
+        got = sc.stage_calls_chunk(STAGE_ANCHORED, 0, L + 1, 0, L)
+        events_filtered = sc.last_event_count()
+        os.environ["RIBBIT_NO_GROUP_FILTER"] = "1"
+        try:
+            sc.load_record(seq)
+            plain = sc.stage_calls_chunk(STAGE_ANCHORED, 0, L + 1, 0, L)
+            events_plain = sc.last_event_count()
+        finally:
+            del os.environ["RIBBIT_NO_GROUP_FILTER"]
+    loop = full[full["pos"] < L]
+    keep = (loop["end"] - loop["start"]) >= np.array([ANCHORED_SPAN(int(m)) for m in loop["mlen"]], dtype=np.int64) if len(loop) else np.zeros(0, bool)
+    assert np.array_equal(got["calls"].view("<i4"), loop[keep].view("<i4"))
+    assert np.array_equal(got["flush"].view("<i4"), full[full["pos"] >= L].view("<i4"))
+    assert got["tail_pend"] == (int(loop["end"].max()) if len(loop) else -1)
+    assert not got["inexact"] and events_filtered <= events_plain
+    # cursor bounds: where one is given it is the largest end of any earlier call
+    seen = np.concatenate(([-1], np.maximum.accumulate(loop["end"].astype(np.int64))[:-1]))[keep] if len(loop) else np.zeros(0, np.int64)
+    for a in (got, plain):
+        if a["pend"] is not None:
+            given = a["pend"] >= 0
+            assert np.array_equal(a["pend"][given], seen[given])
+    assert np.array_equal(got["calls"].view("<i4"), plain["calls"].view("<i4")) and got["tail_pend"] == plain["tail_pend"]
+    assert (got["pend"] is None) == (plain["pend"] is None) and (got["pend"] is None or np.array_equal(got["pend"], plain["pend"]))
+
+
+def test_group_filter_cuts_the_event_volume():
+    name, seq, m_lo, m_hi = [c for c in simulated_cases() if c[0] == "sim_cfg2_120k"][0]
+    from ribbit_amd import STAGE_ANCHORED
+    with ribbit_amd.Scanner(m_lo, m_hi) as sc:
+        sc.load_record(seq)
+        sc.anchored_calls()                         # the full call list: no filter
+        unfiltered = sc.last_event_count()
+        sc.load_record(seq)
+        sc.stage_calls_chunk(STAGE_ANCHORED, 0, len(seq) + 1, 0, len(seq))
+        filtered = sc.last_event_count()
+    assert 0 < filtered < unfiltered / 3, (filtered, unfiltered)
