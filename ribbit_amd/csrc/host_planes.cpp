@@ -1,8 +1,40 @@
 #include "host_planes.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <thread>
 
 namespace rb {
+
+std::shared_ptr<const std::vector<uint8_t>> HostPlanes::symbols(unsigned threads) const {
+    std::lock_guard<std::mutex> lk(sym_mu_);
+    if (sym_cache_ && sym_cache_->size() == (size_t)length + 1) return sym_cache_;
+    auto sym = std::make_shared<std::vector<uint8_t>>((size_t)length + 1, (uint8_t)4);
+    uint8_t *out = sym->data();
+    const int64_t nw = (length + 31) / 32;
+    auto decode = [&](int64_t w0, int64_t w1) {
+        for (int64_t w = w0; w < w1; ++w) {
+            const uint32_t h = hi[(size_t)w], l = lo[(size_t)w], b = brk[(size_t)w];
+            const int64_t base = w * 32;
+            const int n = (int)std::min<int64_t>(32, length - base);
+            for (int k = 0; k < n; ++k)
+                out[base + k] = ((b >> k) & 1u) ? (uint8_t)4 : (uint8_t)((((h >> k) & 1u) << 1) | ((l >> k) & 1u));
+        }
+    };
+    if (!threads) {
+        threads = std::min(std::thread::hardware_concurrency(), 16u);
+        if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
+    }
+    threads = (unsigned)std::max<int64_t>(1, std::min<int64_t>(threads, nw / 65536 + 1));
+    if (threads == 1) decode(0, nw);
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back(decode, nw * t / threads, nw * (t + 1) / threads);
+        for (std::thread &th : pool) th.join();
+    }
+    sym_cache_ = sym;
+    return sym_cache_;
+}
 
 void HostPlanes::index_breaks() {
     blocked.clear();

@@ -9,6 +9,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <memory>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -45,7 +47,19 @@ struct HostPlanes {
         hi.assign(nwords, 0); lo.assign(nwords, 0); brk.assign(nwords, 0);
         blocked.clear();
         xa.clear(); xa_view = nullptr; xa_stride = 0; xa_m_lo = 0; xa_m_hi = -1;
+        sym_cache_.reset();
     }
+    // One byte per base (0..3 = A C G T, 4 = N; one pad entry = 4 at position L), decoded from the planes on first use
+    // (host threads) and kept until the record changes: the refinement stages read bases by the hundred million, and
+    // every one of their calls used to decode the whole record again on one thread (a second per chromosome and call).
+    // Thread-safe; the planes must not change while a caller holds the result.
+    std::shared_ptr<const std::vector<uint8_t>> symbols(unsigned threads = 0) const;
+
+  private:
+    mutable std::shared_ptr<const std::vector<uint8_t>> sym_cache_;
+    mutable std::mutex sym_mu_;
+
+  public:
     bool has_xa(int mlen) const { return mlen >= xa_m_lo && mlen <= xa_m_hi; }
     // popcount of XA_mlen over [start, end)
     int range_count_xa(int mlen, int start, int end) const;

@@ -31,17 +31,12 @@ struct Wide {
     }
 };
 
-// one byte per base, decoded once per record from the planes the GPU packed: 0..3 = A C G T, 4 = N
+// one byte per base, decoded once per record from the planes the GPU packed (HostPlanes::symbols): 0..3 = A C G T, 4 = N
 struct Bases {
     int L;
-    std::vector<uint8_t> sym;
-    explicit Bases(const HostPlanes &hp) : L((int)hp.length), sym((size_t)hp.length + 1, 4) {
-        for (int p = 0; p < L; ++p) {
-            const uint32_t bit = 1u << (p & 31);
-            const size_t w = (size_t)(p >> 5);
-            sym[(size_t)p] = (hp.brk[w] & bit) ? 4 : (uint8_t)((((hp.hi[w] & bit) != 0) << 1) | ((hp.lo[w] & bit) != 0));
-        }
-    }
+    std::shared_ptr<const std::vector<uint8_t>> hold;
+    const uint8_t *sym;
+    explicit Bases(const HostPlanes &hp, unsigned threads = 0) : L((int)hp.length), hold(hp.symbols(threads)), sym(hold->data()) {}
     // N encodes as 00 (fasta_utils.cpp:111-113).  D4: a position below 0 -- reachable only after a motif window that
     // starts before the record, where the reference has already terminated in substr -- reads as base A, not N.
     unsigned code(int p) const { return p < 0 ? 0u : sym[(size_t)p] & 3u; }
@@ -303,7 +298,7 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
                       std::string &motif_pool, unsigned host_threads, size_t seed_lo, size_t seed_hi, const SmallMotifTable *small) {
     jobs.clear();
     motif_pool.clear();
-    const Bases b(hp);
+    const Bases b(hp, host_threads);
     seed_hi = std::min(seed_hi, dispatch.size());
     seed_lo = std::min(seed_lo, seed_hi);
     const size_t n = seed_hi - seed_lo;
@@ -337,10 +332,12 @@ std::atomic<long long> g_t_align{0}, g_t_small{0}, g_t_long{0};       // nanosec
 std::atomic<long> g_n_align{0}, g_n_known{0}, g_n_paths{0}, g_n_small_device{0}, g_n_small_host{0};
 std::atomic<long> g_n_flank{0};
 std::atomic<long long> g_t_flank{0}, g_t_whole_first{0};      // profile: flank-recursion alignments; whole first-level alignments on the host
+std::atomic<long long> g_t_digest{0}, g_t_units{0}, g_t_row{0}, g_t_query{0};      // profile: CIGAR digestion, calculateMotifUnits, row text, query / reference strings
+const bool g_profile = std::getenv("RIBBIT_PROFILE") != nullptr;
 struct Stopwatch {
     std::atomic<long long> *acc;
     std::chrono::steady_clock::time_point t0;
-    explicit Stopwatch(std::atomic<long long> *a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    explicit Stopwatch(std::atomic<long long> *a) : acc(g_profile ? a : nullptr) { if (acc) t0 = std::chrono::steady_clock::now(); }
     ~Stopwatch() { if (acc) acc->fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed); }
 };
 
@@ -423,19 +420,19 @@ Repeat digest_cigar(int seed_start, int seq_len, const std::string &text, int un
 int count_units(const Bases &b, int start, int length, int m, uint32_t unit) {
     const int stop = std::min(start + length, b.L - 1);
     const uint32_t mask = m >= 16 ? 0xffffffffu : (1u << (2 * m)) - 1u;
-    std::unordered_map<uint32_t, std::pair<int, int>> seen;     // class -> (last unit start, units)
+    // the reference keeps (last unit start, units) per rotation class in a map and reads the entry of `unit` at the end;
+    // the classes do not interact, so only that one entry is kept here
+    int last_at = 0, units = 0;
     uint32_t window = 0;
     for (int j = start; j < stop; ++j) {
         window = ((window << 2) | b.code(j)) & mask;
         if (!(j - start >= 0.9 * m - 1)) continue;
-        const uint32_t cls = smallest_rotation(window, m);
+        if (smallest_rotation(window, m) != unit) continue;
         const int at = j - (m - 1);
-        auto it = seen.find(cls);
-        if (it == seen.end()) seen[cls] = {at, 1};
-        else if (at - it->second.first >= m) { it->second.first = at; it->second.second += 1; }
+        if (units == 0) { last_at = at; units = 1; }
+        else if (at - last_at >= m) { last_at = at; units += 1; }
     }
-    auto it = seen.find(unit);
-    return it == seen.end() ? 0 : it->second.second;
+    return units;
 }
 
 struct Writer {
@@ -476,7 +473,7 @@ struct Writer {
         }
         if (query.empty()) { saw_empty_query = true; return last_cigar; }
         std::string ref;
-        while ((long)ref.size() <= (long)ppr_len) ref += motif;
+        { Stopwatch swq(&g_t_query); while ((long)ref.size() <= (long)ppr_len) ref += motif; }
         SswResult res;
         {
             Stopwatch sw(&g_t_align);
@@ -491,6 +488,7 @@ struct Writer {
         return last_cigar;
     }
     void row(const Repeat &r, const std::string &motif, int atom, int m, int type) {   // parse_seed.cpp:434-436
+        Stopwatch sw(&g_t_row);
         os << id << "\t" << r.start << "\t" << r.end << "\t" << motif << "\t" << atom << " | " << m << "\t" << r.end - r.start << "\t"
            << (r.end - r.start) / atom << "\t" << r.purity << "\t" << "+\tSEED-" << type << "\t" << r.cigar << "\n";
     }
@@ -511,8 +509,10 @@ struct Writer {
             const std::string motif = spell(unit, m, atom);
             const int qlen = ends[k] - starts[k];
             const std::string cigar = align(slice(starts[k], qlen), motif, padded_length(qlen, m, qlen, prm.purity_threshold), std::max(starts[k], 0));
-            const Repeat r = digest_cigar(starts[k], qlen, cigar, atom, false, prm);
-            const int units = count_units(b, r.start, r.end - r.start, atom, classes[k] >> (2 * (m - atom)));
+            Repeat r;
+            { Stopwatch swd(&g_t_digest); r = digest_cigar(starts[k], qlen, cigar, atom, false, prm); }
+            int units;
+            { Stopwatch swu(&g_t_units); units = count_units(b, r.start, r.end - r.start, atom, classes[k] >> (2 * (m - atom))); }
             if (units >= prm.perfect_units[atom] && r.end - r.start >= prm.min_length[atom]) row(r, motif, atom, m, seed.type);
         }
     }
@@ -530,7 +530,8 @@ struct Writer {
         const std::string motif = spell(unit, m, atom);
         const std::string cigar = align(slice(start, seq_len), motif, padded_length(seq_len, m, seq_len, prm.purity_threshold),
                                         depth == 0 ? std::max(start, 0) : -1);
-        const Repeat r = digest_cigar(start, seq_len, cigar, atom, true, prm);
+        Repeat r;
+        { Stopwatch swd(&g_t_digest); r = digest_cigar(start, seq_len, cigar, atom, true, prm); }
         if (r.alignment_length >= prm.min_length[atom] && r.end - r.start >= prm.min_length[m]) row(r, motif, atom, m, type);
         // flanks on either side of the aligned repeat, if at least MINIMUM_LENGTH[m] long (:443-463)
         const int right_from = r.end - atom;
@@ -552,7 +553,7 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
                    const std::string &sequence_id, std::string &bed, unsigned host_threads,
                    const std::vector<RibbitAlignJob> *jobs, const std::vector<SswEnds> *ends, const std::vector<SswPath> *paths,
                    size_t seed_lo, size_t seed_hi, bool *order_dependent, const SmallMotifTable *small) {
-    const Bases b(hp);
+    const Bases b(hp, host_threads);
     seed_hi = std::min(seed_hi, dispatch.size());
     seed_lo = std::min(seed_lo, seed_hi);
     const size_t n_seeds = seed_hi - seed_lo;
@@ -614,9 +615,10 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
         run_range(seed_lo, seed_hi, w);
         bed += w.os.str();
     }
-    if (std::getenv("RIBBIT_PROFILE"))
-        std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld (%ld with GPU passes, %ld with GPU paths)  small-motif seeds %ld from the GPU / %ld on the host  (summed over threads) align %.2fs (of it %.2fs in %ld flank-recursion alignments, %.2fs in first-level alignments done whole on the host)  small-motif discovery %.2fs  long-motif consensus %.2fs\n",
-                     n_seeds, threads, g_n_align.load(), g_n_known.load(), g_n_paths.load(), g_n_small_device.load(), g_n_small_host.load(), g_t_align.load() * 1e-9, g_t_flank.load() * 1e-9, g_n_flank.load(), g_t_whole_first.load() * 1e-9, g_t_small.load() * 1e-9, g_t_long.load() * 1e-9);
+    if (g_profile)
+        std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld (%ld with GPU passes, %ld with GPU paths)  small-motif seeds %ld from the GPU / %ld on the host  (summed over threads, cumulative) align %.2fs (of it %.2fs in %ld flank-recursion alignments, %.2fs in first-level alignments done whole on the host)  small-motif discovery %.2fs  long-motif consensus %.2fs  CIGAR digestion %.2fs  motif units %.2fs  row text %.2fs  reference strings %.2fs\n",
+                     n_seeds, threads, g_n_align.load(), g_n_known.load(), g_n_paths.load(), g_n_small_device.load(), g_n_small_host.load(), g_t_align.load() * 1e-9, g_t_flank.load() * 1e-9, g_n_flank.load(), g_t_whole_first.load() * 1e-9, g_t_small.load() * 1e-9, g_t_long.load() * 1e-9,
+                     g_t_digest.load() * 1e-9, g_t_units.load() * 1e-9, g_t_row.load() * 1e-9, g_t_query.load() * 1e-9);
 }
 
 void alignment_counters(long &all, long &gpu_passes, long &gpu_paths) { all = g_n_align.load(); gpu_passes = g_n_known.load(); gpu_paths = g_n_paths.load(); }
