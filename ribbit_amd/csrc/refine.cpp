@@ -327,30 +327,56 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
 // Alignment post-processing and BED rows
 namespace {
 
-// RIBBIT_PROFILE=1: wall-clock split of the refinement stages on stderr (summed over the worker threads)
+// RIBBIT_PROFILE=1: wall-clock split of the refinement stages on stderr (summed over the worker threads).
+// Counters and times are gathered per thread and added to the process-wide totals once per chunk of seeds: a shared
+// atomic bumped for every seed by sixteen threads is a cache line in permanent transit.
 std::atomic<long long> g_t_align{0}, g_t_small{0}, g_t_long{0};       // nanoseconds
 std::atomic<long> g_n_align{0}, g_n_known{0}, g_n_paths{0}, g_n_small_device{0}, g_n_small_host{0};
 std::atomic<long> g_n_flank{0};
 std::atomic<long long> g_t_flank{0}, g_t_whole_first{0};      // profile: flank-recursion alignments; whole first-level alignments on the host
-std::atomic<long long> g_t_digest{0}, g_t_units{0}, g_t_row{0}, g_t_query{0};      // profile: CIGAR digestion, calculateMotifUnits, row text, query / reference strings
+std::atomic<long long> g_t_digest{0}, g_t_units{0}, g_t_row{0}, g_t_query{0}, g_t_atom{0}, g_t_small_all{0}, g_t_long_all{0}, g_t_range{0};
 const bool g_profile = std::getenv("RIBBIT_PROFILE") != nullptr;
+struct LocalCounters {
+    long n_align = 0, n_known = 0, n_paths = 0, n_small_device = 0, n_small_host = 0, n_flank = 0;
+    long long t_align = 0, t_small = 0, t_long = 0, t_flank = 0, t_whole_first = 0, t_digest = 0, t_units = 0, t_row = 0, t_query = 0, t_atom = 0,
+              t_small_all = 0, t_long_all = 0, t_range = 0;
+};
+thread_local LocalCounters tl;
+void flush_counters() {
+    g_n_align += tl.n_align; g_n_known += tl.n_known; g_n_paths += tl.n_paths; g_n_small_device += tl.n_small_device;
+    g_n_small_host += tl.n_small_host; g_n_flank += tl.n_flank;
+    g_t_align += tl.t_align; g_t_small += tl.t_small; g_t_long += tl.t_long; g_t_flank += tl.t_flank; g_t_whole_first += tl.t_whole_first;
+    g_t_digest += tl.t_digest; g_t_units += tl.t_units; g_t_row += tl.t_row; g_t_query += tl.t_query; g_t_atom += tl.t_atom;
+    g_t_small_all += tl.t_small_all; g_t_long_all += tl.t_long_all; g_t_range += tl.t_range;
+    tl = LocalCounters{};
+}
 struct Stopwatch {
-    std::atomic<long long> *acc;
+    long long *acc;
     std::chrono::steady_clock::time_point t0;
-    explicit Stopwatch(std::atomic<long long> *a) : acc(g_profile ? a : nullptr) { if (acc) t0 = std::chrono::steady_clock::now(); }
-    ~Stopwatch() { if (acc) acc->fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed); }
+    explicit Stopwatch(long long *a) : acc(g_profile ? a : nullptr) { if (acc) t0 = std::chrono::steady_clock::now(); }
+    ~Stopwatch() { if (acc) *acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
 struct CigarOp { int len; char op; };
 
-std::vector<CigarOp> parse_cigar(const std::string &text) {        // cigarSplit, process_cigar.cpp:14-31
-    std::vector<CigarOp> ops;
+// text += decimal(n) + op, without the temporary std::to_string makes
+inline void put_op(std::string &text, int n, char op) {
+    char buf[12];
+    int at = 12;
+    unsigned v = n < 0 ? 0u - (unsigned)n : (unsigned)n;
+    do { buf[--at] = (char)('0' + v % 10u); v /= 10u; } while (v);
+    if (n < 0) buf[--at] = '-';
+    text.append(buf + at, (size_t)(12 - at));
+    text.push_back(op);
+}
+
+void parse_cigar(const std::string &text, std::vector<CigarOp> &ops) {        // cigarSplit, process_cigar.cpp:14-31
+    ops.clear();
     int n = 0;
     for (char ch : text) {
         if (ch >= '0' && ch <= '9') n = n * 10 + (ch - '0');
         else { ops.push_back({n, ch}); n = 0; }
     }
-    return ops;
 }
 
 struct Repeat { int start, end, alignment_length, match_units; float purity; std::string cigar; };
@@ -360,10 +386,14 @@ struct Repeat { int start, end, alignment_length, match_units; float purity; std
 // match, non-match, match, ...; trimming drops whole block pairs from either end until the purity
 // reaches the threshold (keeping, per trim depth, the longest combination that reaches it).
 Repeat digest_cigar(int seed_start, int seq_len, const std::string &text, int unit_len, bool prune, const RibbitRefineParams &prm) {
-    const std::vector<CigarOp> ops = parse_cigar(text);
+    // scratch that lives as long as the thread: millions of alignments per record, each a handful of operations
+    static thread_local std::vector<CigarOp> ops;
+    static thread_local std::vector<int> block_of;      // compressed-block index of every aligned (non-S) op
+    static thread_local std::vector<int> block_len;     // lengths of the alternating blocks
+    parse_cigar(text, ops);
+    block_of.clear(); block_len.clear();
     Repeat r{seed_start, seed_start + seq_len, 0, 0, 0.f, std::string()};
-    std::vector<int> block_of;      // compressed-block index of every aligned (non-S) op
-    std::vector<int> block_len;     // lengths of the alternating blocks
+    r.cigar.reserve(text.size() + 4);
     int matches = 0, lead_clip = 0;
     bool in_mismatch = false;
     for (size_t i = 0; i < ops.size(); ++i) {
@@ -378,7 +408,7 @@ Repeat digest_cigar(int seed_start, int seq_len, const std::string &text, int un
         } else continue;
         r.alignment_length += o.len;
         block_of.push_back((int)block_len.size() - 1);
-        r.cigar += std::to_string(o.len) + o.op;
+        put_op(r.cigar, o.len, o.op);
     }
     r.purity = float(matches) / float(r.alignment_length);
     if (!prune || !(r.purity < prm.purity_threshold)) return r;
@@ -408,7 +438,7 @@ Repeat digest_cigar(int seed_start, int seq_len, const std::string &text, int un
         const long b = block_of[i];
         if (b < 2L * drop_left) { if (o.op != 'D') r.start += o.len; }
         else if (b <= nb - 1 - 2L * drop_right) {
-            r.cigar += std::to_string(o.len) + o.op;
+            put_op(r.cigar, o.len, o.op);
             if (o.op == 'M' || o.op == '=') r.match_units += o.len / unit_len;
         } else if (o.op != 'D') r.end -= o.len;
     }
@@ -443,11 +473,14 @@ struct Writer {
     const std::string &id;
     std::ostringstream os;
     std::string last_cigar;     // the Alignment object lives across seeds (fasta_utils.cpp:177): an empty query leaves it untouched
+    Writer(const Bases &b_, const HostPlanes &hp_, const char *sequence_, const RibbitRefineParams &prm_, const std::string &id_)
+        : b(b_), hp(hp_), sequence(sequence_), prm(prm_), id(id_) {}
 
-    std::string slice(int start, int len) const {               // sequence.substr(start, len); D4: negative start clamps
+    struct Span { const char *p; int n; };
+    Span slice(int start, int len) const {                      // sequence.substr(start, len), in place; D4: negative start clamps
         if (start < 0) { len += start; start = 0; }
-        if (start >= b.L || len <= 0) return std::string();
-        return std::string(sequence + start, (size_t)std::min(len, b.L - start));
+        if (start >= b.L || len <= 0) return Span{sequence, 0};
+        return Span{sequence + start, std::min(len, b.L - start)};
     }
     bool saw_empty_query = false;   // the one order dependence between seeds: see refine_to_bed
     // first-level alignments whose striped passes the GPU has done already: the jobs of the current seed, in the
@@ -457,62 +490,63 @@ struct Writer {
     const SswPath *paths = nullptr;     // per job; ops == nullptr && !failed: path not found on the GPU, searched here
     size_t next_job = 0, last_job = 0;
     void begin_seed(size_t first, size_t last) { next_job = first; last_job = last; }
-    // query_start < 0: not a first-level alignment (flank recursion), always aligned here
-    std::string align(const std::string &query, const std::string &motif, int ppr_len, int query_start = -1) {
+    std::string ref;                    // the pseudo-perfect repeat of the current alignment (capacity kept from seed to seed)
+    SswResult res;
+    // query_start < 0: not a first-level alignment (flank recursion), always aligned here.  The result is last_cigar.
+    const std::string &align(Span query, const std::string &motif, int ppr_len, int query_start = -1) {
         const SswEnds *known = nullptr;
         const SswPath *known_path = nullptr;
         if (query_start >= 0 && jobs && next_job < last_job) {
             const RibbitAlignJob &jb = jobs[next_job];
             const SswEnds &e = ends[next_job];
             if (e.flag != -1 && jb.query_start == query_start && jb.ppr_length == ppr_len &&
-                (int)query.size() == std::min(jb.query_length, b.L - jb.query_start) && jb.atomicity == (int)motif.size()) {
+                query.n == std::min(jb.query_length, b.L - jb.query_start) && jb.atomicity == (int)motif.size()) {
                 known = &e;
                 if (paths && (paths[next_job].ops || paths[next_job].failed)) known_path = &paths[next_job];
             }
             ++next_job;
         }
-        if (query.empty()) { saw_empty_query = true; return last_cigar; }
-        std::string ref;
-        { Stopwatch swq(&g_t_query); while ((long)ref.size() <= (long)ppr_len) ref += motif; }
-        SswResult res;
+        if (query.n == 0) { saw_empty_query = true; return last_cigar; }
+        { Stopwatch swq(&tl.t_query); ref.clear(); while ((long)ref.size() <= (long)ppr_len) ref += motif; }
         {
-            Stopwatch sw(&g_t_align);
-            Stopwatch sw2(known ? nullptr : (query_start < 0 ? &g_t_flank : &g_t_whole_first));
-            if (query_start < 0) ++g_n_flank;
-            ++g_n_align;
-            if (known && known_path) { ++g_n_known; ++g_n_paths; ssw_finish_with_path(query.data(), (int)query.size(), ref.data(), ppr_len, *known, *known_path, res); }
-            else if (known) { ++g_n_known; ssw_finish(query.data(), (int)query.size(), ref.data(), ppr_len, *known, res); }
-            else ssw_align(query.data(), (int)query.size(), ref.data(), ppr_len, 15, res);
+            Stopwatch sw(&tl.t_align);
+            Stopwatch sw2(known ? nullptr : (query_start < 0 ? &tl.t_flank : &tl.t_whole_first));
+            if (query_start < 0) ++tl.n_flank;
+            ++tl.n_align;
+            if (known && known_path) { ++tl.n_known; ++tl.n_paths; ssw_finish_with_path(query.p, query.n, ref.data(), ppr_len, *known, *known_path, res); }
+            else if (known) { ++tl.n_known; ssw_finish(query.p, query.n, ref.data(), ppr_len, *known, res); }
+            else ssw_align(query.p, query.n, ref.data(), ppr_len, 15, res);
         }
-        last_cigar = res.cigar;
+        last_cigar.swap(res.cigar);
         return last_cigar;
     }
     void row(const Repeat &r, const std::string &motif, int atom, int m, int type) {   // parse_seed.cpp:434-436
-        Stopwatch sw(&g_t_row);
+        Stopwatch sw(&tl.t_row);
         os << id << "\t" << r.start << "\t" << r.end << "\t" << motif << "\t" << atom << " | " << m << "\t" << r.end - r.start << "\t"
            << (r.end - r.start) / atom << "\t" << r.purity << "\t" << "+\tSEED-" << type << "\t" << r.cigar << "\n";
     }
 
     const SmallMotifTable *small = nullptr;     // possibleMotifs of the dispatched seeds from the GPU (optional)
+    std::vector<uint32_t> classes; std::vector<int> cls_starts, cls_ends;      // of the current small-motif seed
     void small_seed(const RibbitSeed &seed, int longest, size_t index) {                // processSeedMotifWise
         const int m = seed.mlen;
         if (longest < prm.continuous_ones_threshold) return;
-        std::vector<uint32_t> classes; std::vector<int> starts, ends;
+        classes.clear(); cls_starts.clear(); cls_ends.clear();
         {
-            Stopwatch sw(&g_t_small);
-            if (small_motifs_from_table(small, index, prm.min_length[m], prm.perfect_units[m], classes, starts, ends)) g_n_small_device += 1;
-            else { g_n_small_host += 1; discover_small_motifs(b, seed.start, usable_length(b, seed.start, seed.end, m), m, prm.min_length[m], prm.perfect_units[m], classes, starts, ends); }
+            Stopwatch sw(&tl.t_small);
+            if (small_motifs_from_table(small, index, prm.min_length[m], prm.perfect_units[m], classes, cls_starts, cls_ends)) tl.n_small_device += 1;
+            else { tl.n_small_host += 1; discover_small_motifs(b, seed.start, usable_length(b, seed.start, seed.end, m), m, prm.min_length[m], prm.perfect_units[m], classes, cls_starts, cls_ends); }
         }
         for (size_t k = 0; k < classes.size(); ++k) {
             const int atom = small_atomicity(classes[k], m);
             Wide unit; unit.limb[0] = classes[k];
             const std::string motif = spell(unit, m, atom);
-            const int qlen = ends[k] - starts[k];
-            const std::string cigar = align(slice(starts[k], qlen), motif, padded_length(qlen, m, qlen, prm.purity_threshold), std::max(starts[k], 0));
+            const int qlen = cls_ends[k] - cls_starts[k];
+            const std::string &cigar = align(slice(cls_starts[k], qlen), motif, padded_length(qlen, m, qlen, prm.purity_threshold), std::max(cls_starts[k], 0));
             Repeat r;
-            { Stopwatch swd(&g_t_digest); r = digest_cigar(starts[k], qlen, cigar, atom, false, prm); }
+            { Stopwatch swd(&tl.t_digest); r = digest_cigar(cls_starts[k], qlen, cigar, atom, false, prm); }
             int units;
-            { Stopwatch swu(&g_t_units); units = count_units(b, r.start, r.end - r.start, atom, classes[k] >> (2 * (m - atom))); }
+            { Stopwatch swu(&tl.t_units); units = count_units(b, r.start, r.end - r.start, atom, classes[k] >> (2 * (m - atom))); }
             if (units >= prm.perfect_units[atom] && r.end - r.start >= prm.min_length[atom]) row(r, motif, atom, m, seed.type);
         }
     }
@@ -524,14 +558,15 @@ struct Writer {
         if (longest < prm.continuous_ones_threshold) return;
         const int seq_len = usable_length(b, start, end, m);
         Wide unit;
-        { Stopwatch sw(&g_t_long); unit = unit_at(b, known_row >= 0 ? known_row : consensus_row(b, start, seq_len, m), m); }
-        const int atom = long_atomicity(unit, m);
+        { Stopwatch sw(&tl.t_long); unit = unit_at(b, known_row >= 0 ? known_row : consensus_row(b, start, seq_len, m), m); }
+        int atom;
+        { Stopwatch swa(&tl.t_atom); atom = long_atomicity(unit, m); }
         if (m % atom != 0) return;
         const std::string motif = spell(unit, m, atom);
-        const std::string cigar = align(slice(start, seq_len), motif, padded_length(seq_len, m, seq_len, prm.purity_threshold),
-                                        depth == 0 ? std::max(start, 0) : -1);
+        const std::string &cigar = align(slice(start, seq_len), motif, padded_length(seq_len, m, seq_len, prm.purity_threshold),
+                                         depth == 0 ? std::max(start, 0) : -1);
         Repeat r;
-        { Stopwatch swd(&g_t_digest); r = digest_cigar(start, seq_len, cigar, atom, true, prm); }
+        { Stopwatch swd(&tl.t_digest); r = digest_cigar(start, seq_len, cigar, atom, true, prm); }
         if (r.alignment_length >= prm.min_length[atom] && r.end - r.start >= prm.min_length[m]) row(r, motif, atom, m, type);
         // flanks on either side of the aligned repeat, if at least MINIMUM_LENGTH[m] long (:443-463)
         const int right_from = r.end - atom;
@@ -573,8 +608,8 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
         for (size_t i = lo; i < hi; ++i) {
             const RibbitSeed &seed = dispatch[i];
             if (!job_first.empty()) w.begin_seed(job_first[i - seed_lo], job_first[i - seed_lo + 1]);
-            if (seed.mlen <= 10) w.small_seed(seed, longest_runs[i], i);
-            else w.long_seed(seed.start, seed.end, seed.mlen, seed.type, longest_runs[i], best_rows ? best_rows[i] : -1, 0);
+            if (seed.mlen <= 10) { Stopwatch sws(&tl.t_small_all); w.small_seed(seed, longest_runs[i], i); }
+            else { Stopwatch swl(&tl.t_long_all); w.long_seed(seed.start, seed.end, seed.mlen, seed.type, longest_runs[i], best_rows ? best_rows[i] : -1, 0); }
         }
     };
     // Seeds are refined independently of each other, except that an alignment with an EMPTY query leaves the
@@ -599,10 +634,12 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
         for (unsigned t = 0; t < threads; ++t)
             pool.emplace_back([&]() {
                 for (size_t c; (c = next.fetch_add(1)) < nchunks;) {
-                    Writer w{b, hp, sequence, prm, sequence_id, {}, {}};
+                    Stopwatch swr(&tl.t_range);
+                    Writer w(b, hp, sequence, prm, sequence_id);
                     run_range(seed_lo + c * chunk, seed_lo + std::min(n_seeds, (c + 1) * chunk), w);
                     if (w.saw_empty_query) empty_seen = true;
                     parts[c] = w.os.str();
+                    flush_counters();
                 }
             });
         for (std::thread &th : pool) th.join();
@@ -611,14 +648,16 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
         else for (const std::string &p : parts) bed += p;
     }
     if (sequential) {
-        Writer w{b, hp, sequence, prm, sequence_id, {}, {}};
+        Writer w(b, hp, sequence, prm, sequence_id);
         run_range(seed_lo, seed_hi, w);
         bed += w.os.str();
+        flush_counters();
     }
     if (g_profile)
-        std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld (%ld with GPU passes, %ld with GPU paths)  small-motif seeds %ld from the GPU / %ld on the host  (summed over threads, cumulative) align %.2fs (of it %.2fs in %ld flank-recursion alignments, %.2fs in first-level alignments done whole on the host)  small-motif discovery %.2fs  long-motif consensus %.2fs  CIGAR digestion %.2fs  motif units %.2fs  row text %.2fs  reference strings %.2fs\n",
+        std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld (%ld with GPU passes, %ld with GPU paths)  small-motif seeds %ld from the GPU / %ld on the host  (summed over threads, cumulative) align %.2fs (of it %.2fs in %ld flank-recursion alignments, %.2fs in first-level alignments done whole on the host)  small-motif discovery %.2fs  long-motif consensus %.2fs  CIGAR digestion %.2fs  motif units %.2fs  row text %.2fs  reference strings %.2fs  long atomicity %.2fs | whole small seeds %.2fs  whole long seeds %.2fs  whole chunks %.2fs\n",
                      n_seeds, threads, g_n_align.load(), g_n_known.load(), g_n_paths.load(), g_n_small_device.load(), g_n_small_host.load(), g_t_align.load() * 1e-9, g_t_flank.load() * 1e-9, g_n_flank.load(), g_t_whole_first.load() * 1e-9, g_t_small.load() * 1e-9, g_t_long.load() * 1e-9,
-                     g_t_digest.load() * 1e-9, g_t_units.load() * 1e-9, g_t_row.load() * 1e-9, g_t_query.load() * 1e-9);
+                     g_t_digest.load() * 1e-9, g_t_units.load() * 1e-9, g_t_row.load() * 1e-9, g_t_query.load() * 1e-9, g_t_atom.load() * 1e-9,
+                     g_t_small_all.load() * 1e-9, g_t_long_all.load() * 1e-9, g_t_range.load() * 1e-9);
 }
 
 void alignment_counters(long &all, long &gpu_passes, long &gpu_paths) { all = g_n_align.load(); gpu_passes = g_n_known.load(); gpu_paths = g_n_paths.load(); }

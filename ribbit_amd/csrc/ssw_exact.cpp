@@ -343,7 +343,8 @@ void ssw_passes(const char *query, int query_len, const char *ref, int ref_len, 
 namespace {
 // everything of an alignment after the passes; gpu_path: the path the GPU found (ssw_path.hip), null = search it here
 void finish(const char *query, int query_len, const char *ref, int ref_len, const SswEnds &e, const SswPath *gpu_path, SswResult &out) {
-    out = SswResult{};
+    out.cigar.clear();              // the caller's buffer keeps its capacity from alignment to alignment
+    out.mismatches = 0; out.skipped = false;
     out.score = e.score; out.ref_end = e.ref_end; out.query_end = e.query_end;
     out.score2 = e.score2; out.ref_end2 = e.ref_end2;
     out.ref_begin = e.ref_begin; out.query_begin = e.query_begin; out.flag = e.flag;
@@ -377,7 +378,14 @@ void finish(const char *query, int query_len, const char *ref, int ref_len, cons
 
     // CIGAR with '=' / 'X' and soft clips, mismatch count (ssw_cpp.cpp:126-207)
     std::string &c = out.cigar;
-    auto put = [&](int n, char op) { c += std::to_string(n); c += op; };
+    auto put = [&](int n, char op) {
+        char buf[12];
+        int at = 12;
+        unsigned v = (unsigned)n;
+        do { buf[--at] = (char)('0' + v % 10u); v /= 10u; } while (v);
+        c.append(buf + at, (size_t)(12 - at));
+        c += op;
+    };
     if (out.query_begin > 0) put(out.query_begin, 'S');
     const int8_t *rp = r.data() + out.ref_begin, *qp = q.data() + out.query_begin;
     int run_eq = 0, run_x = 0;
