@@ -209,6 +209,7 @@ struct RibbitHandle {
     std::string bed;
     int stage_done = STAGE_NONE;          // how far the seed lists have been advanced
     rb::SeedLists lists;
+    RibbitHandle *aux = nullptr;          // helper handle of ribbit_hip_refine_bed: streams and buffers of the long alignment batch
 
     rb::DevicePlanes planes() const {
         rb::DevicePlanes pl;
@@ -1182,6 +1183,7 @@ int ribbit_hip_open(const RibbitScanParams *params, int device, RibbitHandle **o
 
 int ribbit_hip_close(RibbitHandle *h) {
     if (!h) return RIBBIT_OK;
+    if (h->aux) { (void)ribbit_hip_close(h->aux); h->aux = nullptr; }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
@@ -1193,6 +1195,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     h->d_small_head.release(); h->d_small_records.release(); h->d_small_count.release(); h->small_head.release(); h->small_records.release();
     h->h_events.release(); h->h_counters.release(); h->h_query.release();
     h->d_pair_table.release(); h->d_run_base.release(); h->d_pair_partial.release(); h->d_pair_status.release();
+    h->d_tj.release(); h->d_dropmap.release();
     h->h_pub.release(); h->h_runs.release(); h->h_halves.release(); h->d_halves.release();
     h->d_eval.release(); h->d_first_rev.release(); h->d_word_tmp.release(); h->d_last_word.release(); h->d_bitmap.release();
     h->d_edge_tmp.release(); h->d_edge_end1.release(); h->d_ws_counters.release(); h->d_group.release(); h->d_sort_keys.release();
@@ -1381,8 +1384,20 @@ int ribbit_hip_seed_longest_runs(RibbitHandle *h, const int32_t **out, size_t *n
 
 // forward + reverse striped Smith-Waterman passes of every job in one (two) launches; ends[j].flag == -1 where the
 // job is too large for the kernel's LDS budget (the host aligns those)
+// size class of an alignment job on the GPU: 0 / 1 one DPP row resp. one wavefront with short tails, 2 / 3 the long classes
+// (one wavefront for tens of milliseconds), -1 too large for the kernels (the host aligns it)
+static int ssw_class(const RibbitAlignJob &jb) {
+    if (jb.query_length <= rb::SSW_SMALL_Q && jb.ppr_length <= rb::SSW_SMALL_R) return 0;
+    if (jb.query_length <= rb::SSW_BIG_Q && jb.ppr_length <= rb::SSW_BIG_R) return 1;
+    if (jb.query_length <= rb::SSW_HUGE_Q && jb.ppr_length <= rb::SSW_HUGE_R) return 2;
+    if (jb.query_length <= rb::SSW_GIANT_Q && jb.ppr_length <= rb::SSW_GIANT_R) return 3;
+    return -1;
+}
+
+// classes: bit c set = jobs of size class c run here (the others keep flag -1).  pool_resident: the motif pool is on the
+// device already (an earlier call of the same record uploaded it).
 static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const char *pool, size_t pool_len, int mask_len,
-                          std::vector<rb::SswEnds> &ends, bool large_class = true) {
+                          std::vector<rb::SswEnds> &ends, unsigned classes = 0xfu, bool pool_resident = false) {
     static_assert(sizeof(RibbitAlignJob) == 9 * sizeof(int32_t), "job record layout");
     static_assert(sizeof(rb::SswEnds) == 8 * sizeof(int32_t), "ends record layout");
     ends.assign(n, rb::SswEnds{});
@@ -1394,16 +1409,11 @@ static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n,
     // four size classes, each sorted by work (largest first) so that the alignments of a wavefront are alike.  The last one
     // (queries of 2049..4096 bases: a thousand jobs in a 64-Mbp record, and a third of all its alignment cells) runs on the
     // handle's copy stream beside the others: one such alignment occupies its wavefront for tens of milliseconds.
-    const bool no_huge = !large_class;
     std::vector<uint64_t> keyed[4];
     for (size_t j = 0; j < n; ++j) {
         const RibbitAlignJob &jb = jobs[j];
-        int cls;
-        if (jb.query_length <= rb::SSW_SMALL_Q && jb.ppr_length <= rb::SSW_SMALL_R) cls = 0;
-        else if (jb.query_length <= rb::SSW_BIG_Q && jb.ppr_length <= rb::SSW_BIG_R) cls = 1;
-        else if (!no_huge && jb.query_length <= rb::SSW_HUGE_Q && jb.ppr_length <= rb::SSW_HUGE_R) cls = 2;
-        else if (!no_huge && jb.query_length <= rb::SSW_GIANT_Q && jb.ppr_length <= rb::SSW_GIANT_R) cls = 3;
-        else { ends[j].flag = -1; continue; }
+        const int cls = ssw_class(jb);
+        if (cls < 0 || !((classes >> cls) & 1u)) { ends[j].flag = -1; continue; }
         const uint64_t work = (uint64_t)std::max(jb.query_length, 0) * (uint64_t)std::max(jb.ppr_length, 0);      // < 2^25
         keyed[cls].push_back(((0xffffffffull - work) << 32) | (uint64_t)j);
     }
@@ -1422,7 +1432,7 @@ static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n,
     if ((rc = h->d_ssw_pool.ensure(std::max<size_t>(pool_len, 1)))) return rc;
     HIP_TRY(hipMemcpyAsync(h->d_ssw_jobs.p, jobs, n * sizeof(RibbitAlignJob), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_ssw_order.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    if (pool_len) HIP_TRY(hipMemcpyAsync(h->d_ssw_pool.p, pool, pool_len, hipMemcpyHostToDevice, h->stream));
+    if (pool_len && !pool_resident) HIP_TRY(hipMemcpyAsync(h->d_ssw_pool.p, pool, pool_len, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_ssw_out.p, 0xff, n * 8 * sizeof(int32_t), h->stream));      // flag -1 unless a kernel writes the record
     if (n_giant) {
         HIP_TRY(hipEventRecord(h->ev_ssw, h->stream));
@@ -1722,78 +1732,127 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
     bool done = false;
     if (gpu_ssw && !h->dispatch.empty()) {
-        // The record's seeds go through in slices: a feeder thread sets up the alignment jobs of slice c + 1 and runs
-        // their striped passes and path searches on the GPU while the worker threads refine slice c with the results
-        // of its own batch (host copies; the device buffers are the feeder's alone).
+        // All first-level alignment jobs of the record are set up at once (host threads), then:
+        //   * the LONG ones (queries beyond 512 bases: a few thousand per 64 Mbp, but each holds a wavefront for tens of
+        //     milliseconds, and the longest of a batch is that batch's critical path) go to the GPU as ONE batch on a helper
+        //     handle's streams, and the seeds they belong to are set aside;
+        //   * the rest goes through in slices of the seed list: a feeder thread runs a slice's striped passes and path searches
+        //     while the worker threads refine the previous slice with the results of its own batch.  Without the long jobs a
+        //     batch has no tail to wait for, so the slices can be small and the workers start early;
+        //   * the seeds set aside are refined last, when the long batch has landed, and their rows are put in their places.
+        // (Round 2 ran the long classes inside every slice: ~150 ms of tail per slice, which is why two slices were the optimum
+        // and the workers sat idle for the whole first one -- tools/refine_slices_probe.sh.)
+        const size_t n_seeds = h->dispatch.size();
+        std::vector<RibbitAlignJob> jobs;
+        std::string pool;
+        const double t_setup0 = now_ms();
+        rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), jobs, pool, threads, 0, n_seeds, &small);
+        const size_t n_jobs = jobs.size();
+        std::vector<uint32_t> job_first(n_seeds + 1, (uint32_t)n_jobs);
+        for (size_t j = n_jobs; j-- > 0;) job_first[(size_t)jobs[j].seed_index] = (uint32_t)j;
+        for (size_t i = n_seeds; i-- > 0;) job_first[i] = std::min(job_first[i], job_first[i + 1]);
+        static const char *const large_env = std::getenv("RIBBIT_SSW_LARGE");
+        const bool large_class = large_env ? std::atoi(large_env) != 0 : true;        // 0: the long jobs stay on the host threads (a measurement knob)
+        std::vector<uint8_t> set_aside(n_seeds, 0);
+        std::vector<RibbitAlignJob> long_jobs;
+        std::vector<uint32_t> long_index, later;
+        for (size_t j = 0; j < n_jobs; ++j) {
+            const int cls = ssw_class(jobs[j]);
+            if (cls >= 0 && cls < 2) continue;
+            set_aside[(size_t)jobs[j].seed_index] = 1;
+            if (cls >= 2 && large_class) { long_jobs.push_back(jobs[j]); long_index.push_back((uint32_t)j); }
+        }
+        for (size_t i = 0; i < n_seeds; ++i) if (set_aside[i]) later.push_back((uint32_t)i);
+        std::vector<rb::SswEnds> ends(n_jobs);
+        for (rb::SswEnds &e : ends) e.flag = -1;
+        std::vector<rb::SswPath> paths(n_jobs);
+        const double t_setup = now_ms() - t_setup0;
+
+        // ---- the long batch, on a helper handle (own streams and buffers, same device, same resident bases)
+        std::vector<rb::SswEnds> long_ends;
+        std::vector<rb::SswPath> long_paths;
+        std::vector<uint32_t> long_ops;
+        int long_rc = RIBBIT_OK;
+        std::string long_error;
+        double t_long = 0;
+        std::thread long_thread;
+        static const bool fail_later_slices = std::getenv("RIBBIT_DEBUG_FAIL_BATCHES") != nullptr;      // test hook: see below
+        if (!long_jobs.empty()) {
+            if (!h->aux && (rc = ribbit_hip_open(&h->params, h->device, &h->aux))) return rc;
+            RibbitHandle *aux = h->aux;
+            aux->dev_ascii_src = h->dev_ascii_src; aux->length = h->length; aux->loaded = true;
+            long_thread = std::thread([&, aux]() {
+                const double tl0 = now_ms();
+                try {
+                    long_rc = run_ssw_passes(aux, long_jobs.data(), long_jobs.size(), pool.data(), pool.size(), 15, long_ends, 0xcu);
+                    if (!long_rc) long_rc = run_ssw_paths(aux, long_jobs.data(), long_jobs.size(), long_ends, long_paths);
+                    if (!long_rc) {
+                        size_t n_ops = 0;
+                        for (const rb::SswPath &pt : long_paths) if (pt.ops) n_ops = std::max(n_ops, (size_t)(pt.ops - aux->h_path_ops.p) + (size_t)pt.n_ops);
+                        long_ops.assign(aux->h_path_ops.p, aux->h_path_ops.p + n_ops);
+                        for (rb::SswPath &pt : long_paths) if (pt.ops) pt.ops = long_ops.data() + (pt.ops - aux->h_path_ops.p);
+                    } else long_error = g_last_error;
+                } catch (const std::bad_alloc &) { long_rc = RIBBIT_E_NOMEM; long_error = "out of host memory in the long alignment batch"; }
+                t_long = now_ms() - tl0;
+            });
+        }
+
+        // ---- slices of the seed list: 1 per ~256 K seeds, at least 2 (RIBBIT_SSW_SLICES overrides)
+        size_t n_slices = std::max<size_t>(2, std::min<size_t>(64, n_seeds / 262144));
+        if (const char *env = std::getenv("RIBBIT_SSW_SLICES")) n_slices = (size_t)std::max(1, std::atoi(env));
+        n_slices = std::min(n_slices, n_seeds);
         struct Slice {
             size_t lo = 0, hi = 0;
-            std::vector<RibbitAlignJob> jobs;
-            std::string pool;
-            std::vector<rb::SswEnds> ends;
-            std::vector<rb::SswPath> paths;
             std::vector<uint32_t> ops;
             int rc = RIBBIT_OK;
             std::string error;
             bool ready = false;
-            double t_setup = 0, t_passes = 0, t_paths = 0;
+            double t_passes = 0, t_paths = 0;
         };
-        // two slices: the second one's batches run while the workers refine the first (more slices repeat the per-batch
-        // costs: 5.4 s in two, 5.8 s in four at chromosome size); the long class (queries of 513..2048 bases, half of
-        // all alignment time) is what makes the path pay.  RIBBIT_SSW_SLICES / RIBBIT_SSW_LARGE=0 are there to measure with.
-        size_t n_slices = 2;
-        if (const char *env = std::getenv("RIBBIT_SSW_SLICES")) n_slices = (size_t)std::max(1, std::atoi(env));
-        static const char *const large_env = std::getenv("RIBBIT_SSW_LARGE");
-        const bool large_class = large_env ? std::atoi(large_env) != 0 : true;
-        n_slices = std::min(n_slices, h->dispatch.size());
         std::vector<Slice> slices(n_slices);
-        // slice sizes grow by RIBBIT_SSW_SLICE_GROWTH (default 1: equal slices; a measurement knob): a small first slice
-        // starts the workers early.  Measured at chromosome-1 size (refinement): 2 equal slices 5.4 and 5.8 s in two runs,
-        // 3 slices growing x2 5.5 s, 4 growing x2 5.8 s, 3 growing x3 6.2 s -- the later slices' set-up runs on a quarter of
-        // the threads and becomes what the workers wait for; nothing beats two equal slices by more than the run-to-run
-        // spread, so that stays the default
-        double growth = 1.0;
-        if (const char *env = std::getenv("RIBBIT_SSW_SLICE_GROWTH")) growth = std::max(1.0, std::atof(env));
-        {
-            double total = 0, w = 1;
-            for (size_t c = 0; c < n_slices; ++c, w *= growth) total += w;
-            double acc = 0; w = 1;
-            for (size_t c = 0; c < n_slices; ++c, w *= growth) {
-                slices[c].lo = (size_t)((double)h->dispatch.size() * (acc / total));
-                acc += w;
-                slices[c].hi = c + 1 == n_slices ? h->dispatch.size() : (size_t)((double)h->dispatch.size() * (acc / total));
-            }
-        }
+        for (size_t c = 0; c < n_slices; ++c) { slices[c].lo = n_seeds * c / n_slices; slices[c].hi = n_seeds * (c + 1) / n_slices; }
         std::mutex mu;
         std::condition_variable cv;
         std::atomic<bool> stop{false};
-        const unsigned feed_threads = std::max(1u, threads / 4);
-        // a slice whose set-up runs out of host memory takes the same way out as batches that do not fit the device:
-        // RIBBIT_E_NOMEM, and the record is aligned on the host threads
+        // the motif pool of the whole record goes to the device once; every slice's jobs point into it
+        if ((rc = bind_device(h)) || (rc = h->d_ssw_pool.ensure(std::max<size_t>(pool.size(), 1)))) {
+            if (long_thread.joinable()) long_thread.join();
+            if (rc != RIBBIT_E_NOMEM) return rc;
+        } else if (!pool.empty()) {
+            const hipError_t e = hipMemcpy(h->d_ssw_pool.p, pool.data(), pool.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { if (long_thread.joinable()) long_thread.join(); return fail(RIBBIT_E_DEVICE, "upload of the motif pool failed: %s", hipGetErrorString(e)); }
+        }
+        const int pool_rc = rc;
+        rc = RIBBIT_OK;
         auto feed = [&](size_t c) {
             Slice &sl = slices[c];
             try {
-                const double tj = now_ms();
-                rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sl.jobs, sl.pool,
-                                     c == 0 ? threads : feed_threads, sl.lo, sl.hi, &small);
+                const size_t ja = job_first[sl.lo], jb = job_first[sl.hi];
                 const double tp = now_ms();
-                static const bool fail_later_slices = std::getenv("RIBBIT_DEBUG_FAIL_BATCHES") != nullptr;      // test hook: see below
-                sl.rc = (fail_later_slices && c > 0) ? fail(RIBBIT_E_NOMEM, "forced by RIBBIT_DEBUG_FAIL_BATCHES")
-                                                     : run_ssw_passes(h, sl.jobs.data(), sl.jobs.size(), sl.pool.data(), sl.pool.size(), 15, sl.ends, large_class);
+                std::vector<rb::SswEnds> e;
+                std::vector<rb::SswPath> pth;
+                sl.rc = pool_rc ? pool_rc
+                        : (fail_later_slices && c > 0) ? fail(RIBBIT_E_NOMEM, "forced by RIBBIT_DEBUG_FAIL_BATCHES")
+                                                       : run_ssw_passes(h, jobs.data() + ja, jb - ja, pool.data(), pool.size(), 15, e, 0x3u, true);
                 const double tq = now_ms();
-                if (!sl.rc) sl.rc = run_ssw_paths(h, sl.jobs.data(), sl.jobs.size(), sl.ends, sl.paths);
+                if (!sl.rc) sl.rc = run_ssw_paths(h, jobs.data() + ja, jb - ja, e, pth);
                 if (!sl.rc) {
                     // the paths point into the handle's pinned buffer, which the next slice overwrites
                     size_t n_ops = 0;
-                    for (const rb::SswPath &pt : sl.paths) if (pt.ops) n_ops = std::max(n_ops, (size_t)(pt.ops - h->h_path_ops.p) + (size_t)pt.n_ops);
+                    for (const rb::SswPath &pt : pth) if (pt.ops) n_ops = std::max(n_ops, (size_t)(pt.ops - h->h_path_ops.p) + (size_t)pt.n_ops);
                     sl.ops.assign(h->h_path_ops.p, h->h_path_ops.p + n_ops);
-                    for (rb::SswPath &pt : sl.paths) if (pt.ops) pt.ops = sl.ops.data() + (pt.ops - h->h_path_ops.p);
+                    for (size_t k = 0; k < jb - ja; ++k) {
+                        ends[ja + k] = e[k];
+                        paths[ja + k] = pth[k];
+                        if (pth[k].ops) paths[ja + k].ops = sl.ops.data() + (pth[k].ops - h->h_path_ops.p);
+                    }
                 } else {
                     sl.error = g_last_error;
                 }
-                sl.t_setup = tp - tj; sl.t_passes = tq - tp; sl.t_paths = now_ms() - tq;
+                sl.t_passes = tq - tp; sl.t_paths = now_ms() - tq;
             } catch (const std::bad_alloc &) {
                 sl.rc = RIBBIT_E_NOMEM;
-                sl.error = "out of host memory while setting up a slice's alignment batches";
+                sl.error = "out of host memory while running a slice's alignment batches";
             }
         };
         std::thread feeder([&]() {
@@ -1804,30 +1863,33 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                 if (slices[c].rc) break;
             }
         });
-        // whatever happens on this thread from here on (refine_to_bed may throw std::bad_alloc at chromosome size), the
-        // feeder is stopped and joined before the frame goes: a joinable std::thread's destructor ends the process
+        // whatever happens on this thread from here on (refine_to_bed may throw std::bad_alloc at chromosome size), the helper
+        // threads are stopped and joined before the frame goes: a joinable std::thread's destructor ends the process
         struct JoinGuard {
-            std::atomic<bool> &stop; std::thread &t;
-            ~JoinGuard() { stop = true; if (t.joinable()) t.join(); }
-        } join_guard{stop, feeder};
+            std::atomic<bool> &stop; std::thread &a, &b;
+            ~JoinGuard() { stop = true; if (a.joinable()) a.join(); if (b.joinable()) b.join(); }
+        } join_guard{stop, feeder, long_thread};
         bool order_dependent = false;
-        double t_wait = 0, t_setup = 0, t_passes = 0, t_paths = 0;
-        size_t n_jobs = 0;
+        double t_wait = 0, t_passes = 0, t_paths = 0;
+        std::vector<rb::BedPiece> pieces;
         for (size_t c = 0; c < n_slices; ++c) {
             Slice &sl = slices[c];
             const double tw = now_ms();
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return sl.ready; }); }
             t_wait += now_ms() - tw;
             if (sl.rc) { rc = sl.rc; g_last_error = sl.error; break; }
-            t_setup += sl.t_setup; t_passes += sl.t_passes; t_paths += sl.t_paths; n_jobs += sl.jobs.size();
+            t_passes += sl.t_passes; t_paths += sl.t_paths;
             rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
-                              sequence_id, h->bed, h->host_threads, &sl.jobs, &sl.ends, &sl.paths, sl.lo, sl.hi, &order_dependent, &small);
+                              sequence_id, h->bed, h->host_threads, &jobs, &ends, &paths, sl.lo, sl.hi, &order_dependent, &small,
+                              job_first.data(), set_aside.data(), &pieces);
             if (order_dependent) break;
-            sl = Slice{};                                   // free the slice's memory
-            sl.ready = true;
         }
         stop = true;
         feeder.join();
+        const double tw = now_ms();
+        if (long_thread.joinable()) long_thread.join();
+        const double t_wait_long = now_ms() - tw;
+        if (!rc && long_rc) { rc = long_rc; g_last_error = long_error; }
         bool batches_failed = false;
         if (rc == RIBBIT_E_NOMEM) {
             // the batches' buffers did not fit (several large records in flight on one GPU): the alignments of this record
@@ -1837,11 +1899,26 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             batches_failed = true;
         }
         if (rc) return rc;
-        if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs in %zu slices: feeder thread set-up %.1f ms, GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms; workers waited %.1f ms for it\n",
-                                  n_jobs, n_slices, t_setup, t_passes, t_paths, t_wait);
-        add_ms(t_jobs_us, t_wait);
+        if (!order_dependent && !batches_failed) {
+            // the seeds set aside: their long alignments come from the long batch, the others from the slices
+            for (size_t k = 0; k < long_index.size(); ++k) { ends[long_index[k]] = long_ends[k]; paths[long_index[k]] = long_paths[k]; }
+            if (!later.empty())
+                rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
+                                  sequence_id, h->bed, h->host_threads, &jobs, &ends, &paths, 0, n_seeds, &order_dependent, &small, job_first.data(), nullptr,
+                                  &pieces, &later);
+        }
         done = !order_dependent && !batches_failed;
-        if (!done) h->bed.clear();                         // an empty query somewhere (or no batches): the whole record in one call (below)
+        if (done) {
+            std::sort(pieces.begin(), pieces.end(), [](const rb::BedPiece &x, const rb::BedPiece &y) { return x.first_seed < y.first_seed; });
+            size_t total = 0;
+            for (const rb::BedPiece &pc : pieces) total += pc.text.size();
+            h->bed.reserve(total);
+            for (const rb::BedPiece &pc : pieces) h->bed += pc.text;
+        } else h->bed.clear();                         // an empty query somewhere (or no batches): the whole record in one call (below)
+        if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs (%zu long ones in their own batch: %.1f ms; %zu seeds set aside), set-up %.1f ms; %zu slices: "
+                                  "GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms; workers waited %.1f ms for slices, %.1f ms for the long batch\n",
+                                  n_jobs, long_jobs.size(), t_long, later.size(), t_setup, n_slices, t_passes, t_paths, t_wait, t_wait_long);
+        add_ms(t_jobs_us, t_wait + t_wait_long);
     }
     if (!done) {
         t0 = now_ms();

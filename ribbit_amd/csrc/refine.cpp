@@ -587,30 +587,53 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
                    const SeedVec &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
                    const std::string &sequence_id, std::string &bed, unsigned host_threads,
                    const std::vector<RibbitAlignJob> *jobs, const std::vector<SswEnds> *ends, const std::vector<SswPath> *paths,
-                   size_t seed_lo, size_t seed_hi, bool *order_dependent, const SmallMotifTable *small) {
+                   size_t seed_lo, size_t seed_hi, bool *order_dependent, const SmallMotifTable *small,
+                   const uint32_t *job_first_all, const uint8_t *skip, std::vector<BedPiece> *pieces, const std::vector<uint32_t> *only) {
     const Bases b(hp, host_threads);
     seed_hi = std::min(seed_hi, dispatch.size());
     seed_lo = std::min(seed_lo, seed_hi);
-    const size_t n_seeds = seed_hi - seed_lo;
+    if (only) { seed_lo = 0; seed_hi = dispatch.size(); }
+    const size_t n_seeds = only ? only->size() : seed_hi - seed_lo;
+    const bool have_jobs = jobs && ends && ends->size() == jobs->size();
     // first job of every seed of the range (jobs are in seed order)
-    std::vector<uint32_t> job_first;
-    if (jobs && ends && ends->size() == jobs->size()) {
-        job_first.assign(n_seeds + 1, (uint32_t)jobs->size());
+    std::vector<uint32_t> job_first_own;
+    const uint32_t *job_first = nullptr;          // indexed by seed - job_first_base
+    size_t job_first_base = 0;
+    if (have_jobs && job_first_all) job_first = job_first_all;
+    else if (have_jobs) {
+        const size_t span = seed_hi - seed_lo;
+        job_first_own.assign(span + 1, (uint32_t)jobs->size());
         for (size_t j = jobs->size(); j-- > 0;) {
             const size_t si = (size_t)(*jobs)[j].seed_index;
-            if (si >= seed_lo && si < seed_hi) job_first[si - seed_lo] = (uint32_t)j;
+            if (si >= seed_lo && si < seed_hi) job_first_own[si - seed_lo] = (uint32_t)j;
         }
-        for (size_t i = n_seeds; i-- > 0;) job_first[i] = std::min(job_first[i], job_first[i + 1]);
+        for (size_t i = span; i-- > 0;) job_first_own[i] = std::min(job_first_own[i], job_first_own[i + 1]);
+        job_first = job_first_own.data();
+        job_first_base = seed_lo;
     }
-    auto run_range = [&](size_t lo, size_t hi, Writer &w) {
-        if (!job_first.empty()) { w.jobs = jobs->data(); w.ends = ends->data(); w.paths = (paths && paths->size() == jobs->size()) ? paths->data() : nullptr; }
+    auto prepare = [&](Writer &w) {
+        if (have_jobs) { w.jobs = jobs->data(); w.ends = ends->data(); w.paths = (paths && paths->size() == jobs->size()) ? paths->data() : nullptr; }
         w.small = small;
+    };
+    auto one_seed = [&](size_t i, Writer &w) {
+        const RibbitSeed &seed = dispatch[i];
+        if (have_jobs) w.begin_seed(job_first[i - job_first_base], job_first[i - job_first_base + 1]);
+        if (seed.mlen <= 10) { Stopwatch sws(&tl.t_small_all); w.small_seed(seed, longest_runs[i], i); }
+        else { Stopwatch swl(&tl.t_long_all); w.long_seed(seed.start, seed.end, seed.mlen, seed.type, longest_runs[i], best_rows ? best_rows[i] : -1, 0); }
+    };
+    // seeds lo .. hi into `out`; with `skip`, into segments cut at every seed left out
+    auto run_range = [&](size_t lo, size_t hi, Writer &w, std::vector<BedPiece> *segments) {
+        prepare(w);
+        size_t seg_start = lo;
+        auto close_segment = [&](size_t next_start) {
+            if (segments && w.os.tellp() > 0) { segments->push_back(BedPiece{(uint32_t)seg_start, w.os.str()}); w.os.str(std::string()); }
+            seg_start = next_start;
+        };
         for (size_t i = lo; i < hi; ++i) {
-            const RibbitSeed &seed = dispatch[i];
-            if (!job_first.empty()) w.begin_seed(job_first[i - seed_lo], job_first[i - seed_lo + 1]);
-            if (seed.mlen <= 10) { Stopwatch sws(&tl.t_small_all); w.small_seed(seed, longest_runs[i], i); }
-            else { Stopwatch swl(&tl.t_long_all); w.long_seed(seed.start, seed.end, seed.mlen, seed.type, longest_runs[i], best_rows ? best_rows[i] : -1, 0); }
+            if (skip && skip[i]) { close_segment(i + 1); continue; }
+            one_seed(i, w);
         }
+        if (segments) close_segment(hi);
     };
     // Seeds are refined independently of each other, except that an alignment with an EMPTY query leaves the
     // reference's shared Alignment object untouched and so sees the previous seed's CIGAR.  Chunks of seeds
@@ -620,6 +643,31 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
     if (!host_threads)
         if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
     threads = std::max(1u, std::min(threads, 256u));
+    if (only) {
+        // the seeds an earlier call left out, each a piece of its own (they are few and individually expensive)
+        std::vector<BedPiece> &out = *pieces;
+        const size_t base = out.size();
+        out.resize(base + n_seeds);
+        std::atomic<size_t> next{0};
+        std::atomic<bool> empty_seen{false};
+        auto work = [&]() {
+            for (size_t k; (k = next.fetch_add(1)) < n_seeds;) {
+                Writer w(b, hp, sequence, prm, sequence_id);
+                prepare(w);
+                one_seed((*only)[k], w);
+                if (w.saw_empty_query) empty_seen = true;
+                out[base + k] = BedPiece{(*only)[k], w.os.str()};
+            }
+            flush_counters();
+        };
+        threads = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n_seeds));
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread &th : pool) th.join();
+        if (empty_seen && order_dependent) *order_dependent = true;
+        return;
+    }
     if (n_seeds < 512 && !order_dependent) threads = 1;
     bool sequential = threads == 1 && !order_dependent;
     if (!sequential) {
@@ -627,7 +675,8 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
         const size_t chunk = std::min<size_t>(2048, std::max<size_t>(64, n_seeds / (threads * 8)));
         threads = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, (n_seeds + chunk - 1) / chunk));
         const size_t nchunks = (n_seeds + chunk - 1) / chunk;
-        std::vector<std::string> parts(nchunks);
+        std::vector<std::string> parts(pieces ? 0 : nchunks);
+        std::vector<std::vector<BedPiece>> part_pieces(pieces ? nchunks : 0);
         std::atomic<size_t> next{0};
         std::atomic<bool> empty_seen{false};
         std::vector<std::thread> pool;
@@ -636,21 +685,24 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
                 for (size_t c; (c = next.fetch_add(1)) < nchunks;) {
                     Stopwatch swr(&tl.t_range);
                     Writer w(b, hp, sequence, prm, sequence_id);
-                    run_range(seed_lo + c * chunk, seed_lo + std::min(n_seeds, (c + 1) * chunk), w);
+                    run_range(seed_lo + c * chunk, seed_lo + std::min(n_seeds, (c + 1) * chunk), w, pieces ? &part_pieces[c] : nullptr);
                     if (w.saw_empty_query) empty_seen = true;
-                    parts[c] = w.os.str();
-                    flush_counters();
+                    if (!pieces) parts[c] = w.os.str();
                 }
+                flush_counters();
             });
         for (std::thread &th : pool) th.join();
         if (empty_seen && order_dependent) { *order_dependent = true; return; }
         if (empty_seen) sequential = true;
+        else if (pieces) { for (auto &pp : part_pieces) for (BedPiece &pc : pp) pieces->push_back(std::move(pc)); }
         else for (const std::string &p : parts) bed += p;
     }
     if (sequential) {
         Writer w(b, hp, sequence, prm, sequence_id);
-        run_range(seed_lo, seed_hi, w);
-        bed += w.os.str();
+        std::vector<BedPiece> segs;
+        run_range(seed_lo, seed_hi, w, pieces ? &segs : nullptr);
+        if (pieces) for (BedPiece &pc : segs) pieces->push_back(std::move(pc));
+        else bed += w.os.str();
         flush_counters();
     }
     if (g_profile)

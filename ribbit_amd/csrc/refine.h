@@ -51,12 +51,23 @@ int longest_run_host(const HostPlanes &hp, int mlen, int start, int end);
 // (parse_smallmotif_seed.cpp:190-288) for m <= 10, processSeed incl. its recursion on the flanks
 // (parse_seed.cpp:318-464) for m > 10, alignment by ssw_exact, CIGAR processing (process_cigar.cpp:126-336),
 // and the BED rows (11 tab-separated columns) appended to `bed`.  sequence = the record's bases.
+// One run of BED rows: the rows of the seeds from `first_seed` on up to the next piece's first seed.  A record refined in
+// several calls (slices of the seed list, seeds left for a later call) is put together by ordering the pieces by first_seed.
+struct BedPiece { uint32_t first_seed; std::string text; };
+
 void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
                    const SeedVec &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
                    const std::string &sequence_id, std::string &bed, unsigned host_threads = 0,
                    const std::vector<RibbitAlignJob> *jobs = nullptr, const std::vector<SswEnds> *ends = nullptr,
                    const std::vector<SswPath> *paths = nullptr, size_t seed_lo = 0, size_t seed_hi = (size_t)-1,
-                   bool *order_dependent = nullptr, const SmallMotifTable *small = nullptr);
+                   bool *order_dependent = nullptr, const SmallMotifTable *small = nullptr,
+                   const uint32_t *job_first = nullptr, const uint8_t *skip = nullptr, std::vector<BedPiece> *pieces = nullptr,
+                   const std::vector<uint32_t> *only = nullptr);
+// job_first (optional, with jobs): job_first[i] = first job of dispatch seed i, for i = 0 .. dispatch.size() (else it is worked out
+// from the jobs' seed indices on every call).
+// skip (optional, per dispatch seed): seeds left out of this call (their alignments are not ready); pieces must be given, and the
+// output goes there instead of `bed`, cut at every seed left out.
+// only (optional): refine exactly these seeds (indices into dispatch, increasing), one piece each -- the seeds an earlier call left out.
 // seed_lo, seed_hi: refine the seeds dispatch[seed_lo .. seed_hi) only (jobs, if given, are those of that range).
 // order_dependent (optional): a slice cannot resolve the one order dependence between seeds (an empty query sees the
 // previous seed's CIGAR) on its own; when it meets one it appends nothing, sets the flag and the caller redoes the
