@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <new>
 #include <string>
@@ -210,6 +211,7 @@ struct RibbitHandle {
     int stage_done = STAGE_NONE;          // how far the seed lists have been advanced
     rb::SeedLists lists;
     RibbitHandle *aux = nullptr;          // helper handle of ribbit_hip_refine_bed: streams and buffers of the long alignment batch
+    RibbitAlignBatcher *batcher = nullptr;    // shared alignment batches of the records in flight (ribbit_hip_set_batcher)
 
     rb::DevicePlanes planes() const {
         rb::DevicePlanes pl;
@@ -1681,6 +1683,172 @@ int ribbit_host_longest_runs(const RibbitScanParams *params, int64_t length, con
     return RIBBIT_OK;
 }
 
+// ---- alignment batches across the records in flight (include/ribbit_hip.h) ----------------------------------------
+struct AlignSubmission {
+    const RibbitAlignJob *jobs = nullptr; size_t n = 0;
+    const char *pool = nullptr; size_t pool_len = 0;
+    const uint8_t *dev_bases = nullptr; int64_t length = 0;        // the record's bases on the batcher's device
+    std::vector<rb::SswEnds> ends; std::vector<rb::SswPath> paths; std::vector<uint32_t> ops;      // results
+    int rc = RIBBIT_OK; std::string error;
+    bool done = false;
+};
+
+struct RibbitAlignBatcher {
+    RibbitHandle *bh = nullptr;           // streams and buffers of the batches
+    int device = 0;
+    int clients = 1;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv_submit, cv_done;
+    std::deque<AlignSubmission *> queue;
+    bool closing = false;
+    DevBuf<uint8_t> stage;
+    std::atomic<int64_t> n_batches{0}, n_subs{0}, n_jobs{0}, n_gpu{0};
+
+    void run_batch(std::vector<AlignSubmission *> &subs) {
+        constexpr int64_t PAD = 256;          // between records: a kernel never reads one record's bases for another's query
+        std::vector<RibbitAlignJob> jobs;
+        std::string pool;
+        std::vector<int64_t> base_off(subs.size());
+        std::vector<size_t> first(subs.size() + 1, 0);
+        int64_t total = PAD;
+        for (size_t k = 0; k < subs.size(); ++k) { base_off[k] = total; total += subs[k]->length + PAD; first[k + 1] = first[k] + subs[k]->n; }
+        int rc = RIBBIT_OK;
+        std::string error;
+        std::vector<rb::SswEnds> ends;
+        std::vector<rb::SswPath> paths;
+        try {
+            if (total > INT32_MAX) rc = fail(RIBBIT_E_ARG, "alignment batch of %lld staged bases", (long long)total);
+            jobs.reserve(first.back());
+            for (size_t k = 0; k < subs.size() && !rc; ++k) {
+                const AlignSubmission &sb = *subs[k];
+                const int32_t pool_base = (int32_t)pool.size();
+                pool.append(sb.pool, sb.pool_len);
+                for (size_t j = 0; j < sb.n; ++j) {
+                    RibbitAlignJob jb = sb.jobs[j];
+                    // the kernels' own clipping (a negative start clamps, the end clamps to the record), done here against
+                    // the job's OWN record; then into the staging buffer's coordinates
+                    if (jb.query_start < 0) { jb.query_length += jb.query_start; jb.query_start = 0; }
+                    if ((int64_t)jb.query_start + jb.query_length > sb.length) jb.query_length = (int32_t)(sb.length - jb.query_start);
+                    if (jb.query_length < 0) jb.query_length = 0;
+                    jb.query_start += (int32_t)base_off[k];
+                    jb.motif_offset += pool_base;
+                    jobs.push_back(jb);
+                }
+            }
+            if (!rc) rc = bind_device(bh);
+            if (!rc) rc = stage.ensure((size_t)total);
+            if (!rc) {
+                hipError_t e = hipMemsetAsync(stage.p, 'N', (size_t)total, bh->stream);
+                for (size_t k = 0; k < subs.size() && e == hipSuccess; ++k)
+                    if (subs[k]->length)
+                        e = hipMemcpyAsync(stage.p + base_off[k], subs[k]->dev_bases, (size_t)subs[k]->length, hipMemcpyDeviceToDevice, bh->stream);
+                if (e != hipSuccess) rc = fail(RIBBIT_E_DEVICE, "staging the records' bases failed: %s", hipGetErrorString(e));
+            }
+            if (!rc) {
+                bh->dev_ascii_src = stage.p; bh->length = total; bh->loaded = true;
+                rc = run_ssw_passes(bh, jobs.data(), jobs.size(), pool.data(), pool.size(), 15, ends, 0x3u);
+            }
+            if (!rc) rc = run_ssw_paths(bh, jobs.data(), jobs.size(), ends, paths);
+            if (rc) error = g_last_error;
+        } catch (const std::bad_alloc &) { rc = RIBBIT_E_NOMEM; error = "out of host memory in a shared alignment batch"; }
+        int64_t on_gpu = 0;
+        for (size_t k = 0; k < subs.size(); ++k) {
+            AlignSubmission &sb = *subs[k];
+            sb.rc = rc; sb.error = error;
+            if (!rc) {
+                try {
+                    sb.ends.assign(ends.begin() + (std::ptrdiff_t)first[k], ends.begin() + (std::ptrdiff_t)first[k + 1]);
+                    sb.paths.assign(paths.begin() + (std::ptrdiff_t)first[k], paths.begin() + (std::ptrdiff_t)first[k + 1]);
+                    size_t n_ops = 0;
+                    for (const rb::SswPath &pt : sb.paths) if (pt.ops) n_ops += (size_t)pt.n_ops;
+                    sb.ops.resize(n_ops);
+                    size_t at = 0;
+                    for (rb::SswPath &pt : sb.paths)
+                        if (pt.ops) { std::memcpy(sb.ops.data() + at, pt.ops, (size_t)pt.n_ops * sizeof(uint32_t)); pt.ops = sb.ops.data() + at; at += (size_t)pt.n_ops; }
+                    for (const rb::SswEnds &e : sb.ends) on_gpu += e.flag != -1;
+                } catch (const std::bad_alloc &) { sb.rc = RIBBIT_E_NOMEM; sb.error = "out of host memory in a shared alignment batch"; }
+            }
+        }
+        n_batches += 1; n_subs += (int64_t)subs.size(); n_jobs += (int64_t)first.back(); n_gpu += on_gpu;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (AlignSubmission *sb : subs) sb->done = true;
+        }
+        cv_done.notify_all();
+    }
+
+    void loop() {
+        std::vector<AlignSubmission *> subs;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_submit.wait(lk, [&]() { return closing || !queue.empty(); });
+                if (queue.empty()) return;       // closing
+                // a short window for the other records in flight to get here: a batch of everybody's jobs costs little more
+                // than a batch of one record's
+                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
+                cv_submit.wait_until(lk, deadline, [&]() { return closing || (int)queue.size() >= clients; });
+                subs.assign(queue.begin(), queue.end());
+                queue.clear();
+            }
+            run_batch(subs);
+        }
+    }
+
+    // blocks until the submission's results are in place
+    void submit(AlignSubmission &sb) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            queue.push_back(&sb);
+        }
+        cv_submit.notify_all();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&]() { return sb.done; });
+    }
+};
+
+int ribbit_hip_batcher_open(const RibbitScanParams *params, int device, int32_t expected_clients, RibbitAlignBatcher **out) {
+    if (!params || !out) return fail(RIBBIT_E_ARG, "null argument");
+    RibbitAlignBatcher *b = new (std::nothrow) RibbitAlignBatcher();
+    if (!b) return fail(RIBBIT_E_NOMEM, "out of host memory");
+    const int rc = ribbit_hip_open(params, device, &b->bh);
+    if (rc) { delete b; return rc; }
+    b->device = device;
+    b->clients = std::max(1, (int)expected_clients);
+    b->worker = std::thread([b]() { b->loop(); });
+    *out = b;
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_batcher_close(RibbitAlignBatcher *b) {
+    if (!b) return RIBBIT_OK;
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        b->closing = true;
+    }
+    b->cv_submit.notify_all();
+    if (b->worker.joinable()) b->worker.join();
+    (void)hipSetDevice(b->device);
+    b->stage.release();
+    b->bh->dev_ascii_src = nullptr; b->bh->loaded = false;
+    (void)ribbit_hip_close(b->bh);
+    delete b;
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_set_batcher(RibbitHandle *h, RibbitAlignBatcher *b) {
+    if (!h) return fail(RIBBIT_E_ARG, "null argument");
+    if (b && b->device != h->device) return fail(RIBBIT_E_ARG, "the batcher runs on device %d, the handle on device %d", b->device, h->device);
+    h->batcher = b;
+    return RIBBIT_OK;
+}
+
+void ribbit_hip_batcher_stats(const RibbitAlignBatcher *b, int64_t out[4]) {
+    if (!b || !out) return;
+    out[0] = b->n_batches.load(); out[1] = b->n_subs.load(); out[2] = b->n_jobs.load(); out[3] = b->n_gpu.load();
+}
+
 static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const char *sequence_id, const char **text, size_t *len);
 
 int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const char *sequence_id,
@@ -1797,8 +1965,10 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             });
         }
 
-        // ---- slices of the seed list: 1 per ~256 K seeds, at least 2 (RIBBIT_SSW_SLICES overrides)
-        size_t n_slices = std::max<size_t>(2, std::min<size_t>(64, n_seeds / 262144));
+        // ---- slices of the seed list: one per ~600 K seeds, 2 .. 16 (RIBBIT_SSW_SLICES overrides).  Measured at 64 Mbp (4.5 M
+        // seeds; tools/refine_slices_sweep.sh): 2 slices 788 ms, 6 .. 8 757, 17 787, 32 911, 48 1085 -- a slice costs ~10 ms of
+        // launches, copies and synchronisation beyond its kernels
+        size_t n_slices = std::max<size_t>(2, std::min<size_t>(16, n_seeds / 600000));
         if (const char *env = std::getenv("RIBBIT_SSW_SLICES")) n_slices = (size_t)std::max(1, std::atoi(env));
         n_slices = std::min(n_slices, n_seeds);
         struct Slice {
@@ -1919,6 +2089,28 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                                   "GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms; workers waited %.1f ms for slices, %.1f ms for the long batch\n",
                                   n_jobs, long_jobs.size(), t_long, later.size(), t_setup, n_slices, t_passes, t_paths, t_wait, t_wait_long);
         add_ms(t_jobs_us, t_wait + t_wait_long);
+    }
+    static const char *const shared_env = std::getenv("RIBBIT_SHARED_SSW");
+    if (!done && !gpu_ssw && h->batcher && !h->dispatch.empty() && h->dev_ascii_src && !(shared_env && std::atoi(shared_env) == 0)) {
+        // a short record among several in flight: its alignment jobs join the shared batch of this GPU's batcher
+        std::vector<RibbitAlignJob> jobs;
+        std::string pool;
+        rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), jobs, pool, threads, 0, h->dispatch.size(), &small);
+        AlignSubmission sb;
+        sb.jobs = jobs.data(); sb.n = jobs.size(); sb.pool = pool.data(); sb.pool_len = pool.size();
+        sb.dev_bases = h->dev_ascii_src; sb.length = h->length;
+        if (!jobs.empty()) h->batcher->submit(sb);
+        if (sb.rc == RIBBIT_OK) {
+            bool order_dependent = false;
+            if (jobs.empty()) { sb.ends.clear(); sb.paths.clear(); }
+            rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
+                              sequence_id, h->bed, h->host_threads, &jobs, &sb.ends, &sb.paths, 0, (size_t)-1, &order_dependent, &small);
+            done = !order_dependent;
+            if (!done) h->bed.clear();
+        } else if (sb.rc != RIBBIT_E_NOMEM) {
+            g_last_error = sb.error;
+            return sb.rc;
+        }
     }
     if (!done) {
         t0 = now_ms();

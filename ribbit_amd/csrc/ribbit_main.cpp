@@ -362,6 +362,20 @@ int main(int argc, char **argv) {
         handles.push_back(extra);
         handle_dev.push_back(dev);
     }
+    // Short records side by side on one GPU share their alignment batches (the reference aligns seed by seed,
+    // parse_seed.cpp:404 / parse_smallmotif_seed.cpp:270; a read has too few alignments to pay for batches of its own): one
+    // batcher per GPU slot, fed by all of that slot's handles.
+    std::vector<RibbitAlignBatcher *> batchers((size_t)ndev, nullptr);
+    if (jobs > 1 && !failed)
+        for (int d = 0; d < ndev; ++d) {
+            if (ribbit_hip_batcher_open(&scan, devices[(size_t)d], jobs, &batchers[(size_t)d]) != RIBBIT_OK) {
+                std::cerr << "ribbit-hip: no shared alignment batches on GPU " << devices[(size_t)d] << " (" << ribbit_hip_last_error() << ")\n";
+                batchers[(size_t)d] = nullptr;
+                continue;
+            }
+            for (size_t j = 0; j < handles.size(); ++j)
+                if (handle_dev[j] == d) ribbit_hip_set_batcher(handles[j], batchers[(size_t)d]);
+        }
     std::vector<std::thread> pool;
     for (size_t j = 0; j < handles.size(); ++j) pool.emplace_back(worker, handles[j], handle_dev[j]);
 
@@ -405,6 +419,17 @@ int main(int argc, char **argv) {
         } catch (const PathError &e) { failed = true; failure = e.what; }
     }
     if (failed) { std::cerr << "ribbit-hip: " << failure << "\n"; status = 1; }
+    for (size_t j = 0; j < handles.size(); ++j) ribbit_hip_set_batcher(handles[j], nullptr);
+    for (int d = 0; d < ndev; ++d) {
+        if (!batchers[(size_t)d]) continue;
+        if (std::getenv("RIBBIT_PROFILE")) {
+            int64_t st[4] = {0, 0, 0, 0};
+            ribbit_hip_batcher_stats(batchers[(size_t)d], st);
+            std::cerr << "[shared alignment batches] slot " << d << ": " << st[0] << " batches for " << st[1] << " records, " << st[2] << " alignment jobs, "
+                      << st[3] << " of them on the GPU\n";
+        }
+        ribbit_hip_batcher_close(batchers[(size_t)d]);
+    }
     for (size_t j = 1; j < handles.size(); ++j) ribbit_hip_close(handles[j]);
     ribbit_hip_close(h);
     if (reader) ribbit_fasta_close(reader);
