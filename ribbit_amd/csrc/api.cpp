@@ -1749,7 +1749,11 @@ struct RibbitAlignBatcher {
                 bh->dev_ascii_src = stage.p; bh->length = total; bh->loaded = true;
                 rc = run_ssw_passes(bh, jobs.data(), jobs.size(), pool.data(), pool.size(), 15, ends, 0x3u);
             }
-            if (!rc) rc = run_ssw_paths(bh, jobs.data(), jobs.size(), ends, paths);
+            // RIBBIT_BATCH_PATHS=0: striped passes only; the banded path search of these short alignments stays on the records'
+            // host threads (a batch then is one launch and one synchronisation instead of a round per band width)
+            static const bool gpu_paths = !(std::getenv("RIBBIT_BATCH_PATHS") && std::atoi(std::getenv("RIBBIT_BATCH_PATHS")) == 0);
+            if (!rc && gpu_paths) rc = run_ssw_paths(bh, jobs.data(), jobs.size(), ends, paths);
+            else if (!rc) paths.assign(jobs.size(), rb::SswPath{});
             if (rc) error = g_last_error;
         } catch (const std::bad_alloc &) { rc = RIBBIT_E_NOMEM; error = "out of host memory in a shared alignment batch"; }
         int64_t on_gpu = 0;
@@ -1787,7 +1791,8 @@ struct RibbitAlignBatcher {
                 if (queue.empty()) return;       // closing
                 // a short window for the other records in flight to get here: a batch of everybody's jobs costs little more
                 // than a batch of one record's
-                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
+                static const int window_us = std::getenv("RIBBIT_BATCH_WINDOW_US") ? std::max(0, std::atoi(std::getenv("RIBBIT_BATCH_WINDOW_US"))) : 400;
+                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us);
                 cv_submit.wait_until(lk, deadline, [&]() { return closing || (int)queue.size() >= clients; });
                 subs.assign(queue.begin(), queue.end());
                 queue.clear();
@@ -1892,7 +1897,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
     // 6.7 / 5.4 s -- a fixed cost of about 0.1 s per record, then a gain that grows with the record; and 400 records of
     // 50 kb with 8 in flight take 2.28 s instead of 1.3-1.45 s with it.  The switch is the number of dispatched seeds
     // (1.4 M at 20 Mbp); RIBBIT_GPU_SSW=0 / =1 forces it off / on.
-    constexpr size_t GPU_SSW_MIN_SEEDS = 2000000;
+    constexpr size_t GPU_SSW_MIN_SEEDS = 1000000;
     static const char *const gpu_ssw_env = std::getenv("RIBBIT_GPU_SSW");
     const bool gpu_ssw = gpu_ssw_env ? std::atoi(gpu_ssw_env) != 0 : h->dispatch.size() >= GPU_SSW_MIN_SEEDS;
     unsigned threads = h->host_threads ? h->host_threads : std::min(std::thread::hardware_concurrency(), 16u);
@@ -2091,7 +2096,9 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         add_ms(t_jobs_us, t_wait + t_wait_long);
     }
     static const char *const shared_env = std::getenv("RIBBIT_SHARED_SSW");
-    if (!done && !gpu_ssw && h->batcher && !h->dispatch.empty() && h->dev_ascii_src && !(shared_env && std::atoi(shared_env) == 0)) {
+    static const size_t shared_max_seeds = std::getenv("RIBBIT_SHARED_MAX_SEEDS") ? (size_t)std::atoll(std::getenv("RIBBIT_SHARED_MAX_SEEDS")) : 100000;
+    if (!done && !gpu_ssw && h->batcher && !h->dispatch.empty() && h->dispatch.size() <= shared_max_seeds && h->dev_ascii_src &&
+        !(shared_env && std::atoi(shared_env) == 0)) {
         // a short record among several in flight: its alignment jobs join the shared batch of this GPU's batcher
         std::vector<RibbitAlignJob> jobs;
         std::string pool;

@@ -53,7 +53,7 @@ def test_cli_records_dealt_over_several_devices(tmp_path):
     records.insert(3, ("long one", sims[1][1][:150_000]))
     fa, bed, bed2 = tmp_path / "in.fa", tmp_path / "out.bed", tmp_path / "out2.bed"
     write_fasta(str(fa), records)
-    env = dict(os.environ, RIBBIT_PROFILE="1")
+    env = dict(os.environ, RIBBIT_PROFILE="1", RIBBIT_SHARED_SSW="1")
     r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "30", "--devices", "0,0", "--jobs", "2"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -61,13 +61,13 @@ def test_cli_records_dealt_over_several_devices(tmp_path):
     assert bed.read_text() == want
     dealt = [l for l in r.stderr.split("\n") if l.startswith("[devices] slot")]
     assert len(dealt) == 2 and all(" 0 records" not in l for l in dealt), r.stderr[-1500:]
-    # the short records of a slot share their alignment batches (one batcher per GPU slot)
+    # RIBBIT_SHARED_SSW=1: the short records of a slot share their alignment batches (one batcher per GPU slot)
     shared = [l for l in r.stderr.split("\n") if l.startswith("[shared alignment batches]")]
     assert len(shared) == 2 and sum(int(l.split(" alignment jobs, ")[1].split(" ")[0]) for l in shared) > 100, r.stderr[-1500:]
-    # ... and without them (every record aligns on its own host threads) the BED is the same
+    # ... and without them (the default: every record aligns on its own host threads) the BED is the same
     r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed2), "-m", "2", "-M", "30", "--jobs", "3"], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, RIBBIT_SHARED_SSW="0"))
-    assert r.returncode == 0 and bed2.read_text() == want
+                       env=dict(os.environ, RIBBIT_PROFILE="1"))
+    assert r.returncode == 0 and bed2.read_text() == want and "[shared alignment batches]" not in r.stderr
     # the same list through the environment; an unusable list is refused
     r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed2), "-m", "2", "-M", "30"], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, RIBBIT_DEVICES="0,0,0"))
