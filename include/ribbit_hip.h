@@ -558,7 +558,8 @@ void ribbit_runs_free(RibbitRun *runs);
  * the last scan (kernel + pairing + state machine + sort + read-back), all by HIP events on the launch stream;
  * 3 everything after the pairing of the last window stage (device state machine, sort, read-back; wall clock);
  * 4 the host merge of the last window stage (wall clock); 5 that of the substitution stage when
- * ribbit_hip_seeds_anchored ran both stages; 6 / 7 the scan kernel of the substitution / anchored stage (HIP events). */
+ * ribbit_hip_seeds_anchored ran both stages; 6 / 7 the scan kernel of the substitution / anchored stage (HIP events; the
+ * anchored stage runs as two kernels, 7 is both); 8 / 9 its planes kernel (anchors + composition) / its window-scan kernel. */
 int ribbit_hip_last_timing_ms(const RibbitHandle *h, int what, double *ms);
 /* Profiling aid (no effect on results): streams `nbytes` of the loaded record's ASCII buffer /
  * planes through calib_stream_read_kernel so that a PMC pass contains a launch with a known byte

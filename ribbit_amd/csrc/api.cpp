@@ -205,6 +205,8 @@ struct RibbitHandle {
     hipStream_t up_stream = nullptr;      // uploads: the next record's bases travel while this record's kernels run
     hipEvent_t ev_up = nullptr, ev_busy = nullptr;
     hipEvent_t ev_stage[2][2] = {};       // scan kernel of the substitution [0] / anchored [1] stage
+    hipEvent_t ev_planes = nullptr;       // between the two kernels of the anchored stage (planes | window scan)
+    bool planes_timing_valid = false;     // ev_stage[1][0] .. ev_planes .. ev_stage[1][1] bracket the two kernels of one run
     bool have_stage_timing[2] = {false, false};
     const uint8_t *dev_ascii_src = nullptr;
     std::string bed;
@@ -590,7 +592,10 @@ int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks, int (
     rb::PairLaunch pr{};
     pr.m_lo = (uint32_t)h->params.min_motif;
     pr.nm = (uint32_t)(h->params.max_motif - h->params.min_motif + 1);
-    pr.tile_bases = which == 2 ? (uint32_t)rb::anchored_tile_words(rb::anchored_halo_lanes(h->params.max_motif)) * 32u : (uint32_t)rb::TILE_BASES;
+    // the anchored stage runs as two kernels (planes, then the window scan of the planes: kernels.hip) unless
+    // RIBBIT_FUSED_ANCHORED=1 asks for the fused one (a measurement knob)
+    static const bool fused_anchored = std::getenv("RIBBIT_FUSED_ANCHORED") && std::atoi(std::getenv("RIBBIT_FUSED_ANCHORED")) != 0;
+    pr.tile_bases = (which == 2 && fused_anchored) ? (uint32_t)rb::anchored_tile_words(rb::anchored_halo_lanes(h->params.max_motif)) * 32u : (uint32_t)rb::TILE_BASES;
     pr.ntile = (uint32_t)(h->length / pr.tile_bases + 1);
     pr.own_lo = 0; pr.own_hi = INT64_MAX; pr.pos_offset = 0;
     const size_t entries = (size_t)pr.nm * pr.ntile;
@@ -608,6 +613,7 @@ int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks, int (
     const rb::DevicePlanes pl = h->planes();
     uint64_t produced = 0;
     const bool filter = which == 2 && filter_min_span != nullptr && std::getenv("RIBBIT_NO_GROUP_FILTER") == nullptr;
+    bool first_attempt_fit = false;
     const size_t drop_words = (size_t)(h->length / 32 + 1) + 1024;
     h->dropmap_valid = false;
     if (filter) {
@@ -637,8 +643,17 @@ int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks, int (
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
         HIP_TRY(hipEventRecord(h->ev_stage[which - 1][0], h->stream));
         if (which == 1) rb::launch_scan_window(pl, pp, 1, h->d_events.p, h->d_counters.p, h->stream);
-        else rb::launch_scan_anchored(pl, pp, h->d_xa.p, h->xa_stride, h->d_events.p, h->d_counters.p, filter ? h->d_tj.p : nullptr,
+        else if (fused_anchored) rb::launch_scan_anchored(pl, pp, h->d_xa.p, h->xa_stride, h->d_events.p, h->d_counters.p, filter ? h->d_tj.p : nullptr,
+                                                          filter ? h->d_dropmap.p : nullptr, h->stream);
+        else {
+            if (attempt == 0) {          // the planes do not depend on the event capacity: once
+                rb::launch_scan_anchored(pl, pp, h->d_xa.p, h->xa_stride, nullptr, nullptr, nullptr, nullptr, h->stream);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(h->ev_planes, h->stream));
+            }
+            rb::launch_scan_xa_window(pl, pp, h->d_xa.p, h->xa_stride, h->d_events.p, h->d_counters.p, filter ? h->d_tj.p : nullptr,
                                       filter ? h->d_dropmap.p : nullptr, h->stream);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev[3], h->stream));
         HIP_TRY(hipEventRecord(h->ev_stage[which - 1][1], h->stream));
@@ -651,7 +666,7 @@ int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks, int (
         uint32_t worst = 0;
         produced = 0;
         for (int t = 0; t < rb::EV_SHARDS; ++t) { worst = std::max(worst, h->h_pub.p[t]); produced += h->h_pub.p[t]; }
-        if (worst <= pr.region_cap) break;
+        if (worst <= pr.region_cap) { first_attempt_fit = attempt == 0; break; }
         if (attempt == 2 || (size_t)worst * rb::EV_SHARDS > 0xffffff00u)
             return fail(RIBBIT_E_OVERFLOW, "event buffer overflow: fullest region needs %u events", worst);
         cap = ((size_t)worst + 1024) * rb::EV_SHARDS;
@@ -670,6 +685,7 @@ int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks, int (
     *n_streaks = n;
     h->last_streaks = n;
     h->dropmap_valid = filter;
+    if (which == 2) h->planes_timing_valid = !fused_anchored && first_attempt_fit;
     return RIBBIT_OK;
 }
 
@@ -883,7 +899,8 @@ int prepare_anchored(RibbitHandle *h) {
     if (h->params.max_motif > rb::ANCHORED_MAX_MOTIF)
         return fail(RIBBIT_E_ARG, "the anchored stage of this build supports max_motif <= %d (got %d)", rb::ANCHORED_MAX_MOTIF, h->params.max_motif);
     const size_t nm = (size_t)(h->params.max_motif - h->params.min_motif + 1);
-    h->xa_stride = ((h->length / 32 + 1) + 7) / 8 * 8 + 16;
+    // whole tiles of the window kernel that reads the planes back (scan_xa_window_kernel), plus its two words of look-ahead
+    h->xa_stride = (h->length / 32 + 1 + rb::TILE_WORDS - 1) / rb::TILE_WORDS * rb::TILE_WORDS + 16;
     return h->d_xa.ensure(nm * (size_t)h->xa_stride);
 }
 
@@ -1173,6 +1190,7 @@ int ribbit_hip_open(const RibbitScanParams *params, int device, RibbitHandle **o
     if (err == hipSuccess) err = hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&h->ev_busy, hipEventDisableTiming);
     for (int i = 0; i < 4 && err == hipSuccess; ++i) err = hipEventCreate(&h->ev_stage[i / 2][i % 2]);
+    if (err == hipSuccess) err = hipEventCreate(&h->ev_planes);
     for (int i = 0; i < 6 && err == hipSuccess; ++i) err = hipEventCreate(&h->ev[i]);
     if (err != hipSuccess) {
         delete h;
@@ -1210,6 +1228,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     if (h->ev_up) (void)hipEventDestroy(h->ev_up);
     if (h->ev_busy) (void)hipEventDestroy(h->ev_busy);
     for (int i = 0; i < 4; ++i) if (h->ev_stage[i / 2][i % 2]) (void)hipEventDestroy(h->ev_stage[i / 2][i % 2]);
+    if (h->ev_planes) (void)hipEventDestroy(h->ev_planes);
     if (h->up_stream) { (void)hipStreamSynchronize(h->up_stream); (void)hipStreamDestroy(h->up_stream); }
     for (int i = 0; i < 6; ++i) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -2787,7 +2806,16 @@ int ribbit_hip_last_timing_ms(const RibbitHandle *h, int what, double *ms) {
         *ms = f;
         return RIBBIT_OK;
     }
-    if (what < 0 || what > 7) return fail(RIBBIT_E_ARG, "what must be 0..7");
+    if (what == 8 || what == 9) {      // the anchored stage's two kernels: 8 planes (anchors + composition), 9 window scan of the planes
+        if (!h->have_stage_timing[1] || !h->planes_timing_valid) return fail(RIBBIT_E_STATE, "the anchored stage has not run as two kernels on this handle");
+        float f = 0.f;
+        HIP_TRY(hipEventSynchronize(h->ev_stage[1][1]));
+        if (what == 8) HIP_TRY(hipEventElapsedTime(&f, h->ev_stage[1][0], h->ev_planes));
+        else HIP_TRY(hipEventElapsedTime(&f, h->ev_planes, h->ev_stage[1][1]));
+        *ms = f;
+        return RIBBIT_OK;
+    }
+    if (what < 0 || what > 9) return fail(RIBBIT_E_ARG, "what must be 0..9");
     if (!h->have_timing[what]) return fail(RIBBIT_E_STATE, "no timing recorded yet");
     float f = 0.f;
     HIP_TRY(hipEventSynchronize(h->ev[2 * what + 1]));

@@ -39,8 +39,13 @@ void launch_scan_window(const DevicePlanes &pl, const PerfectLaunch &pp, int all
 // and are not kept for another reason (see the kernel), emit no events and leave their end bit in dropmap (words
 // 0 .. L/32, zeroed by the caller) instead.
 constexpr int GROUP_FILTER_MAX = 16;
+// events == nullptr: the planes only (no window scan; tj_table / dropmap unused) -- launch_scan_xa_window does the rest.
 void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint32_t *xa, int64_t xa_stride,
                           uint64_t *events, uint32_t *counters, const int32_t *tj_table, uint32_t *dropmap, hipStream_t stream);
+// The window scan of processShiftXORsAnchored on composed planes already in HBM (xa, xa_stride words per motif, readable up to
+// word ntiles * TILE_WORDS + 2 of every plane): same events and filter as the fused kernel, tiles of TILE_WORDS words.
+void launch_scan_xa_window(const DevicePlanes &pl, const PerfectLaunch &pp, const uint32_t *xa, int64_t xa_stride, uint64_t *events,
+                           uint32_t *counters, const int32_t *tj_table, uint32_t *dropmap, hipStream_t stream);
 
 // Gathers the used part of every region into `dense` (same capacity) in shard order and writes
 // counters[EV_SUMMARY] = total events, counters[EV_SUMMARY+1] = 1 if any region overflowed.

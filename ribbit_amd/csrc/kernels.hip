@@ -199,8 +199,112 @@ __device__ __forceinline__ void stage_events(const uint32_t (&S)[WORDS_PER_LANE]
     __builtin_amdgcn_wave_barrier();
 }
 
-// -------------------------------------------------------------------------- perfect scan
 constexpr int K = WORDS_PER_LANE;
+
+// ------------------------------------------------------------------------- group filter
+// See scan_anchored_kernel.  PASS / EVAL: words k = -1 .. K of the pass bits and of the evaluated-window mask (word K of PASS
+// need only be exact in bits 0..23).  tj (1 < tj <= GROUP_FILTER_MAX, wave-uniform): positions a group must span.
+// SV (words k = -1 .. K-1; of word -1 only bit 31 is meaningful): bit q = the group position q belongs to is kept.
+// DR (own words): END positions of the groups that are dropped.  Called wave-uniformly.
+__device__ __forceinline__ void group_filter(const uint32_t (&PASS)[K + 2], const uint32_t (&EVAL)[K + 2], int tj, uint32_t (&SV)[K + 1],
+                                             uint32_t (&DR)[K]) {
+    uint32_t J[K + 2], W[K + 2];
+    // closing over gaps <= 7: dilate towards higher positions by 7, erode back
+#pragma unroll
+    for (int j = K + 1; j >= 1; j--) J[j] = PASS[j] | funnel(PASS[j], PASS[j - 1], 31);
+    J[0] = PASS[0] | (PASS[0] << 1);
+#pragma unroll
+    for (int j = K + 1; j >= 1; j--) J[j] = J[j] | funnel(J[j], J[j - 1], 30);
+    J[0] = J[0] | (J[0] << 2);
+#pragma unroll
+    for (int j = K + 1; j >= 1; j--) J[j] = J[j] | funnel(J[j], J[j - 1], 28);
+    J[0] = J[0] | (J[0] << 4);
+#pragma unroll
+    for (int j = 0; j < K + 1; j++) J[j] = J[j] & funnel(J[j + 1], J[j], 1);
+    J[K + 1] = J[K + 1] & (J[K + 1] >> 1);
+#pragma unroll
+    for (int j = 0; j < K + 1; j++) J[j] = J[j] & funnel(J[j + 1], J[j], 2);
+    J[K + 1] = J[K + 1] & (J[K + 1] >> 2);
+#pragma unroll
+    for (int j = 0; j < K + 1; j++) J[j] = J[j] & funnel(J[j + 1], J[j], 4);
+    J[K + 1] = J[K + 1] & (J[K + 1] >> 4);
+    // the closing only ever adds bits between pass bits; where it ran out of neighbours (top of word K, bottom of
+    // word -1) it lost some: put the pass bits back so that J covers PASS everywhere
+#pragma unroll
+    for (int j = 0; j < K + 2; j++) J[j] |= PASS[j];
+    // opening with span tj (<= 16): W = erosion anchored at the low end, then dilated back
+#pragma unroll
+    for (int j = 0; j < K + 2; j++) W[j] = J[j];
+    {
+        int span = 1;
+#pragma unroll
+        for (int step = 0; step < 4; step++) {
+            const int sh = min(span, tj - span);          // wave-uniform
+            if (sh > 0) {
+#pragma unroll
+                for (int j = 0; j < K + 1; j++) W[j] = W[j] & funnel(W[j + 1], W[j], (uint32_t)sh);
+                W[K + 1] = W[K + 1] & (W[K + 1] >> sh);
+                span += sh;
+            }
+        }
+        span = 1;
+#pragma unroll
+        for (int step = 0; step < 4; step++) {
+            const int sh = min(span, tj - span);
+            if (sh > 0) {
+#pragma unroll
+                for (int j = K + 1; j >= 1; j--) W[j] = W[j] | funnel(W[j], W[j - 1], (uint32_t)(32 - sh));
+                W[0] = W[0] | (W[0] << sh);
+                span += sh;
+            }
+        }
+    }
+    // groups kept regardless of their length: the group's end E (first position after its J run) is not an evaluated
+    // window (an N or the end of the record closes its last streak), or the window E + 8 is not (its call is made out
+    // of turn).  Short ones among them (< tj <= 16 positions) are found by a flood from E - 1 down the run.
+    auto special_ends = [&](int j) {          // special group ends in word j - 1
+        const uint32_t jprev = j > 0 ? funnel(J[j], J[j - 1], 31) : (J[0] << 1);            // bit b = J at b - 1
+        const uint32_t ev8 = j < K + 1 ? funnel(EVAL[j + 1], EVAL[j], 8) : (EVAL[K + 1] >> 8);      // bit b = EVAL at b + 8
+        const uint32_t g = ~J[j] & jprev & ~(EVAL[j] & ev8);
+        // a group that reaches an own position ends at or beyond the first own position (j = 0: none); ends more than 16
+        // positions beyond the last one cannot belong to a group shorter than tj that reaches it (and J is not exact there)
+        return j == 0 ? 0u : (j == K + 1 ? (g & 0x0000ffffu) : g);
+    };
+    uint32_t special = 0;
+#pragma unroll
+    for (int j = 1; j < K + 2; j++) special |= special_ends(j);
+    if (__ballot(special != 0) != 0ull) {
+        // G := positions of J runs within 16 below a special end
+        uint32_t G[K + 2], JL[K + 2];
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) { JL[j] = J[j]; G[j] = special_ends(j); }
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) G[j] = funnel(G[j + 1], G[j], 1) & J[j];        // E - 1, inside the run
+        G[K + 1] = (G[K + 1] >> 1) & J[K + 1];
+#pragma unroll
+        for (int sh = 1; sh <= 8; sh <<= 1) {
+            // G |= (G >> sh) & JL, JL[q] = J all ones over q .. q + sh - 1 (... up to the source bit)
+#pragma unroll
+            for (int j = 0; j < K + 1; j++) G[j] |= funnel(G[j + 1], G[j], (uint32_t)sh) & JL[j];
+            G[K + 1] |= (G[K + 1] >> sh) & JL[K + 1];
+#pragma unroll
+            for (int j = 0; j < K + 1; j++) JL[j] = JL[j] & funnel(JL[j + 1], JL[j], (uint32_t)sh);
+            JL[K + 1] = JL[K + 1] & (JL[K + 1] >> sh);
+        }
+#pragma unroll
+        for (int j = 0; j < K + 1; j++) W[j] |= G[j];
+    }
+#pragma unroll
+    for (int j = 0; j < K + 1; j++) SV[j] = W[j];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint32_t jprev = funnel(J[k + 1], J[k], 31);
+        const uint32_t svprev = funnel(W[k + 1], W[k], 31);
+        DR[k] = ~J[k + 1] & jprev & ~svprev;
+    }
+}
+
+// -------------------------------------------------------------------------- perfect scan
 constexpr int LDS_EXTRA = 40;   // halo + shifted-operand words (supports shifts < 1024)
 
 // Hot loop of processShiftXORsPerfect (parse_perfect_shiftxor.cpp:173-223).
@@ -646,7 +750,13 @@ constexpr int RUN_SAT = 1 << 20;
 // it ends, so its end bit goes to `dropmap` (one OR per lane word and wave at the end of the motif loop).
 // Every decision is a function of absolute positions inside a lane's view (its own words, one word to the left, 24 bits of
 // the right neighbour's first word), so all lanes and tiles agree on every group.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_anchored_kernel(DevicePlanes pl, PerfectLaunch pp, int motifs_per_block, int hl,
+// EMIT = false: the planes only (anchor classification + composition, XA_m written to HBM); the window scan of those planes is
+// then scan_xa_window_kernel's.  Two kernels instead of one fused one: the fused kernel holds the shifted operands, the
+// five-shift anchor ring AND the window counters' words at once (256 VGPRs, two waves per SIMD, VALUBusy 58 %); apart, the
+// planes kernel and the window kernel each keep half of that and run at twice the occupancy, for one extra read of the
+// planes (max_motif / 8 bytes per base at HBM speed).
+template <bool EMIT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, EMIT ? 2 : 4))) void scan_anchored_kernel(DevicePlanes pl, PerfectLaunch pp, int motifs_per_block, int hl,
                                                             uint32_t *__restrict__ xa, int64_t xa_stride,
                                                             uint64_t *__restrict__ events,
                                                             uint32_t *__restrict__ counters,
@@ -828,8 +938,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (high_len >= 3 && high_len < two_s) keep |= mask_high;
             AN[R][k + 1] = keep;
         }
-        AN[R][0] = __shfl_up(AN[R][K], 1);          // left neighbour's last own word
-        AN[R][K + 1] = __shfl_down(AN[R][1], 1);    // right neighbour's first own word
+        if constexpr (EMIT) {
+            AN[R][0] = __shfl_up(AN[R][K], 1);          // left neighbour's last own word
+            AN[R][K + 1] = __shfl_down(AN[R][1], 1);    // right neighbour's first own word
+        }
 
         const int m = s - 2;
         if (m < wm_lo) return;
@@ -840,17 +952,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // shift s = m + 2; only when m and s straddle a multiple of 32 they are read from LDS
             const int qm = m >> 5;
             const uint32_t rm = (uint32_t)m & 31u;
+            constexpr int J0 = EMIT ? 0 : 1, J1 = EMIT ? K + 2 : K + 1;      // the planes alone need the own words only
             if (qm == cur_q) {
 #pragma unroll
-                for (int j = 0; j < K + 2; j++) {
+                for (int j = J0; j < J1; j++) {
                     const uint32_t hs = funnel(Hq[j + 1], Hq[j], rm);
                     const uint32_t ls = funnel(Lq[j + 1], Lq[j], rm);
                     A1[j] = ((H[j] ^ hs) | (Lo[j] ^ ls)) & ~(AN[R4][j] | AN[R3][j] | AN[R1][j] | AN[R][j]);
                 }
             } else {
-                uint32_t ph = s_hi[lb + qm], pl = s_lo[lb + qm];
+                uint32_t ph = s_hi[lb + J0 + qm], pl = s_lo[lb + J0 + qm];
 #pragma unroll
-                for (int j = 0; j < K + 2; j++) {
+                for (int j = J0; j < J1; j++) {
                     const uint32_t nh = s_hi[lb + j + 1 + qm], nl = s_lo[lb + j + 1 + qm];
                     A1[j] = ((H[j] ^ funnel(nh, ph, rm)) | (Lo[j] ^ funnel(nl, pl, rm))) & ~(AN[R4][j] | AN[R3][j] | AN[R1][j] | AN[R][j]);
                     ph = nh; pl = nl;
@@ -869,6 +982,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (w_own0 + k < xa_stride) dst[k] = ~A1[k + 1];
             }
         }
+        if constexpr (!EMIT) return;
 #pragma unroll
         for (int j = 0; j < K + 2; j++) {          // span 2
             const uint32_t sa = (j <= K) ? funnel(A1[j + 1 <= K + 1 ? j + 1 : j], A1[j], 1) : (A1[j] >> 1);
@@ -897,102 +1011,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int tj = tj_table ? tj_table[m - pp.m_lo] : 0;          // wave-uniform; 0: every group is kept
         uint32_t SV[K + 1];
         if (tj > 0) {
-            PASS[K + 1] = (uint32_t)__shfl_down((int)PASS[1], 1);     // exact in bits 0..23, which is as far as anything below looks
-            uint32_t J[K + 2], W[K + 2];
-            // closing over gaps <= 7: dilate towards higher positions by 7, erode back
+            PASS[K + 1] = (uint32_t)__shfl_down((int)PASS[1], 1);     // exact in bits 0..23, which is as far as the filter looks
+            uint32_t DR[K];
+            group_filter(PASS, EVAL, tj, SV, DR);
 #pragma unroll
-            for (int j = K + 1; j >= 1; j--) J[j] = PASS[j] | funnel(PASS[j], PASS[j - 1], 31);
-            J[0] = PASS[0] | (PASS[0] << 1);
-#pragma unroll
-            for (int j = K + 1; j >= 1; j--) J[j] = J[j] | funnel(J[j], J[j - 1], 30);
-            J[0] = J[0] | (J[0] << 2);
-#pragma unroll
-            for (int j = K + 1; j >= 1; j--) J[j] = J[j] | funnel(J[j], J[j - 1], 28);
-            J[0] = J[0] | (J[0] << 4);
-#pragma unroll
-            for (int j = 0; j < K + 1; j++) J[j] = J[j] & funnel(J[j + 1], J[j], 1);
-            J[K + 1] = J[K + 1] & (J[K + 1] >> 1);
-#pragma unroll
-            for (int j = 0; j < K + 1; j++) J[j] = J[j] & funnel(J[j + 1], J[j], 2);
-            J[K + 1] = J[K + 1] & (J[K + 1] >> 2);
-#pragma unroll
-            for (int j = 0; j < K + 1; j++) J[j] = J[j] & funnel(J[j + 1], J[j], 4);
-            J[K + 1] = J[K + 1] & (J[K + 1] >> 4);
-            // the closing only ever adds bits between pass bits; where it ran out of neighbours (top of word K, bottom of
-            // word -1) it lost some: put the pass bits back so that J covers PASS everywhere
-#pragma unroll
-            for (int j = 0; j < K + 2; j++) J[j] |= PASS[j];
-            // opening with span tj (<= 16): W = erosion anchored at the low end, then dilated back
-#pragma unroll
-            for (int j = 0; j < K + 2; j++) W[j] = J[j];
-            {
-                int span = 1;
-#pragma unroll
-                for (int step = 0; step < 4; step++) {
-                    const int sh = min(span, tj - span);          // wave-uniform
-                    if (sh > 0) {
-#pragma unroll
-                        for (int j = 0; j < K + 1; j++) W[j] = W[j] & funnel(W[j + 1], W[j], (uint32_t)sh);
-                        W[K + 1] = W[K + 1] & (W[K + 1] >> sh);
-                        span += sh;
-                    }
-                }
-                span = 1;
-#pragma unroll
-                for (int step = 0; step < 4; step++) {
-                    const int sh = min(span, tj - span);
-                    if (sh > 0) {
-#pragma unroll
-                        for (int j = K + 1; j >= 1; j--) W[j] = W[j] | funnel(W[j], W[j - 1], (uint32_t)(32 - sh));
-                        W[0] = W[0] | (W[0] << sh);
-                        span += sh;
-                    }
-                }
-            }
-            // groups kept regardless of their length: the group's end E (first position after its J run) is not an evaluated
-            // window (an N or the end of the record closes its last streak), or the window E + 8 is not (its call is made out
-            // of turn).  Short ones among them (< tj <= 16 positions) are found by a flood from E - 1 down the run.
-            auto special_ends = [&](int j) {          // special group ends in word j - 1
-                const uint32_t jprev = j > 0 ? funnel(J[j], J[j - 1], 31) : (J[0] << 1);            // bit b = J at b - 1
-                const uint32_t ev8 = j < K + 1 ? funnel(EVAL[j + 1], EVAL[j], 8) : (EVAL[K + 1] >> 8);      // bit b = EVAL at b + 8
-                const uint32_t g = ~J[j] & jprev & ~(EVAL[j] & ev8);
-                // a group that reaches an own position ends at or beyond the first own position (j = 0: none); ends more than 16
-                // positions beyond the last one cannot belong to a group shorter than tj that reaches it (and J is not exact there)
-                return j == 0 ? 0u : (j == K + 1 ? (g & 0x0000ffffu) : g);
-            };
-            uint32_t special = 0;
-#pragma unroll
-            for (int j = 1; j < K + 2; j++) special |= special_ends(j);
-            if (__ballot(special != 0) != 0ull) {
-                // G := positions of J runs within 16 below a special end
-                uint32_t G[K + 2], JL[K + 2];
-#pragma unroll
-                for (int j = 0; j < K + 2; j++) { JL[j] = J[j]; G[j] = special_ends(j); }
-#pragma unroll
-                for (int j = 0; j < K + 1; j++) G[j] = funnel(G[j + 1], G[j], 1) & J[j];        // E - 1, inside the run
-                G[K + 1] = (G[K + 1] >> 1) & J[K + 1];
-#pragma unroll
-                for (int sh = 1; sh <= 8; sh <<= 1) {
-                    // G |= (G >> sh) & JL, JL[q] = J all ones over q .. q + sh - 1 (... up to the source bit)
-#pragma unroll
-                    for (int j = 0; j < K + 1; j++) G[j] |= funnel(G[j + 1], G[j], (uint32_t)sh) & JL[j];
-                    G[K + 1] |= (G[K + 1] >> sh) & JL[K + 1];
-#pragma unroll
-                    for (int j = 0; j < K + 1; j++) JL[j] = JL[j] & funnel(JL[j + 1], JL[j], (uint32_t)sh);
-                    JL[K + 1] = JL[K + 1] & (JL[K + 1] >> sh);
-                }
-#pragma unroll
-                for (int j = 0; j < K + 1; j++) W[j] |= G[j];
-            }
-#pragma unroll
-            for (int j = 0; j < K + 1; j++) SV[j] = W[j];
-            // ends of the dropped groups (own positions): what their calls would have contributed downstream
-#pragma unroll
-            for (int k = 0; k < K; k++) {
-                const uint32_t jprev = funnel(J[k + 1], J[k], 31);
-                const uint32_t svprev = funnel(W[k + 1], W[k], 31);
-                DROP[k] |= own_lane ? (~J[k + 1] & jprev & ~svprev) : 0u;
-            }
+            for (int k = 0; k < K; k++) DROP[k] |= own_lane ? DR[k] : 0u;
         } else {
 #pragma unroll
             for (int j = 0; j < K + 1; j++) SV[j] = 0xffffffffu;
@@ -1043,8 +1066,146 @@ void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint3
     int motifs_per_block = (nm + gy - 1) / gy;
     gy = (nm + motifs_per_block - 1) / motifs_per_block;
     dim3 grid((unsigned)ntiles, (unsigned)gy);
-    hipLaunchKernelGGL(scan_anchored_kernel, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, hl, xa, xa_stride, events,
-                       counters, tj_table, dropmap);
+    if (events != nullptr)
+        hipLaunchKernelGGL(scan_anchored_kernel<true>, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, hl, xa, xa_stride, events,
+                           counters, tj_table, dropmap);
+    else
+        hipLaunchKernelGGL(scan_anchored_kernel<false>, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, hl, xa, xa_stride, events,
+                           counters, tj_table, dropmap);
+}
+
+// ------------------------------------------------------------- window scan of composed planes
+// The 6-of-8 window scan of processShiftXORsAnchored (parse_anchored_shiftxor.cpp:580-679) on the composed planes XA_m that
+// scan_anchored_kernel<false> wrote: per (tile, motif) a lane loads its eight words of the plane and three neighbours, counts
+// mismatches (the complement of the plane) over every 8-window bit-sliced, and emits the START / END events of the pass-streaks
+// the group filter keeps (see scan_anchored_kernel).  No shifted operands, no anchor ring: ~110 VGPRs, four to five waves per
+// SIMD.  Same event conventions as the other scan kernels, tiles of TILE_WORDS words.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_xa_window_kernel(DevicePlanes pl, PerfectLaunch pp, int motifs_per_block,
+                                                             const uint32_t *__restrict__ xa, int64_t xa_stride,
+                                                             uint64_t *__restrict__ events, uint32_t *__restrict__ counters,
+                                                             const int32_t *__restrict__ tj_table, uint32_t *__restrict__ dropmap) {
+    __shared__ uint64_t s_stage[4][EV_STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t tile_base = (int64_t)blockIdx.x * TILE_WORDS;
+    const int bm_lo = pp.m_lo + (int)blockIdx.y * motifs_per_block;
+    const int bm_hi = min(pp.m_hi, bm_lo + motifs_per_block - 1);
+    const int wm_lo = bm_lo + wave;          // motifs dealt round-robin to the 4 waves
+    const int wm_hi = bm_hi;
+    if (wm_lo > wm_hi) return;
+
+    const int64_t w0 = tile_base + (int64_t)lane * K;      // global index of this lane's word k = 0
+    uint32_t EVAL[K + 2];   // words k = -1 .. K: window starting here holds no break
+    {
+        uint32_t B[K + 3];
+#pragma unroll
+        for (int j = 0; j < K + 3; j++) B[j] = pl.brk[w0 - 1 + j];
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) B[j] |= funnel(B[j + 1], B[j], 1);
+        B[K + 2] |= B[K + 2] >> 1;
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) B[j] |= funnel(B[j + 1], B[j], 2);
+        B[K + 2] |= B[K + 2] >> 2;
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) EVAL[j] = ~(B[j] | funnel(B[j + 1], B[j], 4));
+    }
+    uint32_t DROP[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) DROP[k] = 0;
+    const int64_t length = pl.length;
+    const uint32_t word0 = (uint32_t)w0;
+
+    EventSink sink;
+    sink.events = events;
+    sink.counters = counters;
+    sink.region_cap = pp.ev_cap / EV_SHARDS;
+    sink.shard = (blockIdx.x * 4u + (uint32_t)wave + blockIdx.y) % EV_SHARDS;
+    volatile uint64_t *stage = s_stage[wave];
+    int staged = 0;
+
+    for (int m = wm_lo; m <= wm_hi; m += 4) {
+        // mismatch words k = -1 .. K+1: the complement of the composed plane.  The planes have no lead padding: the word before
+        // the record reads as all mismatches (no window is evaluated there anyway)
+        const uint32_t *plane = xa + (int64_t)(m - pp.m_lo) * xa_stride;
+        uint32_t A1[K + 3], B1[K + 3], C1[K + 3];
+        A1[0] = w0 > 0 ? ~plane[w0 - 1] : 0xffffffffu;
+        {
+            const uint4 v0 = *reinterpret_cast<const uint4 *>(plane + w0), v1 = *reinterpret_cast<const uint4 *>(plane + w0 + 4);
+            A1[1] = ~v0.x; A1[2] = ~v0.y; A1[3] = ~v0.z; A1[4] = ~v0.w;
+            A1[5] = ~v1.x; A1[6] = ~v1.y; A1[7] = ~v1.z; A1[8] = ~v1.w;
+        }
+        A1[K + 1] = ~plane[w0 + K];
+        A1[K + 2] = ~plane[w0 + K + 1];
+#pragma unroll
+        for (int j = 0; j < K + 3; j++) {          // span 2
+            const uint32_t sa = j < K + 2 ? funnel(A1[j + 1], A1[j], 1) : (A1[j] >> 1);
+            B1[j] = A1[j] & sa;
+            A1[j] = A1[j] | sa;
+        }
+#pragma unroll
+        for (int j = 0; j < K + 3; j++) {          // span 4
+            const uint32_t sa = j < K + 2 ? funnel(A1[j + 1], A1[j], 2) : (A1[j] >> 2);
+            const uint32_t sb = j < K + 2 ? funnel(B1[j + 1], B1[j], 2) : (B1[j] >> 2);
+            C1[j] = (B1[j] & sa) | (A1[j] & sb);
+            B1[j] = B1[j] | sb | (A1[j] & sa);
+            A1[j] = A1[j] | sa;
+        }
+        uint32_t PASS[K + 2];   // words k = -1 .. K
+#pragma unroll
+        for (int j = 0; j < K + 2; j++) {          // span 8: at least three mismatches fail the window
+            const uint32_t sa = funnel(A1[j + 1], A1[j], 4);
+            const uint32_t sb = funnel(B1[j + 1], B1[j], 4);
+            const uint32_t sc = funnel(C1[j + 1], C1[j], 4);
+            const uint32_t bad = C1[j] | sc | (B1[j] & sa) | (A1[j] & sb);
+            PASS[j] = EVAL[j] & ~bad;
+        }
+        const int tj = tj_table ? tj_table[m - pp.m_lo] : 0;          // wave-uniform; 0: every group is kept
+        uint32_t SV[K + 1];
+        if (tj > 0) {
+            uint32_t DR[K];
+            group_filter(PASS, EVAL, tj, SV, DR);
+#pragma unroll
+            for (int k = 0; k < K; k++) DROP[k] |= DR[k];
+        } else {
+#pragma unroll
+            for (int j = 0; j < K + 1; j++) SV[j] = 0xffffffffu;
+        }
+        uint32_t ST[K], EN[K];
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint32_t prev = funnel(PASS[k + 1], PASS[k], 31);
+            const uint32_t svprev = funnel(SV[k + 1], SV[k], 31);
+            ST[k] = PASS[k + 1] & ~prev & SV[k + 1];
+            EN[k] = ~PASS[k + 1] & prev & svprev;
+            any |= ST[k] | EN[k];
+        }
+        if (__ballot(any != 0) != 0ull) {
+            stage_events(ST, EN, word0, (uint32_t)m, sink, stage, staged, lane, [&](int k, uint32_t b, uint32_t pos) {
+                if ((EVAL[k + 1] >> b) & 1u) return (uint32_t)EV_END_ZERO;
+                return ((int64_t)pos + 7 >= length) ? (uint32_t)EV_END_EOS : (uint32_t)EV_END_N;
+            });
+        }
+    }
+    sink_flush(sink, stage, staged, lane);
+    if (dropmap != nullptr) {
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            if (DROP[k]) atomicOr(&dropmap[w0 + k], DROP[k]);
+    }
+}
+
+void launch_scan_xa_window(const DevicePlanes &pl, const PerfectLaunch &pp, const uint32_t *xa, int64_t xa_stride, uint64_t *events,
+                           uint32_t *counters, const int32_t *tj_table, uint32_t *dropmap, hipStream_t stream) {
+    const int nm = pp.m_hi - pp.m_lo + 1;
+    if (nm <= 0 || pl.ntiles <= 0) return;
+    int64_t want_y = (2048 + pl.ntiles - 1) / pl.ntiles;
+    int max_y = (nm + 3) / 4;
+    int gy = (int)(want_y < 1 ? 1 : (want_y > max_y ? max_y : want_y));
+    int motifs_per_block = (nm + gy - 1) / gy;
+    gy = (nm + motifs_per_block - 1) / motifs_per_block;
+    hipLaunchKernelGGL(scan_xa_window_kernel, dim3((unsigned)pl.ntiles, (unsigned)gy), dim3(256), 0, stream, pl, pp, motifs_per_block, xa, xa_stride,
+                       events, counters, tj_table, dropmap);
 }
 
 // ------------------------------------------------------------------------ event compaction

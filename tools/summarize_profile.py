@@ -59,7 +59,9 @@ for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "VALUBus
 # the window-stage scan kernels (launched once per pass by --stage-kernels, on the same 100-Mbp record): per base, so
 # that bench.py can scale them to the chromosome-sized record of its configs[2] leg
 bases = bench["config"]["bases_per_gpu"]
-for key, needle in (("scan_window_kernel", "scan_window_kernel<1>"), ("scan_anchored_kernel", "scan_anchored_kernel")):
+# (the anchored stage runs as two kernels since round 3: the planes kernel scan_anchored_kernel<false> and the window scan of the
+# planes scan_xa_window_kernel; "scan_anchored_kernel" below is whichever instantiation ran)
+for key, needle in (("scan_window_kernel", "scan_window_kernel<1>"), ("scan_anchored_kernel", "scan_anchored_kernel"), ("scan_xa_window_kernel", "scan_xa_window_kernel")):
     k = [name for name in pmc if needle in name]
     if not k or "FETCH_SIZE" not in pmc[k[0]] or "WRITE_SIZE" not in pmc[k[0]]:
         continue
