@@ -233,9 +233,15 @@ def chr1_full_path(ribbit_amd, bases: int, device: int, traffic: dict):
         achieved = bases * ALGO_BYTES_PER_BASE / (ms * 1e-3) / 1e9
         r = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
              "kernel_ms": ms, "algorithmic_bytes_per_launch": bases * ALGO_BYTES_PER_BASE, "kernel_gbases_per_s": bases / (ms * 1e-3) / 1e9, "traffic": None}
+        if key == "scan_anchored_kernel" and traffic and traffic.get("anchored_stage_scan_hbm_bytes_per_base") is not None:
+            key = "anchored_stage_scan"          # the stage's scan is two kernels (planes, window scan of the planes): their sum
+            r["kernels"] = traffic.get("anchored_stage_scan_kernels")
         if key and traffic and traffic.get(key + "_hbm_bytes_per_base") is not None:
             # PMC passes were taken on a 100-Mbp record (profiles/): bytes per base carry over, the record is all that differs
             r["traffic"] = traffic[key + "_hbm_bytes_per_base"] * bases
+            r["traffic_over_algorithmic"] = traffic[key + "_hbm_bytes_per_base"] / ALGO_BYTES_PER_BASE
+            if traffic.get(key + "_hbm_write_bytes_per_base") is not None:
+                r["hbm_write_bytes_per_base"] = traffic[key + "_hbm_write_bytes_per_base"]
             r["traffic_source"] = f"profiles/{traffic.get('tag', '?')} PMC passes (FETCH_SIZE x correction + WRITE_SIZE) per base x this record"
             if traffic.get(key + "_SQ_INSTS_VALU_per_base") is not None:
                 r["valu_wave_instr_per_base"] = traffic[key + "_SQ_INSTS_VALU_per_base"]

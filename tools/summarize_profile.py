@@ -74,6 +74,12 @@ for key, needle in (("scan_window_kernel", "scan_window_kernel<1>"), ("scan_anch
     for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "VALUBusy", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
         if c in m:
             out[key + "_" + c + ("" if c == "VALUBusy" else "_per_base")] = m[c]["mean"] / (1 if c == "VALUBusy" else bases)
+# the anchored stage's scan as a whole = its two kernels
+if "scan_xa_window_kernel_hbm_bytes_per_base" in out and "scan_anchored_kernel_hbm_bytes_per_base" in out:
+    for q in ("hbm_read_bytes_per_base", "hbm_write_bytes_per_base", "hbm_bytes_per_base", "SQ_INSTS_VALU_per_base", "SQ_INSTS_SALU_per_base"):
+        if ("scan_anchored_kernel_" + q) in out and ("scan_xa_window_kernel_" + q) in out:
+            out["anchored_stage_scan_" + q] = out["scan_anchored_kernel_" + q] + out["scan_xa_window_kernel_" + q]
+    out["anchored_stage_scan_kernels"] = ["scan_anchored_kernel<false> (planes)", "scan_xa_window_kernel"]
 with open(os.path.join(dst, "traffic.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out, indent=1))
