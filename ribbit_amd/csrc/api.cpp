@@ -985,8 +985,8 @@ int advance_to_anchored(RibbitHandle *h) {
     h->merge_ms = now_ms() - t0;
     static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
     if (profile)
-        std::fprintf(stderr, "[anchored merge] %zu seeds: %u ranges on %u threads%s, preparation %.1f ms, merges %.1f ms (%.1f ms of it joining the ranges' lists), dispatch order %.1f ms in %u ranges\n",
-                     h->lists.anchored.size(), st.ranges, st.threads, st.redone_in_order ? (st.head_writes ? " (REDONE IN ORDER: list-head writes)" : " (REDONE IN ORDER: first range empty)") : "", st.prepare_ms, st.merge_ms, st.concat_ms, now_ms() - t1, dispatch_ranges);
+        std::fprintf(stderr, "[anchored merge] %zu seeds: %u ranges on %u threads%s, %u passes, %lld changing head writes, %u ranges done again, preparation %.1f ms, merges %.1f ms (%.1f ms of it joining the ranges' lists), dispatch order %.1f ms in %u ranges\n",
+                     h->lists.anchored.size(), st.ranges, st.threads, st.redone_in_order ? " (REDONE IN ORDER)" : (st.head_writes ? " (list-head writes: ranges done again, see passes)" : ""), st.passes, st.head_writes, st.ranges_redone, st.prepare_ms, st.merge_ms, st.concat_ms, now_ms() - t1, dispatch_ranges);
     h->subst_merge_ms = subst_todo ? merge_s : 0.0;
     h->stage_done = STAGE_ANCHORED;
     return RIBBIT_OK;
@@ -2364,7 +2364,7 @@ int32_t ribbit_debug_last_dispatch_ranges(void) { return (int32_t)rb::last_dispa
 void ribbit_debug_last_merge(int stage, int32_t out[5]) {
     const rb::MergeStats st = rb::last_merge_stats(stage);
     out[0] = (int32_t)st.ranges; out[1] = (int32_t)st.ranges_redone; out[2] = st.redone_in_order ? 1 : 0;
-    out[3] = (int32_t)std::min<long long>(st.head_writes, INT32_MAX); out[4] = st.first_range_empty ? 1 : 0;
+    out[3] = (int32_t)std::min<long long>(st.head_writes, INT32_MAX); out[4] = (st.first_range_empty ? 1 : 0) | (int32_t)(st.passes << 8);
 }
 
 int ribbit_hip_set_timing(RibbitHandle *h, int32_t enabled) {

@@ -322,6 +322,7 @@ struct RangeState {
     std::vector<ListRefs::TypeWrite> undo;
     std::vector<ListRefs::TypeRead> foreign_reads;
     std::vector<ListRefs::HeadWrite> head_writes;
+    uint64_t head_reads[2] = {0, 0};      // which list-head entries the coverage code read by loop counter (seed_lists.h)
     int64_t guard_hits = 0;
     Cursor2 cursor;
     void reset(bool sentinel, size_t expect) {
@@ -333,6 +334,7 @@ struct RangeState {
         if (sentinel) own.push_back(SENTINEL);
         guard_hits = 0;
         head_writes.clear();
+        head_reads[0] = head_reads[1] = 0;
     }
     // every seed of an earlier range whose type steered a decision here still has that type (types only ever go to
     // "retired", and earlier ranges are final when this is asked)
@@ -464,9 +466,14 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
     st.prepare_ms = now_ms() - t0;
     const double t1 = now_ms();
     st.cut_pos = cut_pos;
-    st.ranges_redone = run_and_validate(nr, threads, first, state, [&](size_t k, RangeState &me) {
+    // One range's calls.  live == false (the parallel pass): Q8's writes to list heads are logged, not made.  live == true
+    // (a range done again on its own, everything before it final): they are made, and `changes` tells which entries' start /
+    // end / motif size they changed.
+    auto body = [&](size_t k, RangeState &me, bool live, uint64_t *changes) {
         ListRefs l(lists.perfect, lists.subst, me.own, lists.range_count, lists.length, lists.max_motif);
-        l.head_write_log = &me.head_writes;
+        l.head_write_log = live ? nullptr : &me.head_writes;
+        l.head_reads = me.head_reads;
+        l.head_changes = live ? changes : nullptr;
         l.undo = &me.undo;
         l.foreign_reads = &me.foreign_reads;
         l.range_lo = cut_pos[k];
@@ -480,18 +487,61 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
         }
         me.guard_hits = l.guard_hits;
         me.cursor = r.cur;
-    });
-    // Q8 writes to list heads the ranges logged: harmless iff each leaves its target as it is now (every range is final
-    // here, and nothing but such a write changes a head entry after the range that holds it)
+    };
+    // Q8 (parse_anchored_shiftxor.cpp:511-522): the coverage code reads and writes entries at the HEAD of the perfect and
+    // substitution lists by loop counter, from anywhere in the record.  Until round 3 a logged write that would change its
+    // target sent the whole stage back to one thread (5 s instead of 0.4 for a chromosome) -- "never met" on the test
+    // records, met on two of three chromosome-sized ones.  Now the ranges are walked in order after the parallel pass: a
+    // range whose logged writes would change anything is done again on its own with the writes made; if that changed what
+    // the by-counter reads see (start, end, motif size of an entry) and a later range read such an entry, the ranges behind
+    // it run again in parallel against the new heads -- one more pass per change that matters, not a sequential stage.
+    const size_t n_heads_p = std::min<size_t>(lists.perfect.size(), 4096), n_heads_s = std::min<size_t>(lists.subst.size(), 4096);
+    const SeedVec saved_heads_p(lists.perfect.begin(), lists.perfect.begin() + (long)n_heads_p);
+    const SeedVec saved_heads_s(lists.subst.begin(), lists.subst.begin() + (long)n_heads_s);
+    auto differs = [](const RibbitSeed &t, const RibbitSeed &v) { return t.start != v.start || t.end != v.end || t.mlen != v.mlen || t.type != v.type; };
+    size_t done = 0;
+    bool fallback = std::getenv("RIBBIT_MERGE_FORCE_REDO") != nullptr;      // (the variable: test hook)
     int64_t head_writes = 0;
-    for (const RangeState &r : state)
-        for (const ListRefs::HeadWrite &w : r.head_writes) {
-            const RibbitSeed &t = *w.target;
-            head_writes += !(t.start == w.value.start && t.end == w.value.end && t.mlen == w.value.mlen && t.type == w.value.type);
+    unsigned passes = 0;
+    while (done < nr && !fallback) {
+        if (++passes > 16) { fallback = true; break; }
+        const size_t from = done;
+        run_ranges(nr - from, threads, [&](size_t q) {
+            const size_t k = from + q;
+            state[k].reset(k > 0, first[k + 1] - first[k]);
+            body(k, state[k], false, nullptr);
+        });
+        bool again = false;
+        size_t k = from;
+        for (; k < nr; ++k) {
+            bool redo = k > 0 && !state[k].reads_still_valid();
+            int64_t changing = 0;
+            for (const ListRefs::HeadWrite &w : state[k].head_writes) changing += differs(*w.target, w.value);
+            head_writes += changing;
+            uint64_t ch[2] = {0, 0};
+            if (redo || changing) {
+                state[k].reset(k > 0, first[k + 1] - first[k]);
+                body(k, state[k], true, ch);
+                ++st.ranges_redone;
+            }
+            if (k == 0 && state[0].own.empty()) { fallback = true; break; }      // later ranges assumed a non-empty list
+            if (ch[0] | ch[1]) {
+                bool read_later = false;
+                for (size_t j = k + 1; j < nr && !read_later; ++j)
+                    read_later = ((state[j].head_reads[0] & ch[0]) | (state[j].head_reads[1] & ch[1])) != 0;
+                if (read_later) { done = k + 1; again = true; break; }
+            }
         }
+        if (fallback) break;
+        if (!again) done = nr;
+    }
     st.head_writes = head_writes;
+    st.passes = passes;
     st.first_range_empty = state[0].own.empty();
-    if (head_writes || state[0].own.empty() || std::getenv("RIBBIT_MERGE_FORCE_REDO")) {      // (the variable: test hook)
+    if (fallback) {
+        for (size_t k = nr; k-- > 0;) state[k].reset(false, 0);      // takes back the ranges' retirements
+        std::copy(saved_heads_p.begin(), saved_heads_p.end(), lists.perfect.begin());
+        std::copy(saved_heads_s.begin(), saved_heads_s.end(), lists.subst.begin());
         restore_types(lists.perfect, perfect_types);
         restore_types(lists.subst, subst_types);
         lists.guard_hits = guard_before;

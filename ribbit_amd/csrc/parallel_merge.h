@@ -48,7 +48,8 @@ struct MergeStats {
     unsigned threads = 1;
     unsigned ranges_redone = 0;    // ranges that read a seed type an earlier range changed afterwards, merged again
     bool redone_in_order = false;
-    long long head_writes = 0;     // Q8 writes to list heads that would change an entry (any: the stage is redone in order)
+    long long head_writes = 0;     // Q8 writes to list heads that would change an entry (their ranges are done again with the writes made)
+    unsigned passes = 1;           // parallel passes of the anchored stage (one more per head change that a later range read)
     bool first_range_empty = false;
     double prepare_ms = 0.0, merge_ms = 0.0, concat_ms = 0.0;      // concat_ms: the part of merge_ms spent joining the ranges' lists
     std::vector<int> cut_pos;  // the positions the ranges were cut at (first entry INT32_MIN): uncovered by any call or earlier-stage seed

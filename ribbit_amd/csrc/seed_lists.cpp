@@ -481,7 +481,10 @@ Cursor2 anchored_add(ListRefs &sl, int seed_start, int seed_end, int mlen, const
                 const int t = nonfactor_children[j].type;
                 const SeedVec *src = t == RP ? &P : t == RS ? &S : nullptr;
                 if (src) {
-                    if (j < src->size()) { o_start = (*src)[j].start; o_mlen = (*src)[j].mlen; o_end = (*src)[j].end; o_rend = o_end + o_mlen; }
+                    if (j < src->size()) {
+                        if (sl.head_reads) sl.head_reads[src == &P ? 0 : 1] |= 1ull << std::min<size_t>(j, 63);
+                        o_start = (*src)[j].start; o_mlen = (*src)[j].mlen; o_end = (*src)[j].end; o_rend = o_end + o_mlen;
+                    }
                     else ++sl.guard_hits;
                 }
                 if ((uint32_t)o_rend >= prev_start) coverage = (int)((uint32_t)coverage + (prev_start - (uint32_t)o_start));
@@ -502,7 +505,10 @@ Cursor2 anchored_add(ListRefs &sl, int seed_start, int seed_end, int mlen, const
                 const int t = factor_children[j].type;
                 const SeedVec *src = t == RP ? &P : t == RS ? &S : nullptr;
                 if (src) {
-                    if (j < src->size()) { o_start = (*src)[j].start; o_mlen = (*src)[j].mlen; o_end = (*src)[j].end; o_rend = o_end + o_mlen; }
+                    if (j < src->size()) {
+                        if (sl.head_reads) sl.head_reads[src == &P ? 0 : 1] |= 1ull << std::min<size_t>(j, 63);
+                        o_start = (*src)[j].start; o_mlen = (*src)[j].mlen; o_end = (*src)[j].end; o_rend = o_end + o_mlen;
+                    }
                     else ++sl.guard_hits;
                 }
                 const uint32_t prev_start = (uint32_t)prev_of[o_mlen];
@@ -520,11 +526,17 @@ Cursor2 anchored_add(ListRefs &sl, int seed_start, int seed_end, int mlen, const
                     SeedVec *dst = t == RP ? &P : t == RS ? &S : nullptr;
                     if (!dst) continue;
                     if (j >= dst->size()) { ++sl.guard_hits; continue; }
+                    if (sl.head_reads) sl.head_reads[dst == &P ? 0 : 1] |= 1ull << std::min<size_t>(j, 63);
                     o_mlen = (*dst)[j].mlen;
                     if (o_mlen == f) {
                         const RibbitSeed value{o_start, o_end, o_mlen, RIBBIT_RANK_N};
                         if (sl.head_write_log) sl.head_write_log->push_back({&(*dst)[j], value});     // parallel worker: decided later
-                        else (*dst)[j] = value;
+                        else {
+                            RibbitSeed &tgt = (*dst)[j];
+                            if (sl.head_changes && (tgt.start != value.start || tgt.end != value.end || tgt.mlen != value.mlen))
+                                sl.head_changes[dst == &P ? 0 : 1] |= 1ull << std::min<size_t>(j, 63);
+                            tgt = value;
+                        }
                     }
                 }
                 break;

@@ -43,6 +43,12 @@ struct ListRefs {
     // usual case: the entry is retired already and is given its own coordinates) or redoes the stage in order.
     struct HeadWrite { RibbitSeed *target; RibbitSeed value; };
     std::vector<HeadWrite> *head_write_log = nullptr;
+    // What lets the parallel merge stay parallel when such a write does change an entry (round 3: it happens on most
+    // chromosome-sized records).  head_reads[x] (x = 0 perfect, 1 substitution list): bit min(j, 63) set = the coverage code
+    // read entry j of list x by loop counter.  head_changes[x]: when the writes are performed (no log), bit min(j, 63) set =
+    // a write changed start, end or motif size of entry j (what those reads see; a change of the type alone is a retirement
+    // like any other).
+    uint64_t *head_reads = nullptr, *head_changes = nullptr;
     // Parallel workers (parallel_merge.h) share the lists of the earlier stages.  The only field that changes there is
     // `type` (a seed is retired), and the only place where the type of a seed OUTSIDE the worker's range steers a
     // decision is the candidate walk, which pushes the nearest seed to the left unless it is retired

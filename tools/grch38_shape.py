@@ -57,10 +57,12 @@ def main():
     ap.add_argument("--jobs", type=int, default=0)
     ap.add_argument("--workers", type=int, default=min(12, os.cpu_count() or 1))
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--records", type=int, default=len(GRCH38), help="only the first N records")
+    ap.add_argument("--stderr", default="", help="file that receives ribbit-hip's stderr (progress and RIBBIT_PROFILE lines)")
     ap.add_argument("--dir", default="/tmp/grch38_shape")
     a = ap.parse_args()
     os.makedirs(a.dir, exist_ok=True)
-    recs = [(k, name, max(1000, int(n * a.scale)), a.dir) for k, (name, n) in enumerate(GRCH38)]
+    recs = [(k, name, max(1000, int(n * a.scale)), a.dir) for k, (name, n) in enumerate(GRCH38[:a.records])]
     t0 = time.perf_counter()
     with ProcessPoolExecutor(max_workers=a.workers) as pool:
         paths = list(pool.map(make_record, recs))
@@ -85,6 +87,8 @@ def main():
     t1 = time.perf_counter()
     r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=dict(os.environ, RIBBIT_PROFILE="1"))
     wall = time.perf_counter() - t1
+    if a.stderr:
+        open(a.stderr, "w").write(r.stderr)
     if r.returncode != 0:
         print(r.stderr[-3000:], file=sys.stderr)
         raise SystemExit(r.returncode)
