@@ -97,3 +97,17 @@ def test_ranges_that_read_a_stale_type_are_merged_again(tiny_ranges):
     for seed in (20037, 20171):
         seq, m_lo, m_hi = fuzz_case(seed)
         _check(seq, m_lo, m_hi, f"seed {seed}")
+
+
+def test_a_list_head_write_that_changes_its_entry_keeps_the_merge_parallel_and_exact(tiny_ranges):
+    """Q8 (parse_anchored_shiftxor.cpp:511-522): the coverage code writes an entry at the HEAD of the perfect / substitution
+    list from anywhere in the record.  On this record (generator seed 38, 300 kb, -M 30: found by a sweep, such writes are rare
+    below chromosome size) one write changes its entry.  Until round 3 that sent the whole stage back to one thread; now the
+    range that makes it is done again with the write made, the lists still equal the oracle's, and the stage is not redone."""
+    from ribbit_amd.simulate import simulate_sequence
+    seq, _ = simulate_sequence(300_000, 38, 2, 30)
+    _check(seq, 2, 30, "seed 38")
+    out = (C.c_int32 * 5)()
+    ribbit_amd.load_library().ribbit_debug_last_merge(1, C.byref(out))
+    ranges, again, in_order, changing, tail = (int(x) for x in out)
+    assert ranges > 1 and changing >= 1 and again >= 1 and in_order == 0 and (tail >> 8) >= 1, list(out)

@@ -48,3 +48,35 @@ def test_whole_path_on_a_64_megabase_record_matches_oracle(capsys):
         g, w = got.splitlines(), want.splitlines()
         k = next((i for i, (a, b) in enumerate(zip(g, w)) if a != b), min(len(g), len(w)))
         pytest.fail(f"rows {len(g)} vs {len(w)}; first difference at row {k}: {g[k] if k < len(g) else None!r} vs {w[k] if k < len(w) else None!r}")
+
+
+def test_list_head_writes_on_a_chromosome_sized_record_keep_the_merge_parallel_and_exact():
+    """Q8's writes to list heads (parse_anchored_shiftxor.cpp:511-522) that change an entry are rare per megabase and routine
+    per chromosome: generator seed 1004 at chromosome 2's size makes one.  The merge must stay parallel (a second pass over the
+    ranges behind the change, not the whole stage on one thread) and give exactly the lists of the same stage made strictly in
+    call order (RIBBIT_MERGE_FORCE_REDO=1: the reference's order of calls, one after the other)."""
+    import ctypes as C
+
+    import numpy as np
+    from ribbit_amd.simulate import simulate_sequence
+    bases = int(os.environ.get("RIBBIT_TEST_HEAD_BASES", "242193529"))
+    seq, _ = simulate_sequence(bases, 1004, 2, 100)
+    lists, stats = {}, {}
+    for mode in ("parallel", "in order"):
+        if mode == "in order":
+            os.environ["RIBBIT_MERGE_FORCE_REDO"] = "1"
+        try:
+            with ribbit_amd.Scanner(2, 100) as sc:
+                sc.load_record(seq)
+                p, s, a = sc.processShiftXORsAnchored()
+                lists[mode] = (p.copy(), s.copy(), a.copy(), sc.dispatch_seeds().copy())
+                out = (C.c_int32 * 5)()
+                ribbit_amd.load_library().ribbit_debug_last_merge(1, C.byref(out))
+                stats[mode] = [int(x) for x in out]
+        finally:
+            os.environ.pop("RIBBIT_MERGE_FORCE_REDO", None)
+    assert stats["in order"][2] == 1 and stats["parallel"][2] == 0, stats
+    if bases == 242193529:
+        assert stats["parallel"][3] >= 1 and (stats["parallel"][4] >> 8) >= 2, stats          # the write is there, and cost one more pass
+    for x, y in zip(lists["parallel"], lists["in order"]):
+        assert np.array_equal(x.view("<i4"), y.view("<i4"))
