@@ -12,13 +12,16 @@
 // that seed is retired (merge_types.cpp:64-93), and it may lie in the range before.  Reads of such seeds' types are
 // logged; after the parallel pass the ranges are checked in order and one that saw a type its left neighbour changed
 // afterwards is merged again (its own retirements undone first).
-// Two things a cut cannot localise at all are detected, and the whole stage is then redone in order (neither happened
-// in any test or benchmark record, but correctness does not rest on that):
-//   * Q8: the anchored merge's coverage code writes entries at the HEAD of the perfect / substitution lists from
-//     anywhere in the record (parse_anchored_shiftxor.cpp:511-522).  Workers log these writes; one that would change
-//     its target (most give a retired entry its own coordinates) forces the redo;
+// Two things a cut cannot localise at all:
+//   * Q8: the anchored merge's coverage code reads and writes entries at the HEAD of the perfect / substitution lists by
+//     loop counter, from anywhere in the record (parse_anchored_shiftxor.cpp:441-522).  Workers log the writes and the
+//     entries they read that way.  After the parallel pass the ranges are walked in order: a range whose logged writes
+//     would change an entry is merged again on its own with the writes made; if that changed what the by-counter reads see
+//     (start, end, motif size) and a later range read such an entry, the ranges behind it run again in parallel against the
+//     new heads -- one more pass per change that matters.  (Rounds 1-2 redid the whole stage in call order on the first such
+//     write: never met on the test records, met on two of three chromosome-sized ones, 5 s each.)
 //   * the first range appending nothing: later ranges assumed a non-empty list (merge_types.cpp:103 and
-//     parse_substitute_shiftxor.cpp:48-116 take different paths for an empty list).
+//     parse_substitute_shiftxor.cpp:48-116 take different paths for an empty list): the stage is then redone in call order.
 // Product code: must never include anything from oracle/.
 #pragma once
 #include <stddef.h>

@@ -589,6 +589,7 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
                    const std::vector<RibbitAlignJob> *jobs, const std::vector<SswEnds> *ends, const std::vector<SswPath> *paths,
                    size_t seed_lo, size_t seed_hi, bool *order_dependent, const SmallMotifTable *small,
                    const uint32_t *job_first_all, const uint8_t *skip, std::vector<BedPiece> *pieces, const std::vector<uint32_t> *only) {
+    const auto wall0 = std::chrono::steady_clock::now();
     const Bases b(hp, host_threads);
     seed_hi = std::min(seed_hi, dispatch.size());
     seed_lo = std::min(seed_lo, seed_hi);
@@ -705,6 +706,10 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
         else bed += w.os.str();
         flush_counters();
     }
+    static const bool wall_lines = std::getenv("RIBBIT_REFINE_WALL") != nullptr;      // one line per call, no per-seed timers (those perturb)
+    if (wall_lines)
+        std::fprintf(stderr, "[refine] call over %zu seeds on %u threads: %.1f ms wall\n", n_seeds, threads,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
     if (g_profile)
         std::fprintf(stderr, "[refine] seeds %zu  threads %u  alignments %ld (%ld with GPU passes, %ld with GPU paths)  small-motif seeds %ld from the GPU / %ld on the host  (summed over threads, cumulative) align %.2fs (of it %.2fs in %ld flank-recursion alignments, %.2fs in first-level alignments done whole on the host)  small-motif discovery %.2fs  long-motif consensus %.2fs  CIGAR digestion %.2fs  motif units %.2fs  row text %.2fs  reference strings %.2fs  long atomicity %.2fs | whole small seeds %.2fs  whole long seeds %.2fs  whole chunks %.2fs\n",
                      n_seeds, threads, g_n_align.load(), g_n_known.load(), g_n_paths.load(), g_n_small_device.load(), g_n_small_host.load(), g_t_align.load() * 1e-9, g_t_flank.load() * 1e-9, g_n_flank.load(), g_t_whole_first.load() * 1e-9, g_t_small.load() * 1e-9, g_t_long.load() * 1e-9,

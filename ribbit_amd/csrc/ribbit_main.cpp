@@ -300,7 +300,10 @@ int main(int argc, char **argv) {
             ++next_out;
         }
     };
-    auto worker = [&](RibbitHandle *wh, int dev) {
+    // heavy: this GPU's first worker.  A record that takes all of a GPU's job tokens runs alone on it, and always on that worker's
+    // handle: the buffers of a chromosome (gigabytes of page-locked and device memory, a second to allocate) exist once per
+    // GPU, not once per worker (eight handles each meeting their first chromosome cost the whole-genome run 8 of its 83 s).
+    auto worker = [&](RibbitHandle *wh, int dev, bool heavy) {
         for (;;) {
             Record rec;
             int weight;
@@ -314,7 +317,7 @@ int main(int argc, char **argv) {
                             for (size_t i = 1; i < queue.size() && i < (size_t)workers; ++i)
                                 if (queue[i].length > queue[pick].length) pick = i;
                         weight = (int)std::min<size_t>((size_t)jobs, (size_t)queue[pick].length / 4000000 + 1);
-                        if (tokens[(size_t)dev] >= weight) break;
+                        if (tokens[(size_t)dev] >= weight && (weight < jobs || heavy || jobs == 1)) break;
                     } else if (reader_done) {
                         return;
                     }
@@ -382,7 +385,7 @@ int main(int argc, char **argv) {
                 if (handle_dev[j] == d) ribbit_hip_set_batcher(handles[j], batchers[(size_t)d]);
         }
     std::vector<std::thread> pool;
-    for (size_t j = 0; j < handles.size(); ++j) pool.emplace_back(worker, handles[j], handle_dev[j]);
+    for (size_t j = 0; j < handles.size(); ++j) pool.emplace_back(worker, handles[j], handle_dev[j], j < (size_t)ndev);      // handles 0 .. ndev-1: one per GPU
 
     // ribbit.cpp:269-279 -- records as the reference's getline loop delimits them; :280 -- the last record is processed
     // unconditionally and WITHOUT the "Processing sequence" line, also for an empty file (Q4): it bypasses the pipeline
