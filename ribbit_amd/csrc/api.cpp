@@ -1890,6 +1890,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
     h->best_rows_valid = false;
     h->small_valid = false;
     // cumulative over every handle of the process (ribbit-hip runs up to 64 workers through here at once): microseconds in atomics
+    const double t_begin = now_ms();
     static std::atomic<int64_t> t_rows_us{0}, t_text_us{0}, t_jobs_us{0};
     auto add_ms = [](std::atomic<int64_t> &acc, double ms) { acc.fetch_add((int64_t)(ms * 1000.0), std::memory_order_relaxed); };
     static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
@@ -1988,6 +1989,12 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                 t_long = now_ms() - tl0;
             });
         }
+        // the seeds set aside are refined as soon as the long batch AND the slice that holds their short jobs have landed, on a
+        // few threads beside the workers (who are mostly waiting for the feeder): not after everything else, where their long
+        // host-side tails (queries beyond the kernels' reach, flank recursion) were 120 of 715 ms at 64 Mbp
+        std::vector<rb::BedPiece> later_pieces;
+        bool later_order_dependent = false, later_done = false;
+        double t_later_thread = 0;
 
         // ---- slices of the seed list: one per ~600 K seeds, 2 .. 16 (RIBBIT_SSW_SLICES overrides).  Measured at 64 Mbp (4.5 M
         // seeds; tools/refine_slices_sweep.sh): 2 slices 788 ms, 6 .. 8 757, 17 787, 32 911, 48 1085 -- a slice costs ~10 ms of
@@ -2001,13 +2008,14 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             int rc = RIBBIT_OK;
             std::string error;
             bool ready = false;
-            double t_passes = 0, t_paths = 0;
+            double t_passes = 0, t_paths = 0, t_feed = 0;
         };
         std::vector<Slice> slices(n_slices);
         for (size_t c = 0; c < n_slices; ++c) { slices[c].lo = n_seeds * c / n_slices; slices[c].hi = n_seeds * (c + 1) / n_slices; }
         std::mutex mu;
         std::condition_variable cv;
         std::atomic<bool> stop{false};
+        bool feeder_finished = false;
         // the motif pool of the whole record goes to the device once; every slice's jobs point into it
         if ((rc = bind_device(h)) || (rc = h->d_ssw_pool.ensure(std::max<size_t>(pool.size(), 1)))) {
             if (long_thread.joinable()) long_thread.join();
@@ -2020,6 +2028,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         rc = RIBBIT_OK;
         auto feed = [&](size_t c) {
             Slice &sl = slices[c];
+            const double tf0 = now_ms();
             try {
                 const size_t ja = job_first[sl.lo], jb = job_first[sl.hi];
                 const double tp = now_ms();
@@ -2036,6 +2045,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                     for (const rb::SswPath &pt : pth) if (pt.ops) n_ops = std::max(n_ops, (size_t)(pt.ops - h->h_path_ops.p) + (size_t)pt.n_ops);
                     sl.ops.assign(h->h_path_ops.p, h->h_path_ops.p + n_ops);
                     for (size_t k = 0; k < jb - ja; ++k) {
+                        if (e[k].flag == -1) continue;          // not this batch's (a long job: the other thread owns its entries)
                         ends[ja + k] = e[k];
                         paths[ja + k] = pth[k];
                         if (pth[k].ops) paths[ja + k].ops = sl.ops.data() + (pth[k].ops - h->h_path_ops.p);
@@ -2048,6 +2058,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                 sl.rc = RIBBIT_E_NOMEM;
                 sl.error = "out of host memory while running a slice's alignment batches";
             }
+            sl.t_feed = now_ms() - tf0;
         };
         std::thread feeder([&]() {
             for (size_t c = 0; c < n_slices && !stop; ++c) {
@@ -2056,15 +2067,45 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                 cv.notify_all();
                 if (slices[c].rc) break;
             }
+            { std::lock_guard<std::mutex> lk(mu); feeder_finished = true; }
+            cv.notify_all();
         });
+        std::thread later_thread;
+        if (!later.empty())
+            later_thread = std::thread([&]() {
+                if (long_thread.joinable()) long_thread.join();
+                if (long_rc) return;
+                const double tl0 = now_ms();
+                try {
+                    for (size_t k = 0; k < long_index.size(); ++k) { ends[long_index[k]] = long_ends[k]; paths[long_index[k]] = long_paths[k]; }
+                    size_t at = 0;
+                    for (size_t c = 0; c < n_slices && at < later.size(); ++c) {
+                        {
+                            std::unique_lock<std::mutex> lk(mu);
+                            cv.wait(lk, [&]() { return slices[c].ready || feeder_finished || stop.load(); });
+                            if (!slices[c].ready || slices[c].rc) return;
+                        }
+                        std::vector<uint32_t> mine;
+                        while (at < later.size() && later[at] < slices[c].hi) mine.push_back(later[at++]);
+                        if (mine.empty()) continue;
+                        bool od = false;
+                        rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
+                                          sequence_id, h->bed, std::max(2u, threads / 2), &jobs, &ends, &paths, 0, n_seeds, &od, &small, job_first.data(), nullptr,
+                                          &later_pieces, &mine);
+                        if (od) { later_order_dependent = true; return; }
+                    }
+                    later_done = at == later.size();
+                } catch (const std::bad_alloc &) { later_done = false; }
+                t_later_thread = now_ms() - tl0;
+            });
         // whatever happens on this thread from here on (refine_to_bed may throw std::bad_alloc at chromosome size), the helper
         // threads are stopped and joined before the frame goes: a joinable std::thread's destructor ends the process
         struct JoinGuard {
-            std::atomic<bool> &stop; std::thread &a, &b;
-            ~JoinGuard() { stop = true; if (a.joinable()) a.join(); if (b.joinable()) b.join(); }
-        } join_guard{stop, feeder, long_thread};
+            std::atomic<bool> &stop; std::condition_variable &cv; std::thread &a, &b, &c;
+            ~JoinGuard() { stop = true; cv.notify_all(); if (a.joinable()) a.join(); if (b.joinable()) b.join(); if (c.joinable()) c.join(); }
+        } join_guard{stop, cv, feeder, later_thread, long_thread};
         bool order_dependent = false;
-        double t_wait = 0, t_passes = 0, t_paths = 0;
+        double t_wait = 0, t_passes = 0, t_paths = 0, t_feed = 0, t_work = 0, t_later = 0, t_join = 0;
         std::vector<rb::BedPiece> pieces;
         for (size_t c = 0; c < n_slices; ++c) {
             Slice &sl = slices[c];
@@ -2072,17 +2113,22 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return sl.ready; }); }
             t_wait += now_ms() - tw;
             if (sl.rc) { rc = sl.rc; g_last_error = sl.error; break; }
-            t_passes += sl.t_passes; t_paths += sl.t_paths;
+            t_passes += sl.t_passes; t_paths += sl.t_paths; t_feed += sl.t_feed;
+            const double tk = now_ms();
             rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
                               sequence_id, h->bed, h->host_threads, &jobs, &ends, &paths, sl.lo, sl.hi, &order_dependent, &small,
                               job_first.data(), set_aside.data(), &pieces);
+            t_work += now_ms() - tk;
             if (order_dependent) break;
         }
         stop = true;
+        cv.notify_all();
         feeder.join();
         const double tw = now_ms();
+        if (later_thread.joinable()) later_thread.join();          // (it has joined the long batch's thread)
         if (long_thread.joinable()) long_thread.join();
         const double t_wait_long = now_ms() - tw;
+        if (later_order_dependent) order_dependent = true;
         if (!rc && long_rc) { rc = long_rc; g_last_error = long_error; }
         bool batches_failed = false;
         if (rc == RIBBIT_E_NOMEM) {
@@ -2095,13 +2141,18 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         if (rc) return rc;
         if (!order_dependent && !batches_failed) {
             // the seeds set aside: their long alignments come from the long batch, the others from the slices
-            for (size_t k = 0; k < long_index.size(); ++k) { ends[long_index[k]] = long_ends[k]; paths[long_index[k]] = long_paths[k]; }
-            if (!later.empty())
+            const double tl0 = now_ms();
+            if (later_done) { for (rb::BedPiece &pc : later_pieces) pieces.push_back(std::move(pc)); }
+            else if (!later.empty()) {        // (the thread gave up: memory ran out)
+                for (size_t k = 0; k < long_index.size(); ++k) { ends[long_index[k]] = long_ends[k]; paths[long_index[k]] = long_paths[k]; }
                 rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
                                   sequence_id, h->bed, h->host_threads, &jobs, &ends, &paths, 0, n_seeds, &order_dependent, &small, job_first.data(), nullptr,
                                   &pieces, &later);
+            }
+            t_later = now_ms() - tl0;
         }
         done = !order_dependent && !batches_failed;
+        const double tj0 = now_ms();
         if (done) {
             std::sort(pieces.begin(), pieces.end(), [](const rb::BedPiece &x, const rb::BedPiece &y) { return x.first_seed < y.first_seed; });
             size_t total = 0;
@@ -2109,9 +2160,12 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             h->bed.reserve(total);
             for (const rb::BedPiece &pc : pieces) h->bed += pc.text;
         } else h->bed.clear();                         // an empty query somewhere (or no batches): the whole record in one call (below)
+        t_join = now_ms() - tj0;
         if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs (%zu long ones in their own batch: %.1f ms; %zu seeds set aside), set-up %.1f ms; %zu slices: "
-                                  "GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms; workers waited %.1f ms for slices, %.1f ms for the long batch\n",
-                                  n_jobs, long_jobs.size(), t_long, later.size(), t_setup, n_slices, t_passes, t_paths, t_wait, t_wait_long);
+                                  "feeder %.1f ms in all (GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms); workers: %.1f ms in their calls, waited %.1f ms "
+                                  "for slices, %.1f ms for the long batch and the seeds set aside (refined beside the slices in %.1f ms); rows put together %.1f ms; since the call began %.1f ms\n",
+                                  n_jobs, long_jobs.size(), t_long, later.size(), t_setup, n_slices, t_feed, t_passes, t_paths, t_work, t_wait, t_wait_long, t_later_thread + t_later, t_join,
+                                  now_ms() - t_begin);
         add_ms(t_jobs_us, t_wait + t_wait_long);
     }
     static const char *const shared_env = std::getenv("RIBBIT_SHARED_SSW");
