@@ -1946,16 +1946,25 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         for (size_t i = n_seeds; i-- > 0;) job_first[i] = std::min(job_first[i], job_first[i + 1]);
         static const char *const large_env = std::getenv("RIBBIT_SSW_LARGE");
         const bool large_class = large_env ? std::atoi(large_env) != 0 : true;        // 0: the long jobs stay on the host threads (a measurement knob)
-        std::vector<uint8_t> set_aside(n_seeds, 0);
+        std::vector<uint8_t> set_aside(n_seeds, 0);          // 1: waits for the long batch; 2: has a job beyond the kernels' reach (host-aligned)
         std::vector<RibbitAlignJob> long_jobs;
-        std::vector<uint32_t> long_index, later;
+        std::vector<uint32_t> long_index, later, giants;
         for (size_t j = 0; j < n_jobs; ++j) {
             const int cls = ssw_class(jobs[j]);
             if (cls >= 0 && cls < 2) continue;
-            set_aside[(size_t)jobs[j].seed_index] = 1;
-            if (cls >= 2 && large_class) { long_jobs.push_back(jobs[j]); long_index.push_back((uint32_t)j); }
+            uint8_t &mark = set_aside[(size_t)jobs[j].seed_index];
+            mark = std::max<uint8_t>(mark, (cls < 0 || !large_class) ? 2 : 1);
         }
-        for (size_t i = 0; i < n_seeds; ++i) if (set_aside[i]) later.push_back((uint32_t)i);
+        for (size_t j = 0; j < n_jobs; ++j) {
+            // the long batch takes the long jobs of the seeds that wait for it; a seed with a job no kernel takes is aligned on
+            // the host threads as a whole, right away
+            const int cls = ssw_class(jobs[j]);
+            if (cls >= 2 && set_aside[(size_t)jobs[j].seed_index] == 1) { long_jobs.push_back(jobs[j]); long_index.push_back((uint32_t)j); }
+        }
+        for (size_t i = 0; i < n_seeds; ++i) {
+            if (set_aside[i] == 1) later.push_back((uint32_t)i);
+            else if (set_aside[i] == 2) giants.push_back((uint32_t)i);
+        }
         std::vector<rb::SswEnds> ends(n_jobs);
         for (rb::SswEnds &e : ends) e.flag = -1;
         std::vector<rb::SswPath> paths(n_jobs);
@@ -2070,31 +2079,19 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             { std::lock_guard<std::mutex> lk(mu); feeder_finished = true; }
             cv.notify_all();
         });
+        // seeds with a job beyond the kernels' reach (queries over 4096 bases: 5-60 ms of host alignment each) need nothing from
+        // the GPU: they are refined on a few host threads from the start, beside everything else, instead of as a tail
         std::thread later_thread;
-        if (!later.empty())
+        if (!giants.empty())
             later_thread = std::thread([&]() {
-                if (long_thread.joinable()) long_thread.join();
-                if (long_rc) return;
                 const double tl0 = now_ms();
                 try {
-                    for (size_t k = 0; k < long_index.size(); ++k) { ends[long_index[k]] = long_ends[k]; paths[long_index[k]] = long_paths[k]; }
-                    size_t at = 0;
-                    for (size_t c = 0; c < n_slices && at < later.size(); ++c) {
-                        {
-                            std::unique_lock<std::mutex> lk(mu);
-                            cv.wait(lk, [&]() { return slices[c].ready || feeder_finished || stop.load(); });
-                            if (!slices[c].ready || slices[c].rc) return;
-                        }
-                        std::vector<uint32_t> mine;
-                        while (at < later.size() && later[at] < slices[c].hi) mine.push_back(later[at++]);
-                        if (mine.empty()) continue;
-                        bool od = false;
-                        rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
-                                          sequence_id, h->bed, std::max(2u, threads / 2), &jobs, &ends, &paths, 0, n_seeds, &od, &small, job_first.data(), nullptr,
-                                          &later_pieces, &mine);
-                        if (od) { later_order_dependent = true; return; }
-                    }
-                    later_done = at == later.size();
+                    bool od = false;
+                    rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
+                                      sequence_id, h->bed, std::max(2u, threads / 4), nullptr, nullptr, nullptr, 0, n_seeds, &od, &small, nullptr, nullptr,
+                                      &later_pieces, &giants);
+                    if (od) later_order_dependent = true;
+                    else later_done = true;
                 } catch (const std::bad_alloc &) { later_done = false; }
                 t_later_thread = now_ms() - tl0;
             });
@@ -2125,8 +2122,8 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         cv.notify_all();
         feeder.join();
         const double tw = now_ms();
-        if (later_thread.joinable()) later_thread.join();          // (it has joined the long batch's thread)
         if (long_thread.joinable()) long_thread.join();
+        if (later_thread.joinable()) later_thread.join();
         const double t_wait_long = now_ms() - tw;
         if (later_order_dependent) order_dependent = true;
         if (!rc && long_rc) { rc = long_rc; g_last_error = long_error; }
@@ -2142,12 +2139,18 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         if (!order_dependent && !batches_failed) {
             // the seeds set aside: their long alignments come from the long batch, the others from the slices
             const double tl0 = now_ms();
-            if (later_done) { for (rb::BedPiece &pc : later_pieces) pieces.push_back(std::move(pc)); }
-            else if (!later.empty()) {        // (the thread gave up: memory ran out)
-                for (size_t k = 0; k < long_index.size(); ++k) { ends[long_index[k]] = long_ends[k]; paths[long_index[k]] = long_paths[k]; }
+            // the seeds set aside for the long batch: its results in place, then one call over all of them
+            for (size_t k = 0; k < long_index.size(); ++k) { ends[long_index[k]] = long_ends[k]; paths[long_index[k]] = long_paths[k]; }
+            if (!later.empty())
                 rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
                                   sequence_id, h->bed, h->host_threads, &jobs, &ends, &paths, 0, n_seeds, &order_dependent, &small, job_first.data(), nullptr,
                                   &pieces, &later);
+            if (!giants.empty()) {
+                if (later_done) { for (rb::BedPiece &pc : later_pieces) pieces.push_back(std::move(pc)); }
+                else              // (the thread ran out of memory)
+                    rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
+                                      sequence_id, h->bed, h->host_threads, nullptr, nullptr, nullptr, 0, n_seeds, &order_dependent, &small, nullptr, nullptr,
+                                      &pieces, &giants);
             }
             t_later = now_ms() - tl0;
         }
@@ -2163,8 +2166,9 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         t_join = now_ms() - tj0;
         if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs (%zu long ones in their own batch: %.1f ms; %zu seeds set aside), set-up %.1f ms; %zu slices: "
                                   "feeder %.1f ms in all (GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms); workers: %.1f ms in their calls, waited %.1f ms "
-                                  "for slices, %.1f ms for the long batch and the seeds set aside (refined beside the slices in %.1f ms); rows put together %.1f ms; since the call began %.1f ms\n",
-                                  n_jobs, long_jobs.size(), t_long, later.size(), t_setup, n_slices, t_feed, t_passes, t_paths, t_work, t_wait, t_wait_long, t_later_thread + t_later, t_join,
+                                  "for slices, %.1f ms for the long batch; seeds set aside for it %.1f ms; %zu seeds with jobs beyond the kernels' reach refined on the host beside all that in %.1f ms; "
+                                  "rows put together %.1f ms; since the call began %.1f ms\n",
+                                  n_jobs, long_jobs.size(), t_long, later.size(), t_setup, n_slices, t_feed, t_passes, t_paths, t_work, t_wait, t_wait_long, t_later, giants.size(), t_later_thread, t_join,
                                   now_ms() - t_begin);
         add_ms(t_jobs_us, t_wait + t_wait_long);
     }
