@@ -1022,10 +1022,27 @@ int build_best_rows(RibbitHandle *h, const RibbitRefineParams &prm) {
     const size_t n = h->dispatch.size();
     h->best_rows.assign(n, -1);
     rb::SeedVec jobs;          // reused as int4 {seed_start, seed_sequence_length, m, dispatch index}
-    for (size_t i = 0; i < n; ++i) {
-        const RibbitSeed &s = h->dispatch[i];
-        if (s.mlen <= 10 || s.end - s.start < 0.9 * s.mlen || h->longest_runs[i] < prm.continuous_ones_threshold) continue;
-        jobs.push_back(RibbitSeed{s.start, rb::usable_length_host(h->host, s.start, s.end, s.mlen), s.mlen, (int32_t)i});
+    {
+        // the usable length of every long-motif seed (a walk over its bases up to the first N) on the host threads: 0.8 M seeds of
+        // a hundred bases per 64 Mbp were 80 ms on one
+        unsigned nt = h->host_threads ? h->host_threads : std::min(std::thread::hardware_concurrency(), 16u);
+        if (!h->host_threads)
+            if (const char *env = std::getenv("RIBBIT_THREADS")) nt = (unsigned)std::max(1, std::atoi(env));
+        nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, n / 65536 + 1));
+        std::vector<rb::SeedVec> part(nt);
+        auto work = [&](unsigned t) {
+            const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+            for (size_t i = lo; i < hi; ++i) {
+                const RibbitSeed &s = h->dispatch[i];
+                if (s.mlen <= 10 || s.end - s.start < 0.9 * s.mlen || h->longest_runs[i] < prm.continuous_ones_threshold) continue;
+                part[t].push_back(RibbitSeed{s.start, rb::usable_length_host(h->host, s.start, s.end, s.mlen), s.mlen, (int32_t)i});
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (std::thread &th : pool) th.join();
+        for (const rb::SeedVec &p : part) jobs.insert(jobs.end(), p.begin(), p.end());
     }
     if (!jobs.empty()) {
         if ((rc = bind_device(h))) return rc;
@@ -1430,21 +1447,33 @@ static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n,
     // four size classes, each sorted by work (largest first) so that the alignments of a wavefront are alike.  The last one
     // (queries of 2049..4096 bases: a thousand jobs in a 64-Mbp record, and a third of all its alignment cells) runs on the
     // handle's copy stream beside the others: one such alignment occupies its wavefront for tens of milliseconds.
-    std::vector<uint64_t> keyed[4];
+    // Order inside a class: by work (cells), largest first, so that the alignments of a wavefront are alike.  A bucket per
+    // (power of two, next four bits) of the work instead of a comparison sort: the order only has to be roughly monotone, and
+    // the sort was a tenth of a slice's time on the feeder thread (190 K jobs a slice, seven slices a record).
+    constexpr int BUCKETS = 32 * 16;
+    auto bucket_of = [](uint64_t work) {
+        if (work < 16) return (int)work;
+        const int top = 63 - __builtin_clzll(work);                    // >= 4
+        return (top - 3) * 16 + (int)((work >> (top - 4)) & 15u);
+    };
+    std::vector<int32_t> cls_of(n, -1), bkt_of(n, 0);
+    std::vector<uint32_t> count(4 * BUCKETS + 1, 0);                   // slot = class-major, buckets descending
+    size_t class_count[4] = {0, 0, 0, 0};
     for (size_t j = 0; j < n; ++j) {
         const RibbitAlignJob &jb = jobs[j];
         const int cls = ssw_class(jb);
         if (cls < 0 || !((classes >> cls) & 1u)) { ends[j].flag = -1; continue; }
         const uint64_t work = (uint64_t)std::max(jb.query_length, 0) * (uint64_t)std::max(jb.ppr_length, 0);      // < 2^25
-        keyed[cls].push_back(((0xffffffffull - work) << 32) | (uint64_t)j);
+        cls_of[j] = cls;
+        bkt_of[j] = std::min(bucket_of(work), BUCKETS - 1);
+        ++class_count[cls];
+        // order of the list: class 3 first ... class 0 last; inside a class the largest bucket first
+        ++count[(size_t)(3 - cls) * BUCKETS + (size_t)(BUCKETS - 1 - bkt_of[j]) + 1];
     }
-    std::vector<int32_t> order;
-    size_t class_count[4];
-    for (int cls = 3; cls >= 0; --cls) {
-        std::sort(keyed[cls].begin(), keyed[cls].end());
-        class_count[cls] = keyed[cls].size();
-        for (uint64_t k : keyed[cls]) order.push_back((int32_t)(k & 0xffffffffu));
-    }
+    for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
+    std::vector<int32_t> order(count.back());
+    for (size_t j = 0; j < n; ++j)
+        if (cls_of[j] >= 0) order[count[(size_t)(3 - cls_of[j]) * BUCKETS + (size_t)(BUCKETS - 1 - bkt_of[j])]++] = (int32_t)j;
     const size_t n_giant = class_count[3], n_huge = class_count[2], n_big = class_count[1], n_small = class_count[0];
     if (order.empty()) return RIBBIT_OK;
     if ((rc = h->d_ssw_jobs.ensure(n * 9))) return rc;
