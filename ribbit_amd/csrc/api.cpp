@@ -1965,39 +1965,45 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         // (Round 2 ran the long classes inside every slice: ~150 ms of tail per slice, which is why two slices were the optimum
         // and the workers sat idle for the whole first one -- tools/refine_slices_probe.sh.)
         const size_t n_seeds = h->dispatch.size();
-        std::vector<RibbitAlignJob> jobs;
-        std::string pool;
-        const double t_setup0 = now_ms();
-        rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), jobs, pool, threads, 0, n_seeds, &small);
-        const size_t n_jobs = jobs.size();
-        std::vector<uint32_t> job_first(n_seeds + 1, (uint32_t)n_jobs);
-        for (size_t j = n_jobs; j-- > 0;) job_first[(size_t)jobs[j].seed_index] = (uint32_t)j;
-        for (size_t i = n_seeds; i-- > 0;) job_first[i] = std::min(job_first[i], job_first[i + 1]);
         static const char *const large_env = std::getenv("RIBBIT_SSW_LARGE");
         const bool large_class = large_env ? std::atoi(large_env) != 0 : true;        // 0: the long jobs stay on the host threads (a measurement knob)
+        const double t_setup0 = now_ms();
+        // First the seeds that can have a long job at all -- a job's query is at most the seed plus one motif long, and its
+        // reference 15 % more plus a motif: below 500 bases of seed + motif (and a motif of at most 400) both stay inside
+        // the short classes -- so that the long batch is on the GPU while the other four million seeds are still being set up.
+        std::vector<uint32_t> cand;
+        for (size_t i = 0; i < n_seeds; ++i) {
+            const RibbitSeed &sd = h->dispatch[i];
+            if ((int64_t)sd.end - sd.start + sd.mlen > 500 || sd.mlen > 400) cand.push_back((uint32_t)i);
+        }
+        std::vector<RibbitAlignJob> cand_jobs;
+        std::string cand_pool;
+        rb::build_align_jobs_of(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), cand, cand_jobs, cand_pool, threads, &small);
         std::vector<uint8_t> set_aside(n_seeds, 0);          // 1: waits for the long batch; 2: has a job beyond the kernels' reach (host-aligned)
-        std::vector<RibbitAlignJob> long_jobs;
-        std::vector<uint32_t> long_index, later, giants;
-        for (size_t j = 0; j < n_jobs; ++j) {
-            const int cls = ssw_class(jobs[j]);
+        for (const RibbitAlignJob &jb : cand_jobs) {
+            const int cls = ssw_class(jb);
             if (cls >= 0 && cls < 2) continue;
-            uint8_t &mark = set_aside[(size_t)jobs[j].seed_index];
+            uint8_t &mark = set_aside[(size_t)jb.seed_index];
             mark = std::max<uint8_t>(mark, (cls < 0 || !large_class) ? 2 : 1);
         }
-        for (size_t j = 0; j < n_jobs; ++j) {
-            // the long batch takes the long jobs of the seeds that wait for it; a seed with a job no kernel takes is aligned on
-            // the host threads as a whole, right away
-            const int cls = ssw_class(jobs[j]);
-            if (cls >= 2 && set_aside[(size_t)jobs[j].seed_index] == 1) { long_jobs.push_back(jobs[j]); long_index.push_back((uint32_t)j); }
+        // the long batch takes the long jobs of the seeds that wait for it; a seed with a job no kernel takes is aligned on
+        // the host threads as a whole, right away
+        std::vector<RibbitAlignJob> long_jobs;
+        std::vector<uint32_t> long_ordinal, later, giants;      // long_ordinal: which of its seed's jobs a long job is
+        {
+            int32_t seed = -1, ordinal = 0;
+            for (const RibbitAlignJob &jb : cand_jobs) {
+                if (jb.seed_index != seed) { seed = jb.seed_index; ordinal = 0; }
+                if (ssw_class(jb) >= 2 && set_aside[(size_t)seed] == 1) { long_jobs.push_back(jb); long_ordinal.push_back((uint32_t)ordinal); }
+                ++ordinal;
+            }
         }
-        for (size_t i = 0; i < n_seeds; ++i) {
-            if (set_aside[i] == 1) later.push_back((uint32_t)i);
-            else if (set_aside[i] == 2) giants.push_back((uint32_t)i);
+        for (uint32_t i : cand) {
+            if (set_aside[i] == 1) later.push_back(i);
+            else if (set_aside[i] == 2) giants.push_back(i);
         }
-        std::vector<rb::SswEnds> ends(n_jobs);
-        for (rb::SswEnds &e : ends) e.flag = -1;
-        std::vector<rb::SswPath> paths(n_jobs);
-        const double t_setup = now_ms() - t_setup0;
+        const std::string &long_pool = cand_pool;
+        const double t_setup_long = now_ms() - t_setup0;
 
         // ---- the long batch, on a helper handle (own streams and buffers, same device, same resident bases)
         std::vector<rb::SswEnds> long_ends;
@@ -2006,7 +2012,17 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         int long_rc = RIBBIT_OK;
         std::string long_error;
         double t_long = 0;
-        std::thread long_thread;
+        // whatever happens on this thread from here on (the set-up or refine_to_bed may throw std::bad_alloc at chromosome size),
+        // the helper threads are stopped and joined before the frame goes: a joinable std::thread's destructor ends the process
+        std::mutex mu;
+        std::condition_variable cv;
+        std::atomic<bool> stop{false};
+        bool feeder_finished = false;
+        std::thread long_thread, later_thread, feeder;
+        struct JoinGuard {
+            std::atomic<bool> &stop; std::condition_variable &cv; std::thread &a, &b, &c;
+            ~JoinGuard() { stop = true; cv.notify_all(); if (a.joinable()) a.join(); if (b.joinable()) b.join(); if (c.joinable()) c.join(); }
+        } join_guard{stop, cv, feeder, later_thread, long_thread};
         static const bool fail_later_slices = std::getenv("RIBBIT_DEBUG_FAIL_BATCHES") != nullptr;      // test hook: see below
         if (!long_jobs.empty()) {
             if (!h->aux && (rc = ribbit_hip_open(&h->params, h->device, &h->aux))) return rc;
@@ -2015,7 +2031,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             long_thread = std::thread([&, aux]() {
                 const double tl0 = now_ms();
                 try {
-                    long_rc = run_ssw_passes(aux, long_jobs.data(), long_jobs.size(), pool.data(), pool.size(), 15, long_ends, 0xcu);
+                    long_rc = run_ssw_passes(aux, long_jobs.data(), long_jobs.size(), long_pool.data(), long_pool.size(), 15, long_ends, 0xcu);
                     if (!long_rc) long_rc = run_ssw_paths(aux, long_jobs.data(), long_jobs.size(), long_ends, long_paths);
                     if (!long_rc) {
                         size_t n_ops = 0;
@@ -2033,6 +2049,43 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         std::vector<rb::BedPiece> later_pieces;
         bool later_order_dependent = false, later_done = false;
         double t_later_thread = 0;
+        // seeds with a job beyond the kernels' reach (queries over 4096 bases: 5-60 ms of host alignment each) need nothing from
+        // the GPU: they are refined on a few host threads from the start, beside everything else, instead of as a tail
+        if (!giants.empty())
+            later_thread = std::thread([&]() {
+                const double tl0 = now_ms();
+                try {
+                    bool od = false;
+                    rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
+                                      sequence_id, h->bed, std::max(2u, threads / 4), nullptr, nullptr, nullptr, 0, n_seeds, &od, &small, nullptr, nullptr,
+                                      &later_pieces, &giants);
+                    if (od) later_order_dependent = true;
+                    else later_done = true;
+                } catch (const std::bad_alloc &) { later_done = false; }
+                t_later_thread = now_ms() - tl0;
+            });
+
+        // ---- all first-level jobs of the record (the slices' batches and the workers index them)
+        std::vector<RibbitAlignJob> jobs;
+        std::string pool;
+        rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), jobs, pool, threads, 0, n_seeds, &small);
+        const size_t n_jobs = jobs.size();
+        std::vector<uint32_t> job_first(n_seeds + 1, (uint32_t)n_jobs);
+        for (size_t j = n_jobs; j-- > 0;) job_first[(size_t)jobs[j].seed_index] = (uint32_t)j;
+        for (size_t i = n_seeds; i-- > 0;) job_first[i] = std::min(job_first[i], job_first[i + 1]);
+        std::vector<uint32_t> long_index(long_jobs.size());
+        for (size_t k = 0; k < long_jobs.size(); ++k) long_index[k] = job_first[(size_t)long_jobs[k].seed_index] + long_ordinal[k];
+        // safety net: a job outside the short classes whose seed the candidate test above let through would be a bug in that
+        // test's arithmetic, not in the result -- its seed is aligned on the host at the end
+        std::vector<uint32_t> stragglers;
+        for (size_t j = 0; j < n_jobs; ++j) {
+            const int cls = ssw_class(jobs[j]);
+            if ((cls < 0 || cls >= 2) && set_aside[(size_t)jobs[j].seed_index] == 0) { set_aside[(size_t)jobs[j].seed_index] = 3; stragglers.push_back((uint32_t)jobs[j].seed_index); }
+        }
+        std::vector<rb::SswEnds> ends(n_jobs);
+        for (rb::SswEnds &e : ends) e.flag = -1;
+        std::vector<rb::SswPath> paths(n_jobs);
+        const double t_setup = now_ms() - t_setup0;
 
         // ---- slices of the seed list: one per ~600 K seeds, 2 .. 16 (RIBBIT_SSW_SLICES overrides).  Measured at 64 Mbp (4.5 M
         // seeds; tools/refine_slices_sweep.sh): 2 slices 788 ms, 6 .. 8 757, 17 787, 32 911, 48 1085 -- a slice costs ~10 ms of
@@ -2050,10 +2103,6 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         };
         std::vector<Slice> slices(n_slices);
         for (size_t c = 0; c < n_slices; ++c) { slices[c].lo = n_seeds * c / n_slices; slices[c].hi = n_seeds * (c + 1) / n_slices; }
-        std::mutex mu;
-        std::condition_variable cv;
-        std::atomic<bool> stop{false};
-        bool feeder_finished = false;
         // the motif pool of the whole record goes to the device once; every slice's jobs point into it
         if ((rc = bind_device(h)) || (rc = h->d_ssw_pool.ensure(std::max<size_t>(pool.size(), 1)))) {
             if (long_thread.joinable()) long_thread.join();
@@ -2098,7 +2147,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             }
             sl.t_feed = now_ms() - tf0;
         };
-        std::thread feeder([&]() {
+        feeder = std::thread([&]() {
             for (size_t c = 0; c < n_slices && !stop; ++c) {
                 feed(c);
                 { std::lock_guard<std::mutex> lk(mu); slices[c].ready = true; }
@@ -2108,28 +2157,6 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             { std::lock_guard<std::mutex> lk(mu); feeder_finished = true; }
             cv.notify_all();
         });
-        // seeds with a job beyond the kernels' reach (queries over 4096 bases: 5-60 ms of host alignment each) need nothing from
-        // the GPU: they are refined on a few host threads from the start, beside everything else, instead of as a tail
-        std::thread later_thread;
-        if (!giants.empty())
-            later_thread = std::thread([&]() {
-                const double tl0 = now_ms();
-                try {
-                    bool od = false;
-                    rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
-                                      sequence_id, h->bed, std::max(2u, threads / 4), nullptr, nullptr, nullptr, 0, n_seeds, &od, &small, nullptr, nullptr,
-                                      &later_pieces, &giants);
-                    if (od) later_order_dependent = true;
-                    else later_done = true;
-                } catch (const std::bad_alloc &) { later_done = false; }
-                t_later_thread = now_ms() - tl0;
-            });
-        // whatever happens on this thread from here on (refine_to_bed may throw std::bad_alloc at chromosome size), the helper
-        // threads are stopped and joined before the frame goes: a joinable std::thread's destructor ends the process
-        struct JoinGuard {
-            std::atomic<bool> &stop; std::condition_variable &cv; std::thread &a, &b, &c;
-            ~JoinGuard() { stop = true; cv.notify_all(); if (a.joinable()) a.join(); if (b.joinable()) b.join(); if (c.joinable()) c.join(); }
-        } join_guard{stop, cv, feeder, later_thread, long_thread};
         bool order_dependent = false;
         double t_wait = 0, t_passes = 0, t_paths = 0, t_feed = 0, t_work = 0, t_later = 0, t_join = 0;
         std::vector<rb::BedPiece> pieces;
@@ -2174,6 +2201,10 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                 rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
                                   sequence_id, h->bed, h->host_threads, &jobs, &ends, &paths, 0, n_seeds, &order_dependent, &small, job_first.data(), nullptr,
                                   &pieces, &later);
+            if (!stragglers.empty())
+                rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
+                                  sequence_id, h->bed, h->host_threads, nullptr, nullptr, nullptr, 0, n_seeds, &order_dependent, &small, nullptr, nullptr,
+                                  &pieces, &stragglers);
             if (!giants.empty()) {
                 if (later_done) { for (rb::BedPiece &pc : later_pieces) pieces.push_back(std::move(pc)); }
                 else              // (the thread ran out of memory)
@@ -2193,11 +2224,11 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             for (const rb::BedPiece &pc : pieces) h->bed += pc.text;
         } else h->bed.clear();                         // an empty query somewhere (or no batches): the whole record in one call (below)
         t_join = now_ms() - tj0;
-        if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs (%zu long ones in their own batch: %.1f ms; %zu seeds set aside), set-up %.1f ms; %zu slices: "
+        if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs (%zu long ones in their own batch: %.1f ms, set up first in %.1f ms; %zu seeds set aside), set-up in all %.1f ms; %zu slices: "
                                   "feeder %.1f ms in all (GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms); workers: %.1f ms in their calls, waited %.1f ms "
                                   "for slices, %.1f ms for the long batch; seeds set aside for it %.1f ms; %zu seeds with jobs beyond the kernels' reach refined on the host beside all that in %.1f ms; "
                                   "rows put together %.1f ms; since the call began %.1f ms\n",
-                                  n_jobs, long_jobs.size(), t_long, later.size(), t_setup, n_slices, t_feed, t_passes, t_paths, t_work, t_wait, t_wait_long, t_later, giants.size(), t_later_thread, t_join,
+                                  n_jobs, long_jobs.size(), t_long, t_setup_long, later.size(), t_setup, n_slices, t_feed, t_passes, t_paths, t_work, t_wait, t_wait_long, t_later, giants.size(), t_later_thread, t_join,
                                   now_ms() - t_begin);
         add_ms(t_jobs_us, t_wait + t_wait_long);
     }

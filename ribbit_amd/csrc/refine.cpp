@@ -323,6 +323,34 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
     }
 }
 
+void build_align_jobs_of(const HostPlanes &hp, const RibbitRefineParams &prm, const SeedVec &dispatch, const int32_t *longest_runs,
+                         const int32_t *best_rows, const std::vector<uint32_t> &which, std::vector<RibbitAlignJob> &jobs, std::string &motif_pool,
+                         unsigned host_threads, const SmallMotifTable *small) {
+    jobs.clear();
+    motif_pool.clear();
+    const Bases b(hp, host_threads);
+    const size_t n = which.size();
+    const size_t chunk = 256, nchunks = (n + chunk - 1) / chunk;
+    const unsigned threads = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads ? host_threads : 1, nchunks));
+    std::vector<std::vector<RibbitAlignJob>> part_jobs(nchunks);
+    std::vector<std::string> part_pool(nchunks);
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t c; (c = next.fetch_add(1)) < nchunks;)
+            for (size_t k = c * chunk; k < std::min(n, (c + 1) * chunk); ++k)
+                build_align_jobs_range(b, prm, dispatch, longest_runs, best_rows, which[k], (size_t)which[k] + 1, part_jobs[c], part_pool[c], small);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread &th : pool) th.join();
+    for (size_t c = 0; c < nchunks; ++c) {
+        const int32_t base = (int32_t)motif_pool.size();
+        for (RibbitAlignJob &j : part_jobs[c]) { j.motif_offset += base; jobs.push_back(j); }
+        motif_pool += part_pool[c];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Alignment post-processing and BED rows
 namespace {

@@ -34,6 +34,10 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
                       std::string &motif_pool, unsigned host_threads = 1, size_t seed_lo = 0, size_t seed_hi = (size_t)-1,
                       const SmallMotifTable *small = nullptr);
 // (seed_lo, seed_hi: only the seeds dispatch[seed_lo .. seed_hi); job.seed_index stays an index into dispatch)
+// The same for the listed seeds only (increasing indices into dispatch); a seed's jobs are the same, in the same order, as in any other call
+void build_align_jobs_of(const HostPlanes &hp, const RibbitRefineParams &prm, const SeedVec &dispatch, const int32_t *longest_runs,
+                         const int32_t *best_rows, const std::vector<uint32_t> &which, std::vector<RibbitAlignJob> &jobs, std::string &motif_pool,
+                         unsigned host_threads, const SmallMotifTable *small);
 
 // cumulative, process-wide: small-motif seeds refine_to_bed took from a SmallMotifTable / ran possibleMotifs for itself
 void small_motif_counters(long &from_device, long &on_host);
