@@ -504,7 +504,8 @@ int ribbit_hip_debug_set_event_capacity(RibbitHandle *h, size_t events);
  * min(cores, 16)) wherever the call sequence can be cut; this sets the smallest number of calls per range (default 4096). */
 void ribbit_debug_set_merge_min_range(size_t calls);
 /* Test hook: what the last merge of a stage (0 substitution, 1 anchored) on the calling thread did: out = {ranges, ranges
- * merged again (after validation, or because their writes to list heads change an entry), whole stage redone in order (0/1),
+ * merged again (after validation, or because their writes to list heads change an entry), whole stage redone in order (0/1)
+ * | range runs of the anchored stage's parallel passes, all passes together << 1,
  * list-head writes that changed an entry, first range empty (0/1) | parallel passes of the stage << 8}. */
 void ribbit_debug_last_merge(int stage, int32_t out[5]);
 /* Test hook: in how many independent ranges the calling thread's last dispatch merge (fasta_utils.cpp:187-224) ran; 1 = the

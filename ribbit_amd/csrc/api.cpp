@@ -947,6 +947,14 @@ int build_anchored_calls(RibbitHandle *h) {
 
 // processShiftXORswithSubstitutions + processShiftXORsAnchored.  All GPU work of both stages is enqueued before
 // either host merge starts, so the copies (kept calls, composed planes) travel while the host merges.
+// RIBBIT_PROFILE line of the anchored stage's merge (GPU path and host replay alike)
+void print_anchored_merge_profile(size_t seeds, const rb::MergeStats &st, double dispatch_ms, unsigned dispatch_ranges) {
+    std::fprintf(stderr, "[anchored merge] %zu seeds: %u ranges on %u threads%s, %u passes, %lld changing head writes, %u ranges done again, preparation %.1f ms, merges %.1f ms "
+                 "(parallel passes %.1f ms over %u range runs: the ranges' own times sum to %.1f ms = %.1f ms per thread, longest range %.1f ms; in-order walk %.1f ms; joining the ranges' lists %.1f ms), dispatch order %.1f ms in %u ranges\n",
+                 seeds, st.ranges, st.threads, st.redone_in_order ? " (REDONE IN ORDER)" : (st.head_writes ? " (list-head writes: ranges done again, see passes)" : ""), st.passes, st.head_writes,
+                 st.ranges_redone, st.prepare_ms, st.merge_ms, st.pass_ms, st.ranges_run, st.range_ms_sum, st.range_ms_sum / std::max(1u, st.threads), st.range_ms_max, st.walk_ms, st.concat_ms, dispatch_ms, dispatch_ranges);
+}
+
 int advance_to_anchored(RibbitHandle *h) {
     if (h->stage_done >= STAGE_ANCHORED) return RIBBIT_OK;
     int rc = advance_to_perfect(h);
@@ -974,7 +982,7 @@ int advance_to_anchored(RibbitHandle *h) {
     h->lists.range_count = [hp](int shift, int start, int end) {
         return hp->has_xa(shift) ? hp->range_count_xa(shift, start, end) : hp->range_count(shift, start, end);
     };
-    h->lists.anchored.clear();
+    // (lists.anchored is not cleared here: every path of the stage sets it, and the join reuses what it holds, parallel_merge.cpp)
     const double t0 = now_ms();
     const unsigned threads = rb::merge_threads(h->host_threads);
     rb::MergeStats st;
@@ -984,9 +992,7 @@ int advance_to_anchored(RibbitHandle *h) {
     const unsigned dispatch_ranges = rb::dispatch_order_ranges(h->lists, st.cut_pos, threads, h->dispatch);
     h->merge_ms = now_ms() - t0;
     static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
-    if (profile)
-        std::fprintf(stderr, "[anchored merge] %zu seeds: %u ranges on %u threads%s, %u passes, %lld changing head writes, %u ranges done again, preparation %.1f ms, merges %.1f ms (%.1f ms of it joining the ranges' lists), dispatch order %.1f ms in %u ranges\n",
-                     h->lists.anchored.size(), st.ranges, st.threads, st.redone_in_order ? " (REDONE IN ORDER)" : (st.head_writes ? " (list-head writes: ranges done again, see passes)" : ""), st.passes, st.head_writes, st.ranges_redone, st.prepare_ms, st.merge_ms, st.concat_ms, now_ms() - t1, dispatch_ranges);
+    if (profile) print_anchored_merge_profile(h->lists.anchored.size(), st, now_ms() - t1, dispatch_ranges);
     h->subst_merge_ms = subst_todo ? merge_s : 0.0;
     h->stage_done = STAGE_ANCHORED;
     return RIBBIT_OK;
@@ -2481,7 +2487,7 @@ int32_t ribbit_debug_last_dispatch_ranges(void) { return (int32_t)rb::last_dispa
 
 void ribbit_debug_last_merge(int stage, int32_t out[5]) {
     const rb::MergeStats st = rb::last_merge_stats(stage);
-    out[0] = (int32_t)st.ranges; out[1] = (int32_t)st.ranges_redone; out[2] = st.redone_in_order ? 1 : 0;
+    out[0] = (int32_t)st.ranges; out[1] = (int32_t)st.ranges_redone; out[2] = (st.redone_in_order ? 1 : 0) | (int32_t)(st.ranges_run << 1);
     out[3] = (int32_t)std::min<long long>(st.head_writes, INT32_MAX); out[4] = (st.first_range_empty ? 1 : 0) | (int32_t)(st.passes << 8);
 }
 
@@ -2819,7 +2825,9 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
     if (anchored_stage) {
         rb::MergeStats st;
         rb::merge_anchored_stage_full(sl, anchored_calls, n_anchored_calls, rb::merge_threads(0), &st);
-        rb::dispatch_order_ranges(sl, st.cut_pos, rb::merge_threads(0), dispatch);
+        const double td = now_ms();
+        const unsigned dispatch_ranges = rb::dispatch_order_ranges(sl, st.cut_pos, rb::merge_threads(0), dispatch);
+        if (std::getenv("RIBBIT_PROFILE")) print_anchored_merge_profile(sl.anchored.size(), st, now_ms() - td, dispatch_ranges);
     }
     auto give = [](const rb::SeedVec &v, RibbitSeed **p, size_t *n) {
         *n = v.size();

@@ -214,14 +214,19 @@ void run_ranges(size_t n_ranges, unsigned threads, Work work) {
     for (std::thread &t : pool) t.join();
 }
 
-// the ranges' lists, joined in range order (each without its sentinel)
+// the ranges' lists, joined in range order (each without its sentinel).  `out` is NOT cleared first: resize() then only
+// constructs what the list grows by (nothing, for a handle whose previous record was as large), instead of writing half a
+// gigabyte of zeros on one thread that the copies overwrite at once; the copies run on the host threads.
 template <class States>
-void join_ranges(const States &state, SeedVec &out) {
-    size_t total = 0;
-    for (const auto &r : state) total += r.own.size();
-    out.clear();
-    out.reserve(total);
-    for (size_t k = 0; k < state.size(); ++k) out.insert(out.end(), state[k].own.begin() + (k > 0 ? 1 : 0), state[k].own.end());
+void join_ranges(const States &state, SeedVec &out, unsigned threads) {
+    const size_t nr = state.size();
+    std::vector<size_t> at(nr + 1, 0);
+    for (size_t k = 0; k < nr; ++k) at[k + 1] = at[k] + state[k].own.size() - (k > 0 ? 1 : 0);
+    out.resize(at[nr]);
+    run_ranges(nr, threads, [&](size_t k) {
+        const size_t n = at[k + 1] - at[k];
+        if (n) std::memcpy(out.data() + at[k], state[k].own.data() + (k > 0 ? 1 : 0), n * sizeof(RibbitSeed));
+    });
 }
 
 const RibbitSeed SENTINEL{-1, -1, 0, RIBBIT_RANK_N};   // stands for everything earlier ranges appended: ends before any interval of this range
@@ -418,7 +423,7 @@ void merge_subst_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, 
         subst_in_order(lists, kc);
         st.redone_in_order = true;
     } else {
-        join_ranges(state, lists.subst);
+        join_ranges(state, lists.subst, threads);
         for (size_t k = 0; k < nr; ++k) lists.guard_hits += state[k].guard_hits;
         SubstReplay<SeedLists> r{lists, state[nr - 1].cursor.perfect};
         r.pending_end = kc.tail_pend;
@@ -469,11 +474,12 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
     // One range's calls.  live == false (the parallel pass): Q8's writes to list heads are logged, not made.  live == true
     // (a range done again on its own, everything before it final): they are made, and `changes` tells which entries' start /
     // end / motif size they changed.
-    auto body = [&](size_t k, RangeState &me, bool live, uint64_t *changes) {
+    auto body = [&](size_t k, RangeState &me, bool live, uint64_t *changes, int *change_reach) {
         ListRefs l(lists.perfect, lists.subst, me.own, lists.range_count, lists.length, lists.max_motif);
         l.head_write_log = live ? nullptr : &me.head_writes;
         l.head_reads = me.head_reads;
         l.head_changes = live ? changes : nullptr;
+        l.head_change_reach = live ? change_reach : nullptr;
         l.undo = &me.undo;
         l.foreign_reads = &me.foreign_reads;
         l.range_lo = cut_pos[k];
@@ -500,17 +506,32 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
     const SeedVec saved_heads_s(lists.subst.begin(), lists.subst.begin() + (long)n_heads_s);
     auto differs = [](const RibbitSeed &t, const RibbitSeed &v) { return t.start != v.start || t.end != v.end || t.mlen != v.mlen || t.type != v.type; };
     size_t done = 0;
+    std::vector<double> range_ms(nr, 0.0);
+    // the ranges a parallel pass has to run: all of them in the first; in a later one those that can come out differently
+    // after the head change that ended the walk (see below), the others keep what they have
+    std::vector<char> stale(nr, 1);
+    std::vector<size_t> todo;
     bool fallback = std::getenv("RIBBIT_MERGE_FORCE_REDO") != nullptr;      // (the variable: test hook)
+    const bool rerun_all = std::getenv("RIBBIT_MERGE_RERUN_ALL") != nullptr;   // (test hook: every range behind a head change runs again, as until round 3)
     int64_t head_writes = 0;
     unsigned passes = 0;
     while (done < nr && !fallback) {
         if (++passes > 16) { fallback = true; break; }
         const size_t from = done;
-        run_ranges(nr - from, threads, [&](size_t q) {
-            const size_t k = from + q;
+        todo.clear();
+        for (size_t k = from; k < nr; ++k) if (stale[k]) { todo.push_back(k); stale[k] = 0; }
+        const double tp = now_ms();
+        run_ranges(todo.size(), threads, [&](size_t q) {
+            const size_t k = todo[q];
+            const double tr = now_ms();
             state[k].reset(k > 0, first[k + 1] - first[k]);
-            body(k, state[k], false, nullptr);
+            body(k, state[k], false, nullptr, nullptr);
+            range_ms[k] = now_ms() - tr;
         });
+        const double tw = now_ms();
+        st.pass_ms += tw - tp;
+        for (size_t k2 : todo) { st.range_ms_sum += range_ms[k2]; st.range_ms_max = std::max(st.range_ms_max, range_ms[k2]); }
+        st.ranges_run += (unsigned)todo.size();
         bool again = false;
         size_t k = from;
         for (; k < nr; ++k) {
@@ -519,19 +540,35 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
             for (const ListRefs::HeadWrite &w : state[k].head_writes) changing += differs(*w.target, w.value);
             head_writes += changing;
             uint64_t ch[2] = {0, 0};
+            int reach = -1;
             if (redo || changing) {
                 state[k].reset(k > 0, first[k + 1] - first[k]);
-                body(k, state[k], true, ch);
+                body(k, state[k], true, ch, &reach);
                 ++st.ranges_redone;
             }
             if (k == 0 && state[0].own.empty()) { fallback = true; break; }      // later ranges assumed a non-empty list
             if (ch[0] | ch[1]) {
-                bool read_later = false;
-                for (size_t j = k + 1; j < nr && !read_later; ++j)
-                    read_later = ((state[j].head_reads[0] & ch[0]) | (state[j].head_reads[1] & ch[1])) != 0;
-                if (read_later) { done = k + 1; again = true; break; }
+                // A later range comes out differently only if it read a changed entry by loop counter, or if the entry -- where
+                // it was or where the write put it -- can be met by the range's ordinary walks: those stay right of the range's
+                // left cut, so an entry that ends more than a motif before the cut is out of their sight, like every other seed
+                // of the ranges before.  Bit 63 stands for every entry from the 64th on: then all ranges behind run again.
+                const bool wide = rerun_all || ((ch[0] | ch[1]) >> 63) != 0;
+                bool any = false;
+                for (size_t j = k + 1; j < nr; ++j) {
+                    const bool reads = ((state[j].head_reads[0] & ch[0]) | (state[j].head_reads[1] & ch[1])) != 0;
+                    any |= reads;
+                }
+                if (any) {
+                    for (size_t j = k + 1; j < nr; ++j) {
+                        const bool reads = ((state[j].head_reads[0] & ch[0]) | (state[j].head_reads[1] & ch[1])) != 0;
+                        const bool in_sight = (int64_t)cut_pos[j] <= (int64_t)reach + lists.max_motif + 2;
+                        if (wide || reads || in_sight) stale[j] = 1;
+                    }
+                    done = k + 1; again = true; break;
+                }
             }
         }
+        st.walk_ms += now_ms() - tw;
         if (fallback) break;
         if (!again) done = nr;
     }
@@ -549,7 +586,7 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
         st.redone_in_order = true;
     } else {
         const double tc = now_ms();
-        join_ranges(state, lists.anchored);
+        join_ranges(state, lists.anchored, threads);
         for (size_t k = 0; k < nr; ++k) lists.guard_hits += state[k].guard_hits;
         st.concat_ms = now_ms() - tc;
         AnchoredReplay<SeedLists> r{lists, state[nr - 1].cursor};

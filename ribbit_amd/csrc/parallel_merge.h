@@ -53,8 +53,12 @@ struct MergeStats {
     bool redone_in_order = false;
     long long head_writes = 0;     // Q8 writes to list heads that would change an entry (their ranges are done again with the writes made)
     unsigned passes = 1;           // parallel passes of the anchored stage (one more per head change that a later range read)
+    unsigned ranges_run = 0;       // ranges run in those passes, all passes together (== ranges when there was one pass)
     bool first_range_empty = false;
     double prepare_ms = 0.0, merge_ms = 0.0, concat_ms = 0.0;      // concat_ms: the part of merge_ms spent joining the ranges' lists
+    // anchored stage, inside merge_ms: wall time of the parallel passes, of the in-order walks behind them (with the ranges
+    // they do again), and the ranges' own times in the parallel passes (sum over ranges, longest range)
+    double pass_ms = 0.0, walk_ms = 0.0, range_ms_sum = 0.0, range_ms_max = 0.0;
     std::vector<int> cut_pos;  // the positions the ranges were cut at (first entry INT32_MIN): uncovered by any call or earlier-stage seed
 };
 

@@ -533,8 +533,10 @@ Cursor2 anchored_add(ListRefs &sl, int seed_start, int seed_end, int mlen, const
                         if (sl.head_write_log) sl.head_write_log->push_back({&(*dst)[j], value});     // parallel worker: decided later
                         else {
                             RibbitSeed &tgt = (*dst)[j];
-                            if (sl.head_changes && (tgt.start != value.start || tgt.end != value.end || tgt.mlen != value.mlen))
+                            if (sl.head_changes && (tgt.start != value.start || tgt.end != value.end || tgt.mlen != value.mlen)) {
                                 sl.head_changes[dst == &P ? 0 : 1] |= 1ull << std::min<size_t>(j, 63);
+                                if (sl.head_change_reach) *sl.head_change_reach = std::max(*sl.head_change_reach, std::max(tgt.end, value.end));
+                            }
                             tgt = value;
                         }
                     }

@@ -49,6 +49,8 @@ struct ListRefs {
     // a write changed start, end or motif size of entry j (what those reads see; a change of the type alone is a retirement
     // like any other).
     uint64_t *head_reads = nullptr, *head_changes = nullptr;
+    // with head_changes: the largest end among the old and new values of the entries such writes changed (-1: none)
+    int *head_change_reach = nullptr;
     // Parallel workers (parallel_merge.h) share the lists of the earlier stages.  The only field that changes there is
     // `type` (a seed is retired), and the only place where the type of a seed OUTSIDE the worker's range steers a
     // decision is the candidate walk, which pushes the nearest seed to the left unless it is retired

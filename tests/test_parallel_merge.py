@@ -86,7 +86,7 @@ def test_redo_in_order_restores_what_the_ranges_changed(tiny_ranges):
             _check(seq, m_lo, m_hi, name)
         out = (C.c_int32 * 5)()
         ribbit_amd.load_library().ribbit_debug_last_merge(1, C.byref(out))
-        assert out[2] == 1
+        assert out[2] & 1 == 1
     finally:
         del os.environ["RIBBIT_MERGE_FORCE_REDO"]
 
@@ -110,4 +110,17 @@ def test_a_list_head_write_that_changes_its_entry_keeps_the_merge_parallel_and_e
     out = (C.c_int32 * 5)()
     ribbit_amd.load_library().ribbit_debug_last_merge(1, C.byref(out))
     ranges, again, in_order, changing, tail = (int(x) for x in out)
-    assert ranges > 1 and changing >= 1 and again >= 1 and in_order == 0 and (tail >> 8) >= 1, list(out)
+    assert ranges > 1 and changing >= 1 and again >= 1 and in_order & 1 == 0 and (tail >> 8) >= 1, list(out)
+    # Behind the change only the ranges that can come out differently run again (those that read a changed entry by loop
+    # counter, or whose left cut lies within a motif of where the entry was or went): with every range behind it run again,
+    # as until round 3 (the variable is a test hook), the lists are the same and there are more range runs.
+    passes, runs = tail >> 8, in_order >> 1
+    os.environ["RIBBIT_MERGE_RERUN_ALL"] = "1"
+    try:
+        _check(seq, 2, 30, "seed 38, every range behind the change again")
+        ribbit_amd.load_library().ribbit_debug_last_merge(1, C.byref(out))
+    finally:
+        del os.environ["RIBBIT_MERGE_RERUN_ALL"]
+    assert (int(out[4]) >> 8) == passes and int(out[2]) >> 1 >= runs, (list(out), passes, runs)
+    if passes > 1 and ranges > 8:
+        assert int(out[2]) >> 1 > runs, (list(out), runs)

@@ -75,7 +75,7 @@ def test_list_head_writes_on_a_chromosome_sized_record_keep_the_merge_parallel_a
                 stats[mode] = [int(x) for x in out]
         finally:
             os.environ.pop("RIBBIT_MERGE_FORCE_REDO", None)
-    assert stats["in order"][2] == 1 and stats["parallel"][2] == 0, stats
+    assert stats["in order"][2] & 1 == 1 and stats["parallel"][2] & 1 == 0, stats
     if bases == 242193529:
         assert stats["parallel"][3] >= 1 and (stats["parallel"][4] >> 8) >= 2, stats          # the write is there, and cost one more pass
     for x, y in zip(lists["parallel"], lists["in order"]):

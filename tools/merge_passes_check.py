@@ -35,7 +35,7 @@ for seed in seeds:
             L.ribbit_debug_last_merge(1, C.byref(out))
             got[mode] = (p.copy(), s.copy(), a.copy(), d.copy())
             print(f"seed {seed}, {bases} bases, {mode}: substitution + anchored stages {dt:.2f} s, anchored merge {sc.timing_ms(4):.0f} ms; ranges {out[0]}, "
-                  f"done again {out[1]}, in order {out[2]}, changing head writes {out[3]}, passes {out[4] >> 8}", flush=True)
+                  f"done again {out[1]}, in order {out[2] & 1}, range runs {out[2] >> 1}, changing head writes {out[3]}, passes {out[4] >> 8}", flush=True)
     os.environ.pop("RIBBIT_MERGE_FORCE_REDO", None)
     same = all(np.array_equal(x.view("<i4"), y.view("<i4")) for x, y in zip(got["parallel"], got["in order"]))
     print(f"seed {seed}: lists identical to the in-order merge: {same}", flush=True)
