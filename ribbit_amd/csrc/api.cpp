@@ -950,9 +950,9 @@ int build_anchored_calls(RibbitHandle *h) {
 // RIBBIT_PROFILE line of the anchored stage's merge (GPU path and host replay alike)
 void print_anchored_merge_profile(size_t seeds, const rb::MergeStats &st, double dispatch_ms, unsigned dispatch_ranges) {
     std::fprintf(stderr, "[anchored merge] %zu seeds: %u ranges on %u threads%s, %u passes, %lld changing head writes, %u ranges done again, preparation %.1f ms, merges %.1f ms "
-                 "(parallel passes %.1f ms over %u range runs: the ranges' own times sum to %.1f ms = %.1f ms per thread, longest range %.1f ms; in-order walk %.1f ms; joining the ranges' lists %.1f ms), dispatch order %.1f ms in %u ranges\n",
+                 "(parallel passes %.1f ms over %u range runs: the ranges' own times sum to %.1f ms = %.1f ms per thread, longest range %.1f ms; in-order walk %.1f ms; joining the ranges' lists %.1f ms; before the first pass %.1f ms; end-of-sequence calls %.1f ms), dispatch order %.1f ms in %u ranges\n",
                  seeds, st.ranges, st.threads, st.redone_in_order ? " (REDONE IN ORDER)" : (st.head_writes ? " (list-head writes: ranges done again, see passes)" : ""), st.passes, st.head_writes,
-                 st.ranges_redone, st.prepare_ms, st.merge_ms, st.pass_ms, st.ranges_run, st.range_ms_sum, st.range_ms_sum / std::max(1u, st.threads), st.range_ms_max, st.walk_ms, st.concat_ms, dispatch_ms, dispatch_ranges);
+                 st.ranges_redone, st.prepare_ms, st.merge_ms, st.pass_ms, st.ranges_run, st.range_ms_sum, st.range_ms_sum / std::max(1u, st.threads), st.range_ms_max, st.walk_ms, st.concat_ms, st.before_passes_ms, st.flush_ms, dispatch_ms, dispatch_ranges);
 }
 
 int advance_to_anchored(RibbitHandle *h) {

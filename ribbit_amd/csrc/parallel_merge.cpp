@@ -515,6 +515,17 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
     const bool rerun_all = std::getenv("RIBBIT_MERGE_RERUN_ALL") != nullptr;   // (test hook: every range behind a head change runs again, as until round 3)
     int64_t head_writes = 0;
     unsigned passes = 0;
+    // The joined list's storage is made ready beside the passes: a vector constructs (zeroes) what it grows by, on one
+    // thread -- 90 ms for a chromosome's half gigabyte when done at the join.  Nothing reads lists.anchored until then, so a
+    // helper sizes it for the most the stage can append (one seed per kept call) while the ranges run; the join then only
+    // shrinks it and copies on all threads.
+    std::thread presize;
+    if (!fallback) presize = std::thread([&lists, &kc]() {
+        try { lists.anchored.clear(); lists.anchored.resize(kc.n + kc.n_flush + 1); }
+        catch (...) { lists.anchored.clear(); }      // out of memory here: the join's own resize reports it on the calling thread
+    });
+    struct JoinPresize { std::thread &t; ~JoinPresize() { if (t.joinable()) t.join(); } } presize_guard{presize};
+    st.before_passes_ms = now_ms() - t1;
     while (done < nr && !fallback) {
         if (++passes > 16) { fallback = true; break; }
         const size_t from = done;
@@ -575,6 +586,7 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
     st.head_writes = head_writes;
     st.passes = passes;
     st.first_range_empty = state[0].own.empty();
+    if (presize.joinable()) presize.join();
     if (fallback) {
         for (size_t k = nr; k-- > 0;) state[k].reset(false, 0);      // takes back the ranges' retirements
         std::copy(saved_heads_p.begin(), saved_heads_p.end(), lists.perfect.begin());
@@ -589,9 +601,11 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
         join_ranges(state, lists.anchored, threads);
         for (size_t k = 0; k < nr; ++k) lists.guard_hits += state[k].guard_hits;
         st.concat_ms = now_ms() - tc;
+        const double tf = now_ms();
         AnchoredReplay<SeedLists> r{lists, state[nr - 1].cursor};
         r.pending_end = kc.tail_pend;
         r.run(kc.flush, kc.n_flush, lists.length);
+        st.flush_ms = now_ms() - tf;
     }
     st.merge_ms = now_ms() - t1;
     tl_last_stats[1] = st;

@@ -59,6 +59,7 @@ struct MergeStats {
     // anchored stage, inside merge_ms: wall time of the parallel passes, of the in-order walks behind them (with the ranges
     // they do again), and the ranges' own times in the parallel passes (sum over ranges, longest range)
     double pass_ms = 0.0, walk_ms = 0.0, range_ms_sum = 0.0, range_ms_max = 0.0;
+    double before_passes_ms = 0.0, flush_ms = 0.0;     // inside merge_ms too: what precedes the first pass; the end-of-sequence calls after the join
     std::vector<int> cut_pos;  // the positions the ranges were cut at (first entry INT32_MIN): uncovered by any call or earlier-stage seed
 };
 
