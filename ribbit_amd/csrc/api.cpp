@@ -982,6 +982,7 @@ int advance_to_anchored(RibbitHandle *h) {
     h->lists.range_count = [hp](int shift, int start, int end) {
         return hp->has_xa(shift) ? hp->range_count_xa(shift, start, end) : hp->range_count(shift, start, end);
     };
+    if (hp->xa_stored()) { h->lists.plane_words = hp->xa_words(); h->lists.plane_stride = hp->xa_stride; h->lists.plane_lo = hp->xa_m_lo; h->lists.plane_hi = hp->xa_m_hi; }
     // (lists.anchored is not cleared here: every path of the stage sets it, and the join reuses what it holds, parallel_merge.cpp)
     const double t0 = now_ms();
     const unsigned threads = rb::merge_threads(h->host_threads);
@@ -2732,6 +2733,7 @@ int ribbit_host_merge_chunks(const RibbitScanParams *params, int64_t length,
         sl.range_count = [&hp](int shift, int start, int end) {
             return hp.has_xa(shift) ? hp.range_count_xa(shift, start, end) : hp.range_count(shift, start, end);
         };
+        if (hp.xa_stored()) { sl.plane_words = hp.xa_words(); sl.plane_stride = hp.xa_stride; sl.plane_lo = hp.xa_m_lo; sl.plane_hi = hp.xa_m_hi; }
         rb::SeedVec dispatch;
         {
             Joined j;
@@ -2820,6 +2822,7 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
         sl.range_count = [&hp](int shift, int start, int end) {
             return hp.has_xa(shift) ? hp.range_count_xa(shift, start, end) : hp.range_count(shift, start, end);
         };
+        if (hp.xa_stored()) { sl.plane_words = hp.xa_words(); sl.plane_stride = hp.xa_stride; sl.plane_lo = hp.xa_m_lo; sl.plane_hi = hp.xa_m_hi; }
     }
     rb::SeedVec dispatch;
     if (anchored_stage) {

@@ -474,6 +474,11 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
     // One range's calls.  live == false (the parallel pass): Q8's writes to list heads are logged, not made.  live == true
     // (a range done again on its own, everything before it final): they are made, and `changes` tells which entries' start /
     // end / motif size they changed.
+    // Every kept call goes through the candidate walk, and half of them count matches over their interval on their
+    // motif's composed plane -- a random place in 12 bytes per base of planes, i.e. a memory access that nothing has asked
+    // for before.  The call list says where, several calls ahead (RIBBIT_MERGE_PREFETCH: how many; 0 = none).
+    const char *prefetch_env = std::getenv("RIBBIT_MERGE_PREFETCH");      // read per stage: tools/merge_prefetch_sweep.py changes it between runs
+    const size_t ahead = lists.plane_words ? (prefetch_env ? (size_t)std::strtoul(prefetch_env, nullptr, 10) : (size_t)8) : 0;
     auto body = [&](size_t k, RangeState &me, bool live, uint64_t *changes, int *change_reach) {
         ListRefs l(lists.perfect, lists.subst, me.own, lists.range_count, lists.length, lists.max_motif);
         l.head_write_log = live ? nullptr : &me.head_writes;
@@ -489,6 +494,15 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
         AnchoredReplay<ListRefs> r{l, start_cursor[k]};
         for (size_t i = first[k]; i < first[k + 1]; ++i) {
             if (kc.pend) r.pending_end = std::max(r.pending_end, kc.pend[i]);
+            if (ahead && i + ahead < first[k + 1]) {
+                // what the nested-seed tests of a coming call will count over: its own motif's plane, its own interval
+                const RibbitCall &n = kc.calls[i + ahead];
+                if (n.mlen >= lists.plane_lo && n.mlen <= lists.plane_hi) {
+                    const uint32_t *w = lists.plane_words + (int64_t)(n.mlen - lists.plane_lo) * lists.plane_stride;
+                    __builtin_prefetch(w + (n.start >> 5), 0, 1);
+                    __builtin_prefetch(w + (n.end >> 5), 0, 1);
+                }
+            }
             r.call(kc.calls[i], true);
         }
         me.guard_hits = l.guard_hits;

@@ -26,6 +26,12 @@ struct SeedLists {
     SeedVec perfect, subst, anchored;
     RangeCount range_count;
     int64_t guard_hits = 0;   // defined-divergence guards
+    // Where range_count's answers of the anchored stage come from, when the composed planes are stored (host_planes.h):
+    // plane m = plane_words + (m - plane_lo) * plane_stride, for m = plane_lo..plane_hi.  Only a hint: the range-parallel
+    // merge prefetches the words a coming call's queries will read (parallel_merge.cpp); null when there is nothing stored.
+    const uint32_t *plane_words = nullptr;
+    int64_t plane_stride = 0;
+    int plane_lo = 0, plane_hi = -1;
 };
 
 // The same lists by reference, for the window stages' merges: when a record's calls are merged as independent
