@@ -1491,9 +1491,16 @@ static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n,
     HIP_TRY(hipMemcpyAsync(h->d_ssw_order.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     if (pool_len && !pool_resident) HIP_TRY(hipMemcpyAsync(h->d_ssw_pool.p, pool, pool_len, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_ssw_out.p, 0xff, n * 8 * sizeof(int32_t), h->stream));      // flag -1 unless a kernel writes the record
+    // The two long classes run a workgroup per alignment (ssw_group.hip: 8 wavefronts for the giant class, 4 for the huge one)
+    // unless RIBBIT_SSW_GROUP=0 asks for the older one-wavefront-per-alignment kernel (kept for comparison: same results).
+    static const bool group_kernels = !(std::getenv("RIBBIT_SSW_GROUP") && std::atoi(std::getenv("RIBBIT_SSW_GROUP")) == 0);
     if (n_giant) {
         HIP_TRY(hipEventRecord(h->ev_ssw, h->stream));
         HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->ev_ssw, 0));
+        if (group_kernels && rb::ssw_group_fits(rb::SSW_GIANT_Q, 8))
+            rb::launch_ssw_passes_group(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_order.p, (int)n_giant, mask_len,
+                                        rb::SSW_GIANT_Q, rb::SSW_GIANT_R, 8, h->d_ssw_out.p, h->copy_stream);
+        else
         rb::launch_ssw_passes_wave(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_order.p, (int)n_giant, mask_len,
                                    rb::SSW_GIANT_Q, rb::SSW_GIANT_R, h->d_ssw_out.p, h->copy_stream);
         HIP_TRY(hipGetLastError());
@@ -1501,7 +1508,7 @@ static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n,
     }
     const int32_t *rest = h->d_ssw_order.p + n_giant;
     rb::launch_ssw_passes(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, rest + n_huge + n_big, (int)n_small,
-                          rest + n_huge, (int)n_big, rest, (int)n_huge, mask_len, h->d_ssw_out.p, h->stream);
+                          rest + n_huge, (int)n_big, rest, (int)n_huge, mask_len, h->d_ssw_out.p, h->stream, group_kernels ? 4 : 0);
     HIP_TRY(hipGetLastError());
     if (n_giant) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_ssw, 0));
     HIP_TRY(hipMemcpyAsync(ends.data(), h->d_ssw_out.p, n * sizeof(rb::SswEnds), hipMemcpyDeviceToHost, h->stream));
@@ -2072,77 +2079,82 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                 t_later_thread = now_ms() - tl0;
             });
 
-        // ---- all first-level jobs of the record (the slices' batches and the workers index them)
-        std::vector<RibbitAlignJob> jobs;
-        std::string pool;
-        rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), jobs, pool, threads, 0, n_seeds, &small);
-        const size_t n_jobs = jobs.size();
-        std::vector<uint32_t> job_first(n_seeds + 1, (uint32_t)n_jobs);
-        for (size_t j = n_jobs; j-- > 0;) job_first[(size_t)jobs[j].seed_index] = (uint32_t)j;
-        for (size_t i = n_seeds; i-- > 0;) job_first[i] = std::min(job_first[i], job_first[i + 1]);
-        std::vector<uint32_t> long_index(long_jobs.size());
-        for (size_t k = 0; k < long_jobs.size(); ++k) long_index[k] = job_first[(size_t)long_jobs[k].seed_index] + long_ordinal[k];
-        // safety net: a job outside the short classes whose seed the candidate test above let through would be a bug in that
-        // test's arithmetic, not in the result -- its seed is aligned on the host at the end
-        std::vector<uint32_t> stragglers;
-        for (size_t j = 0; j < n_jobs; ++j) {
-            const int cls = ssw_class(jobs[j]);
-            if ((cls < 0 || cls >= 2) && set_aside[(size_t)jobs[j].seed_index] == 0) { set_aside[(size_t)jobs[j].seed_index] = 3; stragglers.push_back((uint32_t)jobs[j].seed_index); }
-        }
-        std::vector<rb::SswEnds> ends(n_jobs);
-        for (rb::SswEnds &e : ends) e.flag = -1;
-        std::vector<rb::SswPath> paths(n_jobs);
-        const double t_setup = now_ms() - t_setup0;
-
         // ---- slices of the seed list: one per ~600 K seeds, 2 .. 16 (RIBBIT_SSW_SLICES overrides).  Measured at 64 Mbp (4.5 M
         // seeds; tools/refine_slices_sweep.sh): 2 slices 788 ms, 6 .. 8 757, 17 787, 32 911, 48 1085 -- a slice costs ~10 ms of
-        // launches, copies and synchronisation beyond its kernels
+        // launches, copies and synchronisation beyond its kernels.
+        // A slice owns its first-level jobs, their motif strings and their results.  The jobs are set up slice by slice on
+        // the host threads, and the feeder takes a slice as soon as it is set up: the GPU used to wait for the set-up of the
+        // whole record (0.45 s at chromosome-1 size, a third of what the feeder then needs for all slices).
         size_t n_slices = std::max<size_t>(2, std::min<size_t>(16, n_seeds / 600000));
         if (const char *env = std::getenv("RIBBIT_SSW_SLICES")) n_slices = (size_t)std::max(1, std::atoi(env));
         n_slices = std::min(n_slices, n_seeds);
         struct Slice {
             size_t lo = 0, hi = 0;
+            std::vector<RibbitAlignJob> jobs;       // in seed order
+            std::string pool;
+            std::vector<uint32_t> job_first;        // job_first[i - lo] = first job of dispatch seed i, for i = lo .. hi
+            std::vector<rb::SswEnds> ends;
+            std::vector<rb::SswPath> paths;
             std::vector<uint32_t> ops;
             int rc = RIBBIT_OK;
             std::string error;
-            bool ready = false;
+            bool built = false, ready = false;
             double t_passes = 0, t_paths = 0, t_feed = 0;
         };
         std::vector<Slice> slices(n_slices);
         for (size_t c = 0; c < n_slices; ++c) { slices[c].lo = n_seeds * c / n_slices; slices[c].hi = n_seeds * (c + 1) / n_slices; }
-        // the motif pool of the whole record goes to the device once; every slice's jobs point into it
-        if ((rc = bind_device(h)) || (rc = h->d_ssw_pool.ensure(std::max<size_t>(pool.size(), 1)))) {
-            if (long_thread.joinable()) long_thread.join();
-            if (rc != RIBBIT_E_NOMEM) return rc;
-        } else if (!pool.empty()) {
-            const hipError_t e = hipMemcpy(h->d_ssw_pool.p, pool.data(), pool.size(), hipMemcpyHostToDevice);
-            if (e != hipSuccess) { if (long_thread.joinable()) long_thread.join(); return fail(RIBBIT_E_DEVICE, "upload of the motif pool failed: %s", hipGetErrorString(e)); }
-        }
-        const int pool_rc = rc;
-        rc = RIBBIT_OK;
+        auto slice_of = [&](size_t seed) {
+            size_t c = std::min(n_slices - 1, seed * n_slices / n_seeds);
+            while (c > 0 && seed < slices[c].lo) --c;
+            while (c + 1 < n_slices && seed >= slices[c].hi) ++c;
+            return c;
+        };
+        // where a long job's results go: (slice of its seed, first job of the seed + which of the seed's jobs it is)
+        std::vector<uint32_t> long_slice(long_jobs.size());
+        for (size_t k = 0; k < long_jobs.size(); ++k) long_slice[k] = (uint32_t)slice_of((size_t)long_jobs[k].seed_index);
+        // safety net: a job outside the short classes whose seed the candidate test above let through would be a bug in that
+        // test's arithmetic, not in the result -- its seed is aligned on the host at the end
+        std::vector<uint32_t> stragglers;
+        size_t n_jobs = 0;
+        auto build_slice = [&](size_t c) {
+            Slice &sl = slices[c];
+            rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sl.jobs, sl.pool, threads, sl.lo, sl.hi, &small);
+            const size_t nj = sl.jobs.size(), span = sl.hi - sl.lo;
+            sl.job_first.assign(span + 1, (uint32_t)nj);
+            for (size_t j = nj; j-- > 0;) sl.job_first[(size_t)sl.jobs[j].seed_index - sl.lo] = (uint32_t)j;
+            for (size_t i = span; i-- > 0;) sl.job_first[i] = std::min(sl.job_first[i], sl.job_first[i + 1]);
+            for (size_t j = 0; j < nj; ++j) {
+                const int cls = ssw_class(sl.jobs[j]);
+                uint8_t &mark = set_aside[(size_t)sl.jobs[j].seed_index];      // (no worker reads this slice's marks before it is refined)
+                if ((cls < 0 || cls >= 2) && mark == 0) { mark = 3; stragglers.push_back((uint32_t)sl.jobs[j].seed_index); }
+            }
+            sl.ends.assign(nj, rb::SswEnds{});
+            for (rb::SswEnds &e : sl.ends) e.flag = -1;
+            sl.paths.assign(nj, rb::SswPath{});
+            n_jobs += nj;
+        };
         auto feed = [&](size_t c) {
             Slice &sl = slices[c];
             const double tf0 = now_ms();
             try {
-                const size_t ja = job_first[sl.lo], jb = job_first[sl.hi];
+                const size_t nj = sl.jobs.size();
                 const double tp = now_ms();
                 std::vector<rb::SswEnds> e;
                 std::vector<rb::SswPath> pth;
-                sl.rc = pool_rc ? pool_rc
-                        : (fail_later_slices && c > 0) ? fail(RIBBIT_E_NOMEM, "forced by RIBBIT_DEBUG_FAIL_BATCHES")
-                                                       : run_ssw_passes(h, jobs.data() + ja, jb - ja, pool.data(), pool.size(), 15, e, 0x3u, true);
+                sl.rc = (fail_later_slices && c > 0) ? fail(RIBBIT_E_NOMEM, "forced by RIBBIT_DEBUG_FAIL_BATCHES")
+                                                     : run_ssw_passes(h, sl.jobs.data(), nj, sl.pool.data(), sl.pool.size(), 15, e, 0x3u);
                 const double tq = now_ms();
-                if (!sl.rc) sl.rc = run_ssw_paths(h, jobs.data() + ja, jb - ja, e, pth);
+                if (!sl.rc) sl.rc = run_ssw_paths(h, sl.jobs.data(), nj, e, pth);
                 if (!sl.rc) {
                     // the paths point into the handle's pinned buffer, which the next slice overwrites
                     size_t n_ops = 0;
                     for (const rb::SswPath &pt : pth) if (pt.ops) n_ops = std::max(n_ops, (size_t)(pt.ops - h->h_path_ops.p) + (size_t)pt.n_ops);
                     sl.ops.assign(h->h_path_ops.p, h->h_path_ops.p + n_ops);
-                    for (size_t k = 0; k < jb - ja; ++k) {
+                    for (size_t k = 0; k < nj; ++k) {
                         if (e[k].flag == -1) continue;          // not this batch's (a long job: the other thread owns its entries)
-                        ends[ja + k] = e[k];
-                        paths[ja + k] = pth[k];
-                        if (pth[k].ops) paths[ja + k].ops = sl.ops.data() + (pth[k].ops - h->h_path_ops.p);
+                        sl.ends[k] = e[k];
+                        sl.paths[k] = pth[k];
+                        if (pth[k].ops) sl.paths[k].ops = sl.ops.data() + (pth[k].ops - h->h_path_ops.p);
                     }
                 } else {
                     sl.error = g_last_error;
@@ -2154,8 +2166,10 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             }
             sl.t_feed = now_ms() - tf0;
         };
+        if ((rc = bind_device(h))) return rc;
         feeder = std::thread([&]() {
             for (size_t c = 0; c < n_slices && !stop; ++c) {
+                { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return slices[c].built || stop.load(); }); if (!slices[c].built) break; }
                 feed(c);
                 { std::lock_guard<std::mutex> lk(mu); slices[c].ready = true; }
                 cv.notify_all();
@@ -2164,6 +2178,12 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             { std::lock_guard<std::mutex> lk(mu); feeder_finished = true; }
             cv.notify_all();
         });
+        for (size_t c = 0; c < n_slices; ++c) {
+            build_slice(c);
+            { std::lock_guard<std::mutex> lk(mu); slices[c].built = true; }
+            cv.notify_all();
+        }
+        const double t_setup = now_ms() - t_setup0;
         bool order_dependent = false;
         double t_wait = 0, t_passes = 0, t_paths = 0, t_feed = 0, t_work = 0, t_later = 0, t_join = 0;
         std::vector<rb::BedPiece> pieces;
@@ -2176,8 +2196,8 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             t_passes += sl.t_passes; t_paths += sl.t_paths; t_feed += sl.t_feed;
             const double tk = now_ms();
             rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
-                              sequence_id, h->bed, h->host_threads, &jobs, &ends, &paths, sl.lo, sl.hi, &order_dependent, &small,
-                              job_first.data(), set_aside.data(), &pieces);
+                              sequence_id, h->bed, h->host_threads, &sl.jobs, &sl.ends, &sl.paths, sl.lo, sl.hi, &order_dependent, &small,
+                              sl.job_first.data(), set_aside.data(), &pieces, nullptr, sl.lo);
             t_work += now_ms() - tk;
             if (order_dependent) break;
         }
@@ -2202,12 +2222,32 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         if (!order_dependent && !batches_failed) {
             // the seeds set aside: their long alignments come from the long batch, the others from the slices
             const double tl0 = now_ms();
-            // the seeds set aside for the long batch: its results in place, then one call over all of them
-            for (size_t k = 0; k < long_index.size(); ++k) { ends[long_index[k]] = long_ends[k]; paths[long_index[k]] = long_paths[k]; }
-            if (!later.empty())
+            // the seeds set aside for the long batch: its results in place, then one call per slice over those of its seeds
+            for (size_t k = 0; k < long_jobs.size(); ++k) {
+                Slice &sl = slices[long_slice[k]];
+                const size_t at = (size_t)sl.job_first[(size_t)long_jobs[k].seed_index - sl.lo] + long_ordinal[k];
+                sl.ends[at] = long_ends[k]; sl.paths[at] = long_paths[k];
+            }
+            if (!later.empty()) {
+                // one call over all of them, on all threads (they are few and individually expensive: a call per slice waited
+                // for its slowest seed seven times over): their jobs and results gathered from the slices, in seed order
+                std::vector<RibbitAlignJob> lj;
+                std::vector<rb::SswEnds> le;
+                std::vector<rb::SswPath> lp;
+                std::vector<uint32_t> lfirst(n_seeds + 1, 0);       // only the entries of these seeds (and the one after each) are read
+                for (uint32_t i : later) {
+                    const Slice &sl = slices[slice_of(i)];
+                    const size_t ja = sl.job_first[i - sl.lo], jb = sl.job_first[i - sl.lo + 1];
+                    lfirst[i] = (uint32_t)lj.size();
+                    lj.insert(lj.end(), sl.jobs.begin() + (long)ja, sl.jobs.begin() + (long)jb);
+                    le.insert(le.end(), sl.ends.begin() + (long)ja, sl.ends.begin() + (long)jb);
+                    lp.insert(lp.end(), sl.paths.begin() + (long)ja, sl.paths.begin() + (long)jb);
+                    lfirst[i + 1] = (uint32_t)lj.size();
+                }
                 rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
-                                  sequence_id, h->bed, h->host_threads, &jobs, &ends, &paths, 0, n_seeds, &order_dependent, &small, job_first.data(), nullptr,
+                                  sequence_id, h->bed, h->host_threads, &lj, &le, &lp, 0, n_seeds, &order_dependent, &small, lfirst.data(), nullptr,
                                   &pieces, &later);
+            }
             if (!stragglers.empty())
                 rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
                                   sequence_id, h->bed, h->host_threads, nullptr, nullptr, nullptr, 0, n_seeds, &order_dependent, &small, nullptr, nullptr,

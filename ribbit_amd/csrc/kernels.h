@@ -168,9 +168,15 @@ constexpr int SSW_SMALL_Q = 128, SSW_SMALL_R = 256, SSW_BIG_Q = 512, SSW_BIG_R =
 // ssw_wave.hip: the same two passes, one wavefront per alignment (queries of 129..qcap bases, reference up to rcap)
 void launch_ssw_passes_wave(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs, const int32_t *order, int n,
                             int mask_len, int qcap, int rcap, int32_t *out, hipStream_t stream);
+// ssw_group.hip: the same two passes, one WORKGROUP of `waves` (4 or 8) wavefronts per alignment: a column's stripes dealt to
+// the wavefronts, for the long classes.  ssw_group_fits: the class's longest query fits that many wavefronts.
+bool ssw_group_fits(int qcap, int waves);
+void launch_ssw_passes_group(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs, const int32_t *order, int n,
+                             int mask_len, int qcap, int rcap, int waves, int32_t *out, hipStream_t stream);
 void launch_ssw_passes(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs,
                        const int32_t *order_small, int n_small, const int32_t *order_big, int n_big, const int32_t *order_huge, int n_huge,
-                       int mask_len, int32_t *out, hipStream_t stream);
+                       int mask_len, int32_t *out, hipStream_t stream, int huge_group_waves = 0);
+// huge_group_waves: 0 = the huge class on one wavefront per alignment (ssw_wave.hip), 4 / 8 = on a workgroup of that many
 
 // The banded path search (ssw.c:590-775) of n_items alignments whose end points are known, one wavefront each (ssw_path.hip).
 // items[4*t] = job index, items[4*t+1] = band of this round; cell_off[t] / ops_off[t]: where item t's cell bytes

@@ -616,7 +616,8 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
                    const std::string &sequence_id, std::string &bed, unsigned host_threads,
                    const std::vector<RibbitAlignJob> *jobs, const std::vector<SswEnds> *ends, const std::vector<SswPath> *paths,
                    size_t seed_lo, size_t seed_hi, bool *order_dependent, const SmallMotifTable *small,
-                   const uint32_t *job_first_all, const uint8_t *skip, std::vector<BedPiece> *pieces, const std::vector<uint32_t> *only) {
+                   const uint32_t *job_first_all, const uint8_t *skip, std::vector<BedPiece> *pieces, const std::vector<uint32_t> *only,
+                   size_t job_first_given_base) {
     const auto wall0 = std::chrono::steady_clock::now();
     const Bases b(hp, host_threads);
     seed_hi = std::min(seed_hi, dispatch.size());
@@ -628,7 +629,7 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
     std::vector<uint32_t> job_first_own;
     const uint32_t *job_first = nullptr;          // indexed by seed - job_first_base
     size_t job_first_base = 0;
-    if (have_jobs && job_first_all) job_first = job_first_all;
+    if (have_jobs && job_first_all) { job_first = job_first_all; job_first_base = job_first_given_base; }
     else if (have_jobs) {
         const size_t span = seed_hi - seed_lo;
         job_first_own.assign(span + 1, (uint32_t)jobs->size());

@@ -66,9 +66,10 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
                    const std::vector<SswPath> *paths = nullptr, size_t seed_lo = 0, size_t seed_hi = (size_t)-1,
                    bool *order_dependent = nullptr, const SmallMotifTable *small = nullptr,
                    const uint32_t *job_first = nullptr, const uint8_t *skip = nullptr, std::vector<BedPiece> *pieces = nullptr,
-                   const std::vector<uint32_t> *only = nullptr);
-// job_first (optional, with jobs): job_first[i] = first job of dispatch seed i, for i = 0 .. dispatch.size() (else it is worked out
-// from the jobs' seed indices on every call).
+                   const std::vector<uint32_t> *only = nullptr, size_t job_first_base = 0);
+// job_first (optional, with jobs): job_first[i - job_first_base] = first job (index into jobs) of dispatch seed i, for every seed
+// the call refines and the one after it (else it is worked out from the jobs' seed indices on every call).  With a base, `jobs`
+// may hold the jobs of a slice of the seed list only.
 // skip (optional, per dispatch seed): seeds left out of this call (their alignments are not ready); pieces must be given, and the
 // output goes there instead of `bed`, cut at every seed left out.
 // only (optional): refine exactly these seeds (indices into dispatch, increasing), one piece each -- the seeds an earlier call left out.

@@ -219,10 +219,13 @@ __global__ __launch_bounds__(16 * ROWS) void ssw_passes_kernel(const uint8_t *__
 
 void launch_ssw_passes(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs,
                        const int32_t *order_small, int n_small, const int32_t *order_big, int n_big, const int32_t *order_huge, int n_huge,
-                       int mask_len, int32_t *out, hipStream_t stream) {
-    // queries of more than 128 bases: one wavefront per alignment, stripes spread over its lanes (ssw_wave.hip); the
-    // longest first
-    launch_ssw_passes_wave(ascii, length, motif_pool, jobs, order_huge, n_huge, mask_len, SSW_HUGE_Q, SSW_HUGE_R, out, stream);
+                       int mask_len, int32_t *out, hipStream_t stream, int huge_group_waves) {
+    // queries of more than 128 bases: one wavefront per alignment, stripes spread over its lanes (ssw_wave.hip) -- or, for
+    // the huge class, a workgroup per alignment (ssw_group.hip); the longest first
+    if (huge_group_waves && ssw_group_fits(SSW_HUGE_Q, huge_group_waves))
+        launch_ssw_passes_group(ascii, length, motif_pool, jobs, order_huge, n_huge, mask_len, SSW_HUGE_Q, SSW_HUGE_R, huge_group_waves, out, stream);
+    else
+        launch_ssw_passes_wave(ascii, length, motif_pool, jobs, order_huge, n_huge, mask_len, SSW_HUGE_Q, SSW_HUGE_R, out, stream);
     launch_ssw_passes_wave(ascii, length, motif_pool, jobs, order_big, n_big, mask_len, SSW_BIG_Q, SSW_BIG_R, out, stream);
     if (n_small > 0)
         hipLaunchKernelGGL((ssw_passes_kernel<SSW_SMALL_Q, SSW_SMALL_R, 4>), dim3((unsigned)((n_small + 3) / 4)), dim3(64), 0, stream,

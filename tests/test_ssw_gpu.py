@@ -240,6 +240,42 @@ def test_wave_kernel_on_long_queries_of_every_kind():
     _check_whole_alignments(pairs, need_paths=len(pairs) // 2)
 
 
+def test_group_kernel_on_long_queries_of_every_kind():
+    """ssw_group.hip (queries of 513..4096 bases, a workgroup of 4 or 8 wavefronts per alignment, a column's stripes dealt to
+    the wavefronts): what is new there is the carry between wavefronts, the lazy-F loop of the first wavefront running on into
+    stripes the others own, and stripe counts that do not divide by the wavefronts -- so: unrelated long pairs (scores of a few
+    dozen: F is raised again and again), long gaps (a block deleted from / inserted into a repeat: F carries across many
+    stripes), unknown bases, lengths around every multiple that matters, references far shorter and far longer than the query.
+    Passes and whole alignments equal the reference library's."""
+    rs = np.random.RandomState(777)
+    pairs = []
+    lengths = [513, 514, 519, 520, 521, 527, 528, 529, 543, 544, 545, 575, 576, 577, 767, 768, 769, 1000, 1031, 1279, 1280, 1281, 1536, 1537,
+               2047, 2048, 2049, 2050, 2063, 2064, 2065, 2111, 2112, 2113, 2560, 3071, 3072, 3073, 3583, 3584, 3585, 4000, 4031, 4032, 4033, 4080, 4095, 4096]
+    for n in lengths:
+        motif = _rand(rs, int(rs.randint(1, 60)))
+        pure = (motif * (n // len(motif) + 2))[:n]
+        q = _mutate(rs, pure, float(rs.choice([0.0, 0.1, 0.3, 0.45])))[:n]
+        if len(q) > 512:
+            pairs.append((q, motif, min(8192, len(q) + len(motif) + int(0.15 * len(q)))))
+    for n in (600, 900, 1500, 2048, 2100, 3000, 4096):        # unrelated: many lazy-F rounds, on both kernels' widths
+        q = _rand(rs, n, b"ACGTN" if n % 2 else b"ACGT")
+        ref = _rand(rs, int(rs.randint(50, 1200)))
+        pairs.append((q, ref, len(ref)))
+        pairs.append((q, _rand(rs, 7), min(8192, n + 200)))
+    for n in (700, 1800, 2500, 3900):                          # a long gap either way inside a clean repeat
+        motif = _rand(rs, int(rs.randint(3, 30)))
+        pure = (motif * (n // len(motif) + 2))[:n]
+        cut = int(rs.randint(100, n - 300))
+        gap = int(rs.randint(20, 150))
+        pairs.append((pure[:cut] + pure[cut + gap:], motif, min(8192, n + 100)))                    # deletion from the query
+        pairs.append(((pure[:cut] + _rand(rs, gap) + pure[cut:])[:4096], motif, min(8192, n + 100)))  # insertion into it
+    for n in (1000, 2600, 4096):                               # reference far shorter than the query
+        motif = _rand(rs, 5)
+        pairs.append((_mutate(rs, (motif * (n // 5 + 2))[:n], 0.05)[:n], motif, 60))
+    assert _check_batch(pairs) == len(pairs)
+    _check_whole_alignments(pairs, need_paths=1)
+
+
 def test_two_batches_of_different_size_on_one_handle():
     """Regression for a crash of round 2 (feeder thread of ribbit_hip_refine_bed): the path search's result slots are reused
     from batch to batch, and a second, smaller batch read a path-operation count the first batch had left in a slot it did not
