@@ -1,5 +1,10 @@
-import json,sys
-for line in sys.stdin:
+"""One line per bench.py JSON line.  Usage: python tools/show_bench.py FILE [FILE ...]   (or: ... | python tools/show_bench.py -)
+Reads files named on the command line; standard input only when asked for with "-" (a run on the GPU box that waits for
+input that never comes is killed for its silence after seven minutes)."""
+import fileinput,json,sys
+if len(sys.argv) < 2:
+    sys.exit(__doc__)
+for line in fileinput.input(sys.argv[1:]):
     line=line.strip()
     if not line.startswith("{"): continue
     d=json.loads(line)
