@@ -1608,6 +1608,37 @@ __device__ __forceinline__ int diag_matches(const uint8_t *__restrict__ sym, int
     return d;
 }
 
+// The five jittered diagonals of one step, eight symbols at a time: matches[x + 2] = diag_matches(sym, row0, col0 + x, lo, hi,
+// n, 1) for x = -2 .. 2.  A symbol is 0..4, so the bytes of (a ^ b) + 0x7f..7f have bit 7 clear exactly where the symbols are
+// equal (no carry between bytes), and a column symbol is a base where its bit 2 is clear.  The walk of the scalar form ends
+// at the first column outside [lo, hi): for an increasing column that is "none at all if the first is below lo, else the
+// first hi - col0".  Loads run up to 7 bytes past what is counted: sym is padded by 16 bytes, and whatever is there is masked
+// (a carry out of such a byte only reaches bytes further up, which are masked too).
+__device__ __forceinline__ void diag_matches5(const uint8_t *__restrict__ sym, int row0, int col0, int lo, int hi, int n, int (&matches)[5]) {
+    int cnt[5];
+#pragma unroll
+    for (int x = 0; x < 5; ++x) {
+        const int c0 = col0 + x - 2;
+        cnt[x] = c0 < lo ? 0 : max(0, min(n, hi - c0));
+        matches[x] = 0;
+    }
+    const int most = max(max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3])), cnt[4]);
+    for (int i = 0; i < most; i += 8) {
+        uint64_t b;
+        __builtin_memcpy(&b, sym + row0 + i, 8);
+#pragma unroll
+        for (int x = 0; x < 5; ++x) {
+            const int left = cnt[x] - i;
+            if (left <= 0) continue;
+            uint64_t a;
+            __builtin_memcpy(&a, sym + col0 + x - 2 + i, 8);
+            uint64_t eq = ~((a ^ b) + 0x7f7f7f7f7f7f7f7full) & ~(a << 5) & 0x8080808080808080ull;
+            if (left < 8) eq &= (1ull << (8 * left)) - 1ull;
+            matches[x] += __popcll(eq);
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void long_motif_rows_kernel(const uint8_t *__restrict__ sym, int64_t length,
                                                              const int4 *__restrict__ jobs, int64_t njobs,
                                                              const int2 *__restrict__ blocks,
@@ -1623,22 +1654,23 @@ __global__ __launch_bounds__(64) void long_motif_rows_kernel(const uint8_t *__re
     const int row = seed_start + blk.y + (int)threadIdx.x;
     if (row < seed_end - m + 1) {
         int score = 0;
+        int d5[5];
         for (int col = row + m; col < seed_end;) {
             int pick = -2, top = 0;
-            for (int x = -2; x <= 2; ++x) {
-                const int d = diag_matches(sym, row, col + x, INT_MIN, seed_end, m, 1);
-                if (d > top) { top = d; pick = x; }
-            }
+            diag_matches5(sym, row, col, INT_MIN, seed_end, m, d5);
+#pragma unroll
+            for (int x = -2; x <= 2; ++x)
+                if (d5[x + 2] > top) { top = d5[x + 2]; pick = x; }
             score += top;
             col += pick + m;
         }
         int col = row - m;
         for (; col > seed_start;) {
             int pick = -2, top = 0;
-            for (int x = -2; x <= 2; ++x) {
-                const int d = diag_matches(sym, row, col + x, 0, INT_MAX, m, 1);
-                if (d > top) { top = d; pick = x; }
-            }
+            diag_matches5(sym, row, col, 0, INT_MAX, m, d5);
+#pragma unroll
+            for (int x = -2; x <= 2; ++x)
+                if (d5[x + 2] > top) { top = d5[x + 2]; pick = x; }
             score += top;
             col += pick - m;
         }
