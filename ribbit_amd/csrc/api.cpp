@@ -1955,12 +1955,12 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
     h->bed.clear();
     // First-level alignments set up on host threads, the striped passes and the banded path search of all of them in GPU
     // batches, the host then only writes the CIGAR text (whole alignments for oversized jobs and the flank recursion).
-    // Used for LARGE records only, on measurements (refinement, host only against this path with the long
-    // class in two slices): 2 Mbp 83 / 141 ms, 5 Mbp 144 / 204, 10 Mbp 287 / 320, 20 Mbp 528 / 492, chromosome-1 size
-    // 6.7 / 5.4 s -- a fixed cost of about 0.1 s per record, then a gain that grows with the record; and 400 records of
-    // 50 kb with 8 in flight take 2.28 s instead of 1.3-1.45 s with it.  The switch is the number of dispatched seeds
-    // (1.4 M at 20 Mbp); RIBBIT_GPU_SSW=0 / =1 forces it off / on.
-    constexpr size_t GPU_SSW_MIN_SEEDS = 1000000;
+    // Used from a record size on, by measurement (tools/refine_threshold_probe.sh; refinement of one record, host
+    // threads only / this path): 1 Mbp 46 / 79 ms, 2 Mbp 71 / 108, 5 Mbp 148 / 145, 10 Mbp 280 / 173, 20 Mbp 484 / 182,
+    // 40 Mbp 906 / 285 -- about 70 ms fixed (the long batch and a slice's launches, which a small record cannot hide behind
+    // anything), then 5 ms per Mbp against 24 on the host; and 400 records of 50 kb with 8 in flight take 2.28 s instead of
+    // 1.3 s with it.  The switch is the number of dispatched seeds (0.35 M at 5 Mbp); RIBBIT_GPU_SSW=0 / =1 forces it off / on.
+    constexpr size_t GPU_SSW_MIN_SEEDS = 400000;
     static const char *const gpu_ssw_env = std::getenv("RIBBIT_GPU_SSW");
     const bool gpu_ssw = gpu_ssw_env ? std::atoi(gpu_ssw_env) != 0 : h->dispatch.size() >= GPU_SSW_MIN_SEEDS;
     unsigned threads = h->host_threads ? h->host_threads : std::min(std::thread::hardware_concurrency(), 16u);
