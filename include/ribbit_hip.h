@@ -198,7 +198,7 @@ typedef struct RibbitAlignJob {
  * What the two striped passes of an alignment determine (ssw.c:843-891: score, end point, second best score outside
  * the mask window, begin point): everything of StripedSmithWaterman::Alignment except the CIGAR.
  * flag: 0 ok, 2 the reverse pass scored less than the forward pass, -1 not computed (job too large for the
- * GPU kernels: query_length > 4096 or ppr_length > 8192) -- align those with ribbit_ssw_align.
+ * GPU kernels: query_length > 8192 or ppr_length > 16384) -- align those with ribbit_ssw_align.
  */
 typedef struct RibbitSswEnds {
     int32_t score, ref_end, query_end, score2, ref_end2, ref_begin, query_begin, flag;

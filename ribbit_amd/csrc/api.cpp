@@ -1429,20 +1429,21 @@ int ribbit_hip_seed_longest_runs(RibbitHandle *h, const int32_t **out, size_t *n
 
 // forward + reverse striped Smith-Waterman passes of every job in one (two) launches; ends[j].flag == -1 where the
 // job is too large for the kernel's LDS budget (the host aligns those)
-// size class of an alignment job on the GPU: 0 / 1 one DPP row resp. one wavefront with short tails, 2 / 3 the long classes
-// (one wavefront for tens of milliseconds), -1 too large for the kernels (the host aligns it)
+// size class of an alignment job on the GPU: 0 / 1 one DPP row resp. one wavefront with short tails, 2 / 3 / 4 the long classes
+// (a workgroup of 4 / 8 / 16 wavefronts per alignment), -1 too large for the kernels (the host aligns it)
 static int ssw_class(const RibbitAlignJob &jb) {
     if (jb.query_length <= rb::SSW_SMALL_Q && jb.ppr_length <= rb::SSW_SMALL_R) return 0;
     if (jb.query_length <= rb::SSW_BIG_Q && jb.ppr_length <= rb::SSW_BIG_R) return 1;
     if (jb.query_length <= rb::SSW_HUGE_Q && jb.ppr_length <= rb::SSW_HUGE_R) return 2;
     if (jb.query_length <= rb::SSW_GIANT_Q && jb.ppr_length <= rb::SSW_GIANT_R) return 3;
+    if (jb.query_length <= rb::SSW_COLOSSAL_Q && jb.ppr_length <= rb::SSW_COLOSSAL_R) return 4;
     return -1;
 }
 
 // classes: bit c set = jobs of size class c run here (the others keep flag -1).  pool_resident: the motif pool is on the
 // device already (an earlier call of the same record uploaded it).
 static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const char *pool, size_t pool_len, int mask_len,
-                          std::vector<rb::SswEnds> &ends, unsigned classes = 0xfu, bool pool_resident = false) {
+                          std::vector<rb::SswEnds> &ends, unsigned classes = 0x1fu, bool pool_resident = false) {
     static_assert(sizeof(RibbitAlignJob) == 9 * sizeof(int32_t), "job record layout");
     static_assert(sizeof(rb::SswEnds) == 8 * sizeof(int32_t), "ends record layout");
     ends.assign(n, rb::SswEnds{});
@@ -1464,24 +1465,25 @@ static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n,
         return (top - 3) * 16 + (int)((work >> (top - 4)) & 15u);
     };
     std::vector<int32_t> cls_of(n, -1), bkt_of(n, 0);
-    std::vector<uint32_t> count(4 * BUCKETS + 1, 0);                   // slot = class-major, buckets descending
-    size_t class_count[4] = {0, 0, 0, 0};
+    constexpr int NCLS = 5;
+    std::vector<uint32_t> count(NCLS * BUCKETS + 1, 0);                // slot = class-major, buckets descending
+    size_t class_count[NCLS] = {0, 0, 0, 0, 0};
     for (size_t j = 0; j < n; ++j) {
         const RibbitAlignJob &jb = jobs[j];
         const int cls = ssw_class(jb);
         if (cls < 0 || !((classes >> cls) & 1u)) { ends[j].flag = -1; continue; }
-        const uint64_t work = (uint64_t)std::max(jb.query_length, 0) * (uint64_t)std::max(jb.ppr_length, 0);      // < 2^25
+        const uint64_t work = (uint64_t)std::max(jb.query_length, 0) * (uint64_t)std::max(jb.ppr_length, 0);      // < 2^27
         cls_of[j] = cls;
         bkt_of[j] = std::min(bucket_of(work), BUCKETS - 1);
         ++class_count[cls];
-        // order of the list: class 3 first ... class 0 last; inside a class the largest bucket first
-        ++count[(size_t)(3 - cls) * BUCKETS + (size_t)(BUCKETS - 1 - bkt_of[j]) + 1];
+        // order of the list: class 4 first ... class 0 last; inside a class the largest bucket first
+        ++count[(size_t)(NCLS - 1 - cls) * BUCKETS + (size_t)(BUCKETS - 1 - bkt_of[j]) + 1];
     }
     for (size_t k = 1; k < count.size(); ++k) count[k] += count[k - 1];
     std::vector<int32_t> order(count.back());
     for (size_t j = 0; j < n; ++j)
-        if (cls_of[j] >= 0) order[count[(size_t)(3 - cls_of[j]) * BUCKETS + (size_t)(BUCKETS - 1 - bkt_of[j])]++] = (int32_t)j;
-    const size_t n_giant = class_count[3], n_huge = class_count[2], n_big = class_count[1], n_small = class_count[0];
+        if (cls_of[j] >= 0) order[count[(size_t)(NCLS - 1 - cls_of[j]) * BUCKETS + (size_t)(BUCKETS - 1 - bkt_of[j])]++] = (int32_t)j;
+    const size_t n_colossal = class_count[4], n_giant = class_count[3], n_huge = class_count[2], n_big = class_count[1], n_small = class_count[0];
     if (order.empty()) return RIBBIT_OK;
     if ((rc = h->d_ssw_jobs.ensure(n * 9))) return rc;
     if ((rc = h->d_ssw_out.ensure(n * 8))) return rc;
@@ -1494,23 +1496,31 @@ static int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n,
     // The two long classes run a workgroup per alignment (ssw_group.hip: 8 wavefronts for the giant class, 4 for the huge one)
     // unless RIBBIT_SSW_GROUP=0 asks for the older one-wavefront-per-alignment kernel (kept for comparison: same results).
     static const bool group_kernels = !(std::getenv("RIBBIT_SSW_GROUP") && std::atoi(std::getenv("RIBBIT_SSW_GROUP")) == 0);
-    if (n_giant) {
+    const size_t n_apart = n_colossal + n_giant;      // on the copy stream beside the others
+    if (n_apart) {
         HIP_TRY(hipEventRecord(h->ev_ssw, h->stream));
         HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->ev_ssw, 0));
-        if (group_kernels && rb::ssw_group_fits(rb::SSW_GIANT_Q, 8))
-            rb::launch_ssw_passes_group(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_order.p, (int)n_giant, mask_len,
-                                        rb::SSW_GIANT_Q, rb::SSW_GIANT_R, 8, h->d_ssw_out.p, h->copy_stream);
-        else
-        rb::launch_ssw_passes_wave(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_order.p, (int)n_giant, mask_len,
-                                   rb::SSW_GIANT_Q, rb::SSW_GIANT_R, h->d_ssw_out.p, h->copy_stream);
+        // queries of 4097..8192 bases: only as a workgroup (16 wavefronts, 124 KB of LDS); with the group kernels off they are
+        // the host's, as until the end of round 3
+        if (n_colossal && group_kernels && rb::ssw_group_fits(rb::SSW_COLOSSAL_Q, 16))
+            HIP_TRY(rb::launch_ssw_passes_group(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_order.p, (int)n_colossal, mask_len,
+                                                rb::SSW_COLOSSAL_Q, rb::SSW_COLOSSAL_R, 16, h->d_ssw_out.p, h->copy_stream));
+        if (n_giant) {
+            if (group_kernels && rb::ssw_group_fits(rb::SSW_GIANT_Q, 8))
+                HIP_TRY(rb::launch_ssw_passes_group(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_order.p + n_colossal, (int)n_giant, mask_len,
+                                                    rb::SSW_GIANT_Q, rb::SSW_GIANT_R, 8, h->d_ssw_out.p, h->copy_stream));
+            else
+                rb::launch_ssw_passes_wave(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_order.p + n_colossal, (int)n_giant, mask_len,
+                                           rb::SSW_GIANT_Q, rb::SSW_GIANT_R, h->d_ssw_out.p, h->copy_stream);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->ev_ssw, h->copy_stream));
     }
-    const int32_t *rest = h->d_ssw_order.p + n_giant;
+    const int32_t *rest = h->d_ssw_order.p + n_apart;
     rb::launch_ssw_passes(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, rest + n_huge + n_big, (int)n_small,
                           rest + n_huge, (int)n_big, rest, (int)n_huge, mask_len, h->d_ssw_out.p, h->stream, group_kernels ? 4 : 0);
     HIP_TRY(hipGetLastError());
-    if (n_giant) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_ssw, 0));
+    if (n_apart) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_ssw, 0));
     HIP_TRY(hipMemcpyAsync(ends.data(), h->d_ssw_out.p, n * sizeof(rb::SswEnds), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return RIBBIT_OK;
@@ -2045,7 +2055,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             long_thread = std::thread([&, aux]() {
                 const double tl0 = now_ms();
                 try {
-                    long_rc = run_ssw_passes(aux, long_jobs.data(), long_jobs.size(), long_pool.data(), long_pool.size(), 15, long_ends, 0xcu);
+                    long_rc = run_ssw_passes(aux, long_jobs.data(), long_jobs.size(), long_pool.data(), long_pool.size(), 15, long_ends, 0x1cu);
                     if (!long_rc) long_rc = run_ssw_paths(aux, long_jobs.data(), long_jobs.size(), long_ends, long_paths);
                     if (!long_rc) {
                         size_t n_ops = 0;
@@ -2063,7 +2073,8 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         std::vector<rb::BedPiece> later_pieces;
         bool later_order_dependent = false, later_done = false;
         double t_later_thread = 0;
-        // seeds with a job beyond the kernels' reach (queries over 4096 bases: 5-60 ms of host alignment each) need nothing from
+        // seeds with a job beyond the kernels' reach (queries over 8192 bases; over 4096 until the end of round 3: 5-60 ms of host
+        // alignment each) need nothing from
         // the GPU: they are refined on a few host threads from the start, beside everything else, instead of as a tail
         if (!giants.empty())
             later_thread = std::thread([&]() {

@@ -164,15 +164,17 @@ void launch_long_motif_rows(const uint8_t *sym, int64_t length, const void *jobs
 // three size classes (order_small / order_big / order_huge: job indices, each list sorted by size); out[8*job .. +8) = score,
 // ref_end, query_end, score2, ref_end2, ref_begin, query_begin, flag -- flag -1: too large for its class, not computed.
 constexpr int SSW_SMALL_Q = 128, SSW_SMALL_R = 256, SSW_BIG_Q = 512, SSW_BIG_R = 1024, SSW_HUGE_Q = 2048, SSW_HUGE_R = 4096,
-              SSW_GIANT_Q = 4096, SSW_GIANT_R = 8192;      // 61.6 KB of LDS per alignment: the most one workgroup gets by default
+              SSW_GIANT_Q = 4096, SSW_GIANT_R = 8192,      // 61.6 KB of LDS per alignment: the most one workgroup gets by default
+              SSW_COLOSSAL_Q = 8192, SSW_COLOSSAL_R = 16384;    // 124 KB: asked for with hipFuncAttributeMaxDynamicSharedMemorySize (a
+                                                                // workgroup may have all 160 KB of a CU: tools/probes/lds_probe.hip)
 // ssw_wave.hip: the same two passes, one wavefront per alignment (queries of 129..qcap bases, reference up to rcap)
 void launch_ssw_passes_wave(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs, const int32_t *order, int n,
                             int mask_len, int qcap, int rcap, int32_t *out, hipStream_t stream);
-// ssw_group.hip: the same two passes, one WORKGROUP of `waves` (4 or 8) wavefronts per alignment: a column's stripes dealt to
+// ssw_group.hip: the same two passes, one WORKGROUP of `waves` (4, 8 or 16) wavefronts per alignment: a column's stripes dealt to
 // the wavefronts, for the long classes.  ssw_group_fits: the class's longest query fits that many wavefronts.
 bool ssw_group_fits(int qcap, int waves);
-void launch_ssw_passes_group(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs, const int32_t *order, int n,
-                             int mask_len, int qcap, int rcap, int waves, int32_t *out, hipStream_t stream);
+hipError_t launch_ssw_passes_group(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs, const int32_t *order, int n,
+                                   int mask_len, int qcap, int rcap, int waves, int32_t *out, hipStream_t stream);
 void launch_ssw_passes(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs,
                        const int32_t *order_small, int n_small, const int32_t *order_big, int n_big, const int32_t *order_huge, int n_huge,
                        int mask_len, int32_t *out, hipStream_t stream, int huge_group_waves = 0);

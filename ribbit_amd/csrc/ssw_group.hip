@@ -7,7 +7,7 @@
 // stripes walked G at a time ("chunks").  A query of 4096 bases has 64 chunks per column, each a round trip through LDS, and
 // one such alignment keeps its wavefront for 40-160 ms while its 50-60 KB of LDS keep all but three wavefronts off the CU: a
 // record's long alignments (a few thousand) were the longest single step of its refinement.  Here the chunks of a column are
-// dealt to the T wavefronts of a workgroup (wavefront w: chunks w*C .. w*C+C-1, C = ceil(chunks / T) <= 8, unrolled, so that a
+// dealt to the T wavefronts of a workgroup (T = 4, 8 or 16 by query length; wavefront w: chunks w*C .. w*C+C-1, C = ceil(chunks / T) <= 8, unrolled, so that a
 // wavefront's LDS reads are in flight together), on the same LDS footprint:
 //   1. every wavefront forms g, E and the prefix term b of its stripes (ssw_wave.hip's closed form of the main loop) and the
 //      prefix maximum INSIDE its own chunks; its total per register lane goes to LDS;                          [barrier]
@@ -308,15 +308,23 @@ size_t group_lds_bytes(int qcap, int rcap) {
 // (byte: q/16 stripes in chunks of 4; word: q/8 stripes in chunks of 8)
 bool ssw_group_fits(int qcap, int waves) { return ((qcap + 7) / 8 + 7) / 8 <= waves * MAXC; }
 
-void launch_ssw_passes_group(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs, const int32_t *order, int n,
-                             int mask_len, int qcap, int rcap, int waves, int32_t *out, hipStream_t stream) {
-    if (n <= 0) return;
-    if (waves == 8)
+hipError_t launch_ssw_passes_group(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs, const int32_t *order, int n,
+                                   int mask_len, int qcap, int rcap, int waves, int32_t *out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    if (waves == 16) {
+        // the largest class needs more LDS than a workgroup gets without asking (64 KB); a CU has 160 KB
+        const size_t lds = group_lds_bytes<16>(qcap, rcap);
+        const hipError_t e = hipFuncSetAttribute((const void *)ssw_passes_group_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(ssw_passes_group_kernel<16>, dim3((unsigned)n), dim3(1024), lds, stream, ascii, length, motif_pool, jobs,
+                           order, n, mask_len, qcap, rcap, out);
+    } else if (waves == 8)
         hipLaunchKernelGGL(ssw_passes_group_kernel<8>, dim3((unsigned)n), dim3(512), group_lds_bytes<8>(qcap, rcap), stream, ascii, length, motif_pool, jobs,
                            order, n, mask_len, qcap, rcap, out);
     else
         hipLaunchKernelGGL(ssw_passes_group_kernel<4>, dim3((unsigned)n), dim3(256), group_lds_bytes<4>(qcap, rcap), stream, ascii, length, motif_pool, jobs,
                            order, n, mask_len, qcap, rcap, out);
+    return hipGetLastError();
 }
 
 }  // namespace rb

@@ -223,7 +223,7 @@ void launch_ssw_passes(const uint8_t *ascii, int64_t length, const uint8_t *moti
     // queries of more than 128 bases: one wavefront per alignment, stripes spread over its lanes (ssw_wave.hip) -- or, for
     // the huge class, a workgroup per alignment (ssw_group.hip); the longest first
     if (huge_group_waves && ssw_group_fits(SSW_HUGE_Q, huge_group_waves))
-        launch_ssw_passes_group(ascii, length, motif_pool, jobs, order_huge, n_huge, mask_len, SSW_HUGE_Q, SSW_HUGE_R, huge_group_waves, out, stream);
+        (void)launch_ssw_passes_group(ascii, length, motif_pool, jobs, order_huge, n_huge, mask_len, SSW_HUGE_Q, SSW_HUGE_R, huge_group_waves, out, stream);      // (the caller checks hipGetLastError)
     else
         launch_ssw_passes_wave(ascii, length, motif_pool, jobs, order_huge, n_huge, mask_len, SSW_HUGE_Q, SSW_HUGE_R, out, stream);
     launch_ssw_passes_wave(ascii, length, motif_pool, jobs, order_big, n_big, mask_len, SSW_BIG_Q, SSW_BIG_R, out, stream);

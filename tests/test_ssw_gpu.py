@@ -34,7 +34,7 @@ def _check_batch(pairs, mask_len=15):
     n_gpu = 0
     for k, (query, motif, ppr_len) in enumerate(pairs):
         if got[k]["flag"] == -1:
-            assert len(query) > 4096 or ppr_len > 8192, (k, len(query), ppr_len)
+            assert len(query) > 8192 or ppr_len > 16384, (k, len(query), ppr_len)
             continue
         n_gpu += 1
         ref = motif * (ppr_len // len(motif) + 2)
@@ -79,13 +79,14 @@ def test_random_pairs_and_unknown_bases_match_reference_library():
 def test_long_alignments_take_the_16bit_path_and_oversized_jobs_are_left_to_the_host():
     rs = np.random.RandomState(7)
     pairs = []
-    for n in (130, 140, 200, 300, 400, 500, 512, 513, 600, 1500, 2048, 2049, 2500, 4096, 4097, 5000):
+    for n in (130, 140, 200, 300, 400, 500, 512, 513, 600, 1500, 2048, 2049, 2500, 4096, 4097, 5000, 8192, 8193, 9000):
         motif = _rand(rs, int(rs.randint(2, 12)))
         pure = (motif * (n // len(motif) + 2))[:n]
         query = _mutate(rs, pure, 0.05)[:n]
         pairs.append((query, motif, len(query) + len(motif) + int(0.15 * len(query))))
     n_gpu = _check_batch(pairs)
-    assert len(pairs) - 3 <= n_gpu < len(pairs)
+    fits = sum(1 for q, _, ppr in pairs if len(q) <= 8192 and ppr <= 16384)      # (a mutated query may be shorter than asked for)
+    assert n_gpu == fits and fits < len(pairs)      # the query of 9000 bases is the host's
 
 
 def test_mask_length_below_15_disables_the_second_best():
@@ -241,7 +242,7 @@ def test_wave_kernel_on_long_queries_of_every_kind():
 
 
 def test_group_kernel_on_long_queries_of_every_kind():
-    """ssw_group.hip (queries of 513..4096 bases, a workgroup of 4 or 8 wavefronts per alignment, a column's stripes dealt to
+    """ssw_group.hip (queries of 513..8192 bases, a workgroup of 4, 8 or 16 wavefronts per alignment, a column's stripes dealt to
     the wavefronts): what is new there is the carry between wavefronts, the lazy-F loop of the first wavefront running on into
     stripes the others own, and stripe counts that do not divide by the wavefronts -- so: unrelated long pairs (scores of a few
     dozen: F is raised again and again), long gaps (a block deleted from / inserted into a repeat: F carries across many
@@ -250,26 +251,27 @@ def test_group_kernel_on_long_queries_of_every_kind():
     rs = np.random.RandomState(777)
     pairs = []
     lengths = [513, 514, 519, 520, 521, 527, 528, 529, 543, 544, 545, 575, 576, 577, 767, 768, 769, 1000, 1031, 1279, 1280, 1281, 1536, 1537,
-               2047, 2048, 2049, 2050, 2063, 2064, 2065, 2111, 2112, 2113, 2560, 3071, 3072, 3073, 3583, 3584, 3585, 4000, 4031, 4032, 4033, 4080, 4095, 4096]
+               2047, 2048, 2049, 2050, 2063, 2064, 2065, 2111, 2112, 2113, 2560, 3071, 3072, 3073, 3583, 3584, 3585, 4000, 4031, 4032, 4033, 4080, 4095, 4096,
+               4097, 4100, 4111, 4112, 4113, 4608, 5000, 6143, 6144, 6145, 7000, 8063, 8064, 8065, 8190, 8191, 8192]      # 16 wavefronts, 124 KB of LDS
     for n in lengths:
         motif = _rand(rs, int(rs.randint(1, 60)))
         pure = (motif * (n // len(motif) + 2))[:n]
         q = _mutate(rs, pure, float(rs.choice([0.0, 0.1, 0.3, 0.45])))[:n]
         if len(q) > 512:
-            pairs.append((q, motif, min(8192, len(q) + len(motif) + int(0.15 * len(q)))))
-    for n in (600, 900, 1500, 2048, 2100, 3000, 4096):        # unrelated: many lazy-F rounds, on both kernels' widths
+            pairs.append((q, motif, min(16384, len(q) + len(motif) + int(0.15 * len(q)))))
+    for n in (600, 900, 1500, 2048, 2100, 3000, 4096, 5001, 8192):        # unrelated: many lazy-F rounds, on all three widths
         q = _rand(rs, n, b"ACGTN" if n % 2 else b"ACGT")
         ref = _rand(rs, int(rs.randint(50, 1200)))
         pairs.append((q, ref, len(ref)))
-        pairs.append((q, _rand(rs, 7), min(8192, n + 200)))
-    for n in (700, 1800, 2500, 3900):                          # a long gap either way inside a clean repeat
+        pairs.append((q, _rand(rs, 7), min(16384, n + 200)))
+    for n in (700, 1800, 2500, 3900, 6000, 8000):              # a long gap either way inside a clean repeat
         motif = _rand(rs, int(rs.randint(3, 30)))
         pure = (motif * (n // len(motif) + 2))[:n]
         cut = int(rs.randint(100, n - 300))
         gap = int(rs.randint(20, 150))
-        pairs.append((pure[:cut] + pure[cut + gap:], motif, min(8192, n + 100)))                    # deletion from the query
-        pairs.append(((pure[:cut] + _rand(rs, gap) + pure[cut:])[:4096], motif, min(8192, n + 100)))  # insertion into it
-    for n in (1000, 2600, 4096):                               # reference far shorter than the query
+        pairs.append((pure[:cut] + pure[cut + gap:], motif, min(16384, n + 100)))                   # deletion from the query
+        pairs.append(((pure[:cut] + _rand(rs, gap) + pure[cut:])[:8192], motif, min(16384, n + 100)))  # insertion into it
+    for n in (1000, 2600, 4096, 8192):                         # reference far shorter than the query
         motif = _rand(rs, 5)
         pairs.append((_mutate(rs, (motif * (n // 5 + 2))[:n], 0.05)[:n], motif, 60))
     assert _check_batch(pairs) == len(pairs)
