@@ -214,18 +214,22 @@ def chr1_full_path(ribbit_amd, bases: int, device: int, traffic: dict):
         sc.scan_perfect_runs()
         kern["scan_perfect_kernel"] = sc.timing_ms(1)
         # refinement of the lists just made (the perfect re-scan above does not touch them)
+        # (the text as the C ABI returns it, by pointer: what ribbit-hip writes to its output file; the Python mirror's copy and
+        # decoding of 150 MB into a str is not the path's, like the seed lists above)
         t3 = time.perf_counter()
-        bed = sc.refine_bed("chr1")
+        bed = sc.refine_bed_view("chr1")
         t4 = time.perf_counter()
+        bed_rows = int(np.count_nonzero(bed == ord("\n")))
+        del bed
     scans = passes[1]["scans_and_merges_s"]
     out.update({
         "passes": passes, "kernel_ms": kern, "scans_and_merges_s": scans, "refinement_and_bed_s": t4 - t3,
         "seconds": scans + (t4 - t3), "value": bases / (scans + (t4 - t3)) / 1e9, "unit": "Gbases/s",
         "scans_and_merges_gbases_per_s": bases / scans / 1e9,
         "seeds": {"perfect": n_lists[0], "substitution": n_lists[1], "anchored": n_lists[2]},
-        "dispatched": n_lists[3], "bed_rows": bed.count("\n"),
+        "dispatched": n_lists[3], "bed_rows": bed_rows,
         "what": "one chromosome-1-sized record, -m 2 -M 100: FASTA record in page-locked memory -> BED text (pass 2 of the scans and "
-                "merges; pass 1, with every allocation, is listed too); the seed lists are taken as the C ABI returns them, by pointer"})
+                "merges; pass 1, with every allocation, is listed too); the seed lists and the BED text are taken as the C ABI returns them, by pointer"})
     roof = {}
     for name, key in (("scan_window_kernel<1>", "scan_window_kernel"), ("scan_anchored_kernel", "scan_anchored_kernel"), ("scan_perfect_kernel", None)):
         # "scan_anchored_kernel": the anchored stage's scan, i.e. its planes kernel and the window scan of the planes together

@@ -707,6 +707,20 @@ class Scanner:
         self._check(self._L.ribbit_hip_refine_bed(self._h, C.byref(rp), sequence_id.encode(), C.byref(text), C.byref(n)))
         return C.string_at(text.value, n.value).decode()
 
+    def refine_bed_view(self, sequence_id: str = "seq", refine_params=None) -> np.ndarray:
+        """The same BED text as the C ABI hands it out: a uint8 view of the library's buffer (valid until the handle's next
+        refine_bed call or its close), without the copy and the decoding into a Python string that refine_bed adds -- 150 MB
+        twice over for a chromosome, which a C caller (ribbit-hip writes the buffer straight to its output file) never pays."""
+        rp = refine_params
+        if rp is None:
+            rp = RefineParams()
+            self._L.ribbit_refine_params_default(C.byref(rp), self.params.min_motif, self.params.max_motif)
+        text, n = C.c_void_p(), C.c_size_t()
+        self._check(self._L.ribbit_hip_refine_bed(self._h, C.byref(rp), sequence_id.encode(), C.byref(text), C.byref(n)))
+        if not n.value:
+            return np.zeros(0, dtype=np.uint8)
+        return np.ctypeslib.as_array(C.cast(text.value, C.POINTER(C.c_uint8)), shape=(n.value,))
+
     def guard_hits(self) -> int:
         return int(self._L.ribbit_hip_guard_hits(self._h))
 

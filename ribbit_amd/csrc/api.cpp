@@ -2107,9 +2107,9 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             std::vector<rb::SswEnds> ends;
             std::vector<rb::SswPath> paths;
             std::vector<uint32_t> ops;
-            int rc = RIBBIT_OK;
+            int rc = RIBBIT_OK, table_rc = RIBBIT_OK;      // rc: the feeder's; table_rc: the table maker's (folded into rc by the feeder)
             std::string error;
-            bool built = false, ready = false;
+            bool built = false, tabled = false, ready = false;
             double t_passes = 0, t_paths = 0, t_feed = 0;
         };
         std::vector<Slice> slices(n_slices);
@@ -2127,22 +2127,28 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         // test's arithmetic, not in the result -- its seed is aligned on the host at the end
         std::vector<uint32_t> stragglers;
         size_t n_jobs = 0;
+        rb::build_align_jobs_join_ms(true);
         auto build_slice = [&](size_t c) {
             Slice &sl = slices[c];
             rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sl.jobs, sl.pool, threads, sl.lo, sl.hi, &small);
+            n_jobs += sl.jobs.size();
+        };
+        // a slice's tables: first job of every seed, the results' places, the safety net.  Needed when its batch has landed, not
+        // before: made by a helper thread of their own, neither between two slices' set-ups on the main thread (56 ms of the
+        // set-up's 400 at chromosome-1 size) nor by the feeder (whose slices the workers then waited for)
+        auto slice_tables = [&](Slice &sl) {
             const size_t nj = sl.jobs.size(), span = sl.hi - sl.lo;
             sl.job_first.assign(span + 1, (uint32_t)nj);
             for (size_t j = nj; j-- > 0;) sl.job_first[(size_t)sl.jobs[j].seed_index - sl.lo] = (uint32_t)j;
             for (size_t i = span; i-- > 0;) sl.job_first[i] = std::min(sl.job_first[i], sl.job_first[i + 1]);
             for (size_t j = 0; j < nj; ++j) {
                 const int cls = ssw_class(sl.jobs[j]);
-                uint8_t &mark = set_aside[(size_t)sl.jobs[j].seed_index];      // (no worker reads this slice's marks before it is refined)
+                uint8_t &mark = set_aside[(size_t)sl.jobs[j].seed_index];      // (no worker reads this slice's marks before it is ready)
                 if ((cls < 0 || cls >= 2) && mark == 0) { mark = 3; stragglers.push_back((uint32_t)sl.jobs[j].seed_index); }
             }
             sl.ends.assign(nj, rb::SswEnds{});
             for (rb::SswEnds &e : sl.ends) e.flag = -1;
             sl.paths.assign(nj, rb::SswPath{});
-            n_jobs += nj;
         };
         auto feed = [&](size_t c) {
             Slice &sl = slices[c];
@@ -2156,6 +2162,8 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                                                      : run_ssw_passes(h, sl.jobs.data(), nj, sl.pool.data(), sl.pool.size(), 15, e, 0x3u);
                 const double tq = now_ms();
                 if (!sl.rc) sl.rc = run_ssw_paths(h, sl.jobs.data(), nj, e, pth);
+                { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return sl.tabled || stop.load(); }); if (!sl.tabled) return; }
+                if (!sl.rc && sl.table_rc) { sl.rc = fail(sl.table_rc, "out of host memory while making a slice's tables"); }
                 if (!sl.rc) {
                     // the paths point into the handle's pinned buffer, which the next slice overwrites
                     size_t n_ops = 0;
@@ -2178,6 +2186,17 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             sl.t_feed = now_ms() - tf0;
         };
         if ((rc = bind_device(h))) return rc;
+        std::thread tabler;
+        struct TablerGuard { std::atomic<bool> &stop; std::condition_variable &cv; std::thread &t; ~TablerGuard() { stop = true; cv.notify_all(); if (t.joinable()) t.join(); } } tabler_guard{stop, cv, tabler};
+        tabler = std::thread([&]() {
+            for (size_t c = 0; c < n_slices; ++c) {
+                { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return slices[c].built || stop.load(); }); if (!slices[c].built) return; }
+                try { slice_tables(slices[c]); }
+                catch (const std::bad_alloc &) { slices[c].table_rc = RIBBIT_E_NOMEM; }      // (published with `tabled`, under the mutex, below)
+                { std::lock_guard<std::mutex> lk(mu); slices[c].tabled = true; }
+                cv.notify_all();
+            }
+        });
         feeder = std::thread([&]() {
             for (size_t c = 0; c < n_slices && !stop; ++c) {
                 { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return slices[c].built || stop.load(); }); if (!slices[c].built) break; }
@@ -2195,6 +2214,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             cv.notify_all();
         }
         const double t_setup = now_ms() - t_setup0;
+        const double t_setup_join = rb::build_align_jobs_join_ms(true);
         bool order_dependent = false;
         double t_wait = 0, t_passes = 0, t_paths = 0, t_feed = 0, t_work = 0, t_later = 0, t_join = 0;
         std::vector<rb::BedPiece> pieces;
@@ -2255,9 +2275,14 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                     lp.insert(lp.end(), sl.paths.begin() + (long)ja, sl.paths.begin() + (long)jb);
                     lfirst[i + 1] = (uint32_t)lj.size();
                 }
+                // the longest first: a seed of these costs anything from microseconds to tens of milliseconds (digestion of a long
+                // alignment, flank recursion on the host), and the call ends with its last seed
+                std::vector<uint32_t> by_cost(later);
+                std::stable_sort(by_cost.begin(), by_cost.end(), [&](uint32_t x, uint32_t y) {
+                    return h->dispatch[x].end - h->dispatch[x].start > h->dispatch[y].end - h->dispatch[y].start; });
                 rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
                                   sequence_id, h->bed, h->host_threads, &lj, &le, &lp, 0, n_seeds, &order_dependent, &small, lfirst.data(), nullptr,
-                                  &pieces, &later);
+                                  &pieces, &by_cost);
             }
             if (!stragglers.empty())
                 rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
@@ -2282,11 +2307,11 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             for (const rb::BedPiece &pc : pieces) h->bed += pc.text;
         } else h->bed.clear();                         // an empty query somewhere (or no batches): the whole record in one call (below)
         t_join = now_ms() - tj0;
-        if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs (%zu long ones in their own batch: %.1f ms, set up first in %.1f ms; %zu seeds set aside), set-up in all %.1f ms; %zu slices: "
+        if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs (%zu long ones in their own batch: %.1f ms, set up first in %.1f ms; %zu seeds set aside), set-up in all %.1f ms (of it joining the chunks' jobs %.1f ms); %zu slices: "
                                   "feeder %.1f ms in all (GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms); workers: %.1f ms in their calls, waited %.1f ms "
                                   "for slices, %.1f ms for the long batch; seeds set aside for it %.1f ms; %zu seeds with jobs beyond the kernels' reach refined on the host beside all that in %.1f ms; "
                                   "rows put together %.1f ms; since the call began %.1f ms\n",
-                                  n_jobs, long_jobs.size(), t_long, t_setup_long, later.size(), t_setup, n_slices, t_feed, t_passes, t_paths, t_work, t_wait, t_wait_long, t_later, giants.size(), t_later_thread, t_join,
+                                  n_jobs, long_jobs.size(), t_long, t_setup_long, later.size(), t_setup, t_setup_join, n_slices, t_feed, t_passes, t_paths, t_work, t_wait, t_wait_long, t_later, giants.size(), t_later_thread, t_join,
                                   now_ms() - t_begin);
         add_ms(t_jobs_us, t_wait + t_wait_long);
     }

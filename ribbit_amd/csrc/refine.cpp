@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <atomic>
 #include <sstream>
+#include <cstring>
 #include <thread>
 #include <unordered_map>
 
@@ -246,6 +247,7 @@ int usable_length_host(const HostPlanes &hp, int start, int end, int m) {
 }
 
 namespace {
+thread_local double tl_build_join_ms = 0.0;      // profile: joining the chunks' jobs and pools, on the calling thread (sequential)
 void build_align_jobs_range(const Bases &b, const RibbitRefineParams &prm, const SeedVec &dispatch,
                             const int32_t *longest_runs, const int32_t *best_rows, size_t lo, size_t hi,
                             std::vector<RibbitAlignJob> &jobs, std::string &motif_pool, const SmallMotifTable *small) {
@@ -316,12 +318,29 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
                 build_align_jobs_range(b, prm, dispatch, longest_runs, best_rows, seed_lo + c * chunk, seed_lo + std::min(n, (c + 1) * chunk), part_jobs[c], part_pool[c], small);
         });
     for (std::thread &th : pool) th.join();
-    for (size_t c = 0; c < nchunks; ++c) {
-        const int32_t base = (int32_t)motif_pool.size();
-        for (RibbitAlignJob &j : part_jobs[c]) { j.motif_offset += base; jobs.push_back(j); }
-        motif_pool += part_pool[c];
-    }
+    // the chunks' jobs and motif strings into place, on the threads again (one thread did this for a fifth of the set-up's time)
+    const auto tj0 = std::chrono::steady_clock::now();
+    std::vector<size_t> job_at(nchunks + 1, 0), pool_at(nchunks + 1, 0);
+    for (size_t c = 0; c < nchunks; ++c) { job_at[c + 1] = job_at[c] + part_jobs[c].size(); pool_at[c + 1] = pool_at[c] + part_pool[c].size(); }
+    jobs.resize(job_at[nchunks]);
+    motif_pool.resize(pool_at[nchunks]);
+    next = 0;
+    auto place = [&]() {
+        for (size_t c; (c = next.fetch_add(1)) < nchunks;) {
+            RibbitAlignJob *out = jobs.data() + job_at[c];
+            const int32_t base = (int32_t)pool_at[c];
+            for (size_t k = 0; k < part_jobs[c].size(); ++k) { out[k] = part_jobs[c][k]; out[k].motif_offset += base; }
+            if (!part_pool[c].empty()) std::memcpy(&motif_pool[pool_at[c]], part_pool[c].data(), part_pool[c].size());
+        }
+    };
+    pool.clear();
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(place);
+    place();
+    for (std::thread &th : pool) th.join();
+    tl_build_join_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj0).count();
 }
+
+double build_align_jobs_join_ms(bool reset) { const double v = tl_build_join_ms; if (reset) tl_build_join_ms = 0.0; return v; }
 
 void build_align_jobs_of(const HostPlanes &hp, const RibbitRefineParams &prm, const SeedVec &dispatch, const int32_t *longest_runs,
                          const int32_t *best_rows, const std::vector<uint32_t> &which, std::vector<RibbitAlignJob> &jobs, std::string &motif_pool,

@@ -35,6 +35,8 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
                       const SmallMotifTable *small = nullptr);
 // (seed_lo, seed_hi: only the seeds dispatch[seed_lo .. seed_hi); job.seed_index stays an index into dispatch)
 // The same for the listed seeds only (increasing indices into dispatch); a seed's jobs are the same, in the same order, as in any other call
+// profile: milliseconds the calling thread's build_align_jobs calls spent joining their chunks' results (sequential part)
+double build_align_jobs_join_ms(bool reset);
 void build_align_jobs_of(const HostPlanes &hp, const RibbitRefineParams &prm, const SeedVec &dispatch, const int32_t *longest_runs,
                          const int32_t *best_rows, const std::vector<uint32_t> &which, std::vector<RibbitAlignJob> &jobs, std::string &motif_pool,
                          unsigned host_threads, const SmallMotifTable *small);
@@ -72,7 +74,8 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
 // may hold the jobs of a slice of the seed list only.
 // skip (optional, per dispatch seed): seeds left out of this call (their alignments are not ready); pieces must be given, and the
 // output goes there instead of `bed`, cut at every seed left out.
-// only (optional): refine exactly these seeds (indices into dispatch, increasing), one piece each -- the seeds an earlier call left out.
+// only (optional): refine exactly these seeds (indices into dispatch, in the order they are to be started: a piece carries its
+// seed's index, so any order gives the same pieces), one piece each -- the seeds an earlier call left out.
 // seed_lo, seed_hi: refine the seeds dispatch[seed_lo .. seed_hi) only (jobs, if given, are those of that range).
 // order_dependent (optional): a slice cannot resolve the one order dependence between seeds (an empty query sees the
 // previous seed's CIGAR) on its own; when it meets one it appends nothing, sets the flag and the caller redoes the

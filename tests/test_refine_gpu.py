@@ -93,3 +93,19 @@ def test_substitution_rich_seed_of_a_ten_base_motif():
         for f in ("seed_index", "atomicity", "query_start", "query_length", "ppr_length", "small"):
             assert np.array_equal(gjobs[f], wjobs[f]), f
         assert sc.refine_bed("s") == o.refine_bed("s")
+
+
+@pytest.mark.gpu
+def test_bed_view_is_the_same_text_without_the_copy():
+    """Scanner.refine_bed_view: the library's buffer as a uint8 view (what bench.py's whole-path leg times, and what ribbit-hip
+    writes to its output file) holds exactly the text refine_bed returns as a str"""
+    from ribbit_amd.simulate import simulate_sequence
+    seq, _ = simulate_sequence(300_000, 11, 2, 40)
+    with ribbit_amd.Scanner(2, 40) as sc:
+        sc.load_record(seq)
+        text = sc.refine_bed("v")
+        view = sc.refine_bed_view("v")
+        assert view.dtype == np.uint8 and view.tobytes() == text.encode() and text.count("\n") > 100
+    with ribbit_amd.Scanner(2, 6) as sc:
+        sc.load_record(b"ACGTTGCA" * 3)
+        assert len(sc.refine_bed_view("none")) == len(sc.refine_bed("none"))
