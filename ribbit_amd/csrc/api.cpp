@@ -213,6 +213,7 @@ struct RibbitHandle {
     int stage_done = STAGE_NONE;          // how far the seed lists have been advanced
     rb::SeedLists lists;
     RibbitHandle *aux = nullptr;          // helper handle of ribbit_hip_refine_bed: streams and buffers of the long alignment batch
+    RibbitHandle *aux2 = nullptr;         // ... and of its second feeder (every other slice of the short alignments)
     RibbitAlignBatcher *batcher = nullptr;    // shared alignment batches of the records in flight (ribbit_hip_set_batcher)
 
     rb::DevicePlanes planes() const {
@@ -1228,6 +1229,7 @@ int ribbit_hip_open(const RibbitScanParams *params, int device, RibbitHandle **o
 int ribbit_hip_close(RibbitHandle *h) {
     if (!h) return RIBBIT_OK;
     if (h->aux) { (void)ribbit_hip_close(h->aux); h->aux = nullptr; }
+    if (h->aux2) { (void)ribbit_hip_close(h->aux2); h->aux2 = nullptr; }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
@@ -2041,7 +2043,6 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         std::mutex mu;
         std::condition_variable cv;
         std::atomic<bool> stop{false};
-        bool feeder_finished = false;
         std::thread long_thread, later_thread, feeder;
         struct JoinGuard {
             std::atomic<bool> &stop; std::condition_variable &cv; std::thread &a, &b, &c;
@@ -2150,7 +2151,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             for (rb::SswEnds &e : sl.ends) e.flag = -1;
             sl.paths.assign(nj, rb::SswPath{});
         };
-        auto feed = [&](size_t c) {
+        auto feed = [&](size_t c, RibbitHandle *fh) {
             Slice &sl = slices[c];
             const double tf0 = now_ms();
             try {
@@ -2159,21 +2160,21 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                 std::vector<rb::SswEnds> e;
                 std::vector<rb::SswPath> pth;
                 sl.rc = (fail_later_slices && c > 0) ? fail(RIBBIT_E_NOMEM, "forced by RIBBIT_DEBUG_FAIL_BATCHES")
-                                                     : run_ssw_passes(h, sl.jobs.data(), nj, sl.pool.data(), sl.pool.size(), 15, e, 0x3u);
+                                                     : run_ssw_passes(fh, sl.jobs.data(), nj, sl.pool.data(), sl.pool.size(), 15, e, 0x3u);
                 const double tq = now_ms();
-                if (!sl.rc) sl.rc = run_ssw_paths(h, sl.jobs.data(), nj, e, pth);
+                if (!sl.rc) sl.rc = run_ssw_paths(fh, sl.jobs.data(), nj, e, pth);
                 { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return sl.tabled || stop.load(); }); if (!sl.tabled) return; }
                 if (!sl.rc && sl.table_rc) { sl.rc = fail(sl.table_rc, "out of host memory while making a slice's tables"); }
                 if (!sl.rc) {
                     // the paths point into the handle's pinned buffer, which the next slice overwrites
                     size_t n_ops = 0;
-                    for (const rb::SswPath &pt : pth) if (pt.ops) n_ops = std::max(n_ops, (size_t)(pt.ops - h->h_path_ops.p) + (size_t)pt.n_ops);
-                    sl.ops.assign(h->h_path_ops.p, h->h_path_ops.p + n_ops);
+                    for (const rb::SswPath &pt : pth) if (pt.ops) n_ops = std::max(n_ops, (size_t)(pt.ops - fh->h_path_ops.p) + (size_t)pt.n_ops);
+                    sl.ops.assign(fh->h_path_ops.p, fh->h_path_ops.p + n_ops);
                     for (size_t k = 0; k < nj; ++k) {
                         if (e[k].flag == -1) continue;          // not this batch's (a long job: the other thread owns its entries)
                         sl.ends[k] = e[k];
                         sl.paths[k] = pth[k];
-                        if (pth[k].ops) sl.paths[k].ops = sl.ops.data() + (pth[k].ops - h->h_path_ops.p);
+                        if (pth[k].ops) sl.paths[k].ops = sl.ops.data() + (pth[k].ops - fh->h_path_ops.p);
                     }
                 } else {
                     sl.error = g_last_error;
@@ -2197,17 +2198,29 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                 cv.notify_all();
             }
         });
-        feeder = std::thread([&]() {
-            for (size_t c = 0; c < n_slices && !stop; ++c) {
+        // Two feeders on alternating slices, the second on a helper handle of its own (streams, buffers): a launch of the path
+        // search lasts as long as its longest alignment, and with one feeder the GPU idles through every such tail before the
+        // next slice's passes start (RIBBIT_SSW_FEEDERS=1: one feeder, as until the end of round 3).
+        static const char *const feeders_env = std::getenv("RIBBIT_SSW_FEEDERS");
+        size_t n_feeders = feeders_env ? (size_t)std::max(1, std::min(2, std::atoi(feeders_env))) : 2;
+        if (n_slices < 2) n_feeders = 1;
+        if (n_feeders == 2) {
+            if (!h->aux2 && ribbit_hip_open(&h->params, h->device, &h->aux2) != RIBBIT_OK) n_feeders = 1;      // (no memory for it: one feeder)
+            else { h->aux2->dev_ascii_src = h->dev_ascii_src; h->aux2->length = h->length; h->aux2->loaded = true; }
+        }
+        auto feeder_loop = [&](size_t k, RibbitHandle *fh) {
+            for (size_t c = k; c < n_slices && !stop; c += n_feeders) {
                 { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return slices[c].built || stop.load(); }); if (!slices[c].built) break; }
-                feed(c);
+                feed(c, fh);
                 { std::lock_guard<std::mutex> lk(mu); slices[c].ready = true; }
                 cv.notify_all();
                 if (slices[c].rc) break;
             }
-            { std::lock_guard<std::mutex> lk(mu); feeder_finished = true; }
-            cv.notify_all();
-        });
+        };
+        std::thread feeder2;
+        struct Feeder2Guard { std::atomic<bool> &stop; std::condition_variable &cv; std::thread &t; ~Feeder2Guard() { stop = true; cv.notify_all(); if (t.joinable()) t.join(); } } feeder2_guard{stop, cv, feeder2};
+        feeder = std::thread([&]() { feeder_loop(0, h); });
+        if (n_feeders == 2) feeder2 = std::thread([&]() { feeder_loop(1, h->aux2); });
         for (size_t c = 0; c < n_slices; ++c) {
             build_slice(c);
             { std::lock_guard<std::mutex> lk(mu); slices[c].built = true; }
@@ -2235,6 +2248,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         stop = true;
         cv.notify_all();
         feeder.join();
+        if (feeder2.joinable()) feeder2.join();
         const double tw = now_ms();
         if (long_thread.joinable()) long_thread.join();
         if (later_thread.joinable()) later_thread.join();
