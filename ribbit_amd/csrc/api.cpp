@@ -1665,7 +1665,7 @@ int ribbit_hip_ssw_align_jobs(RibbitHandle *h, const RibbitAlignJob *jobs, size_
         const bool gpu_ends = ends[j].flag != -1 && ql > 0;
         const bool gpu_path = gpu_ends && (paths[j].ops || paths[j].failed);
         if (ql <= 0) { r = rb::SswResult{}; r.ref_begin = r.query_begin = -1; }
-        else if (gpu_path) rb::ssw_finish_with_path(bases.data() + qs, ql, ref.data(), jobs[j].ppr_length, ends[j], paths[j], r);
+        else if (gpu_path) rb::ssw_finish_with_path_periodic(bases.data() + qs, ql, motif_pool + jobs[j].motif_offset, jobs[j].atomicity, ends[j], paths[j], r);
         else if (gpu_ends) rb::ssw_finish(bases.data() + qs, ql, ref.data(), jobs[j].ppr_length, ends[j], r);
         else rb::ssw_align(bases.data() + qs, ql, ref.data(), jobs[j].ppr_length, mask_len, r);
         if (on_gpu) on_gpu[j] = gpu_path ? 2 : gpu_ends ? 1 : 0;

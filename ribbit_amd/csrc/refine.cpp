@@ -554,13 +554,14 @@ struct Writer {
             ++next_job;
         }
         if (query.n == 0) { saw_empty_query = true; return last_cigar; }
-        { Stopwatch swq(&tl.t_query); ref.clear(); while ((long)ref.size() <= (long)ppr_len) ref += motif; }
+        // with end points AND path known nothing reads the reference as a string (ssw_finish_with_path_periodic)
+        if (!(known && known_path)) { Stopwatch swq(&tl.t_query); ref.clear(); while ((long)ref.size() <= (long)ppr_len) ref += motif; }
         {
             Stopwatch sw(&tl.t_align);
             Stopwatch sw2(known ? nullptr : (query_start < 0 ? &tl.t_flank : &tl.t_whole_first));
             if (query_start < 0) ++tl.n_flank;
             ++tl.n_align;
-            if (known && known_path) { ++tl.n_known; ++tl.n_paths; ssw_finish_with_path(query.p, query.n, ref.data(), ppr_len, *known, *known_path, res); }
+            if (known && known_path) { ++tl.n_known; ++tl.n_paths; ssw_finish_with_path_periodic(query.p, query.n, motif.data(), (int)motif.size(), *known, *known_path, res); }
             else if (known) { ++tl.n_known; ssw_finish(query.p, query.n, ref.data(), ppr_len, *known, res); }
             else ssw_align(query.p, query.n, ref.data(), ppr_len, 15, res);
         }

@@ -413,6 +413,61 @@ void ssw_finish_with_path(const char *query, int query_len, const char *ref, int
     finish(query, query_len, ref, ref_len, e, &path, out);
 }
 
+// The same result as ssw_finish_with_path for a reference that is `motif` (atom bases) repeated -- which every reference of
+// ribbit's alignments is (the pseudo-perfect repeat, parse_seed.cpp:404) -- without the reference: with end points and path
+// known, all that is left of ssw_cpp.cpp:126-207 is to split the path's M runs into '=' / 'X' and to count, and that reads the
+// aligned windows only.  (finish() translates the whole query and the whole reference first, and its caller had spelt the
+// reference out to the padded length: three passes over more bases than the alignment covers, ten million times a chromosome.)
+void ssw_finish_with_path_periodic(const char *query, int query_len, const char *motif, int atom, const SswEnds &e, const SswPath &path, SswResult &out) {
+    out.cigar.clear();
+    out.mismatches = 0; out.skipped = false;
+    out.score = e.score; out.ref_end = e.ref_end; out.query_end = e.query_end;
+    out.score2 = e.score2; out.ref_end2 = e.ref_end2;
+    out.ref_begin = e.ref_begin; out.query_begin = e.query_begin; out.flag = e.flag;
+    if (e.score == 0 || e.ref_end < 0) {            // as finish(): "no alignment"
+        out.cigar = std::to_string(query_len) + "S";
+        out.ref_end = -1; out.ref_begin = -1; out.query_begin = -1;
+        return;
+    }
+    std::string &c = out.cigar;
+    auto put = [&](int n, char op) {
+        char buf[12];
+        int at = 12;
+        unsigned v = (unsigned)n;
+        do { buf[--at] = (char)('0' + v % 10u); v /= 10u; } while (v);
+        c.append(buf + at, (size_t)(12 - at));
+        c += op;
+    };
+    const bool too_far = out.ref_end - out.ref_begin > DISTANCE_FILTER || out.query_end - out.query_begin > DISTANCE_FILTER;
+    if (path.failed && !too_far) out.flag = 1;
+    if (out.query_begin > 0) put(out.query_begin, 'S');
+    if (!too_far && !path.failed && atom > 0) {
+        int8_t tm[1024];                              // the motif, translated (a motif is at most a few hundred bases)
+        static thread_local std::vector<int8_t> tm_long;
+        const int8_t *t = tm;
+        if (atom > 1024) { tm_long.resize((size_t)atom); for (int k = 0; k < atom; ++k) tm_long[(size_t)k] = translate(motif[k]); t = tm_long.data(); }
+        else for (int k = 0; k < atom; ++k) tm[k] = translate(motif[k]);
+        const char *qp = query + out.query_begin;
+        int rj = out.ref_begin % atom;                // reference position, modulo the motif
+        int run_eq = 0, run_x = 0;
+        auto close_run = [&]() { if (run_eq) put(run_eq, '='); else if (run_x) put(run_x, 'X'); run_eq = run_x = 0; };
+        for (int k = 0; k < path.n_ops; ++k) {
+            const int len = (int)(path.ops[k] >> 2), op = (int)(path.ops[k] & 3u);
+            if (op == 0) {
+                for (int i = 0; i < len; ++i, ++qp) {
+                    if (t[rj] != translate(*qp)) { ++out.mismatches; if (run_eq) put(run_eq, '='); run_eq = 0; ++run_x; }
+                    else { if (run_x) put(run_x, 'X'); run_x = 0; ++run_eq; }
+                    if (++rj == atom) rj = 0;
+                }
+            } else if (op == 1) { qp += len; out.mismatches += len; close_run(); put(len, 'I'); }
+            else if (op == 2) { rj = (int)(((long)rj + len) % atom); out.mismatches += len; close_run(); put(len, 'D'); }
+        }
+        close_run();
+    }
+    const int tail = query_len - out.query_end - 1;
+    if (tail > 0) put(tail, 'S');
+}
+
 void ssw_align(const char *query, int query_len, const char *ref, int ref_len, int mask_len, SswResult &out) {
     if (query_len <= 0) {       // Aligner::Align returns before touching `alignment`
         out = SswResult{};
