@@ -49,7 +49,7 @@ struct HostPlanes {
         xa.clear(); xa_view = nullptr; xa_stride = 0; xa_m_lo = 0; xa_m_hi = -1;
         sym_cache_.reset();
     }
-    // One byte per base (0..3 = A C G T, 4 = N; one pad entry = 4 at position L), decoded from the planes on first use
+    // One byte per base (0..3 = A C G T, 4 = N; 16 pad entries = 4 from position L on), decoded from the planes on first use
     // (host threads) and kept until the record changes: the refinement stages read bases by the hundred million, and
     // every one of their calls used to decode the whole record again on one thread (a second per chromosome and call).
     // Thread-safe; the planes must not change while a caller holds the result.

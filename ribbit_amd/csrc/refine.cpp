@@ -191,25 +191,51 @@ int consensus_row(const Bases &b, int seed_start, int seq_len, int m) {
         }
         return d;
     };
+    // The five jittered forward diagonals of one step, eight symbols at a time (as long_motif_rows_kernel does on the GPU: a
+    // symbol is 0..4, so the bytes of (a ^ b) + 0x7f..7f have bit 7 clear exactly where the symbols are equal, and a column
+    // symbol is a base where its bit 2 is clear).  The walk of `diagonal` ends at the first column outside [lo, hi): for an
+    // increasing column, none if the first is below lo, else the first hi - col0.  Loads run up to 7 bytes past what is counted:
+    // sym is padded by 16 entries (host_planes.cpp).  Flank seeds get their row here: 29 K of them per chromosome and pass.
+    auto diagonals5 = [&](int row0, int col0, int lo, int hi, int n, int (&matches)[5]) {
+        int cnt[5], most = 0;
+        for (int x = 0; x < 5; ++x) {
+            const int c0 = col0 + x - 2;
+            cnt[x] = c0 < lo ? 0 : std::max(0, std::min(n, hi - c0));
+            most = std::max(most, cnt[x]);
+            matches[x] = 0;
+        }
+        for (int i = 0; i < most; i += 8) {
+            uint64_t rb8;
+            std::memcpy(&rb8, b.sym + row0 + i, 8);
+            for (int x = 0; x < 5; ++x) {
+                const int left = cnt[x] - i;
+                if (left <= 0) continue;
+                uint64_t a;
+                std::memcpy(&a, b.sym + (col0 + x - 2 + i), 8);
+                uint64_t eq = ~((a ^ rb8) + 0x7f7f7f7f7f7f7f7full) & ~(a << 5) & 0x8080808080808080ull;
+                if (left < 8) eq &= (1ull << (8 * left)) - 1ull;
+                matches[x] += __builtin_popcountll(eq);
+            }
+        }
+    };
     int best_row = 0, best_score = 0;
+    int d5[5];
     for (int row = seed_start; row < seed_end - m + 1; ++row) {
         int score = 0;
         for (int col = row + m; col < seed_end;) {                    // downstream copies (:181-198)
             int pick = -2, top = 0;
-            for (int x = -2; x <= 2; ++x) {
-                const int d = diagonal(row, col + x, INT32_MIN, seed_end, m, 1);
-                if (d > top) { top = d; pick = x; }
-            }
+            diagonals5(row, col, INT32_MIN, seed_end, m, d5);
+            for (int x = -2; x <= 2; ++x)
+                if (d5[x + 2] > top) { top = d5[x + 2]; pick = x; }
             score += top;
             col += pick + m;
         }
         int col = row - m;
         for (; col > seed_start;) {                                   // upstream copies (:200-217)
             int pick = -2, top = 0;
-            for (int x = -2; x <= 2; ++x) {
-                const int d = diagonal(row, col + x, 0, INT32_MAX, m, 1);
-                if (d > top) { top = d; pick = x; }
-            }
+            diagonals5(row, col, 0, INT32_MAX, m, d5);
+            for (int x = -2; x <= 2; ++x)
+                if (d5[x + 2] > top) { top = d5[x + 2]; pick = x; }
             score += top;
             col += pick - m;
         }
