@@ -544,7 +544,14 @@ struct Writer {
     const char *sequence;
     const RibbitRefineParams &prm;
     const std::string &id;
-    std::ostringstream os;
+    // the rows, as text.  A plain string with the three calls of a string stream that the callers use: a row through an
+    // ostringstream (locale, sentry, virtual calls per field) was a seventh of the workers' time -- 2.6 M rows a chromosome
+    struct Text {
+        std::string s;
+        size_t tellp() const { return s.size(); }
+        std::string str() const { return s; }
+        void str(std::string v) { s = std::move(v); }
+    } os;
     std::string last_cigar;     // the Alignment object lives across seeds (fasta_utils.cpp:177): an empty query leaves it untouched
     Writer(const Bases &b_, const HostPlanes &hp_, const char *sequence_, const RibbitRefineParams &prm_, const std::string &id_)
         : b(b_), hp(hp_), sequence(sequence_), prm(prm_), id(id_) {}
@@ -596,8 +603,23 @@ struct Writer {
     }
     void row(const Repeat &r, const std::string &motif, int atom, int m, int type) {   // parse_seed.cpp:434-436
         Stopwatch sw(&tl.t_row);
-        os << id << "\t" << r.start << "\t" << r.end << "\t" << motif << "\t" << atom << " | " << m << "\t" << r.end - r.start << "\t"
-           << (r.end - r.start) / atom << "\t" << r.purity << "\t" << "+\tSEED-" << type << "\t" << r.cigar << "\n";
+        // id \t start \t end \t motif \t atom | m \t length \t units \t purity \t + \t SEED-type \t cigar \n.  The purity is a float
+        // through an ostream in the reference: "%g" at the default precision of 6, which is what num_put hands to printf
+        std::string &t = os.s;
+        auto num = [&](long v) {
+            char buf[24];
+            int at = 24;
+            unsigned long u = v < 0 ? 0ul - (unsigned long)v : (unsigned long)v;
+            do { buf[--at] = (char)('0' + u % 10ul); u /= 10ul; } while (u);
+            if (v < 0) buf[--at] = '-';
+            t.append(buf + at, (size_t)(24 - at));
+        };
+        t += id; t += '\t'; num(r.start); t += '\t'; num(r.end); t += '\t'; t += motif; t += '\t'; num(atom); t += " | "; num(m); t += '\t';
+        num(r.end - r.start); t += '\t'; num((r.end - r.start) / atom); t += '\t';
+        char pbuf[40];
+        const int pn = std::snprintf(pbuf, sizeof pbuf, "%g", (double)r.purity);
+        t.append(pbuf, (size_t)std::max(0, std::min(pn, (int)sizeof pbuf - 1)));
+        t += "\t+\tSEED-"; num(type); t += '\t'; t += r.cigar; t += '\n';
     }
 
     const SmallMotifTable *small = nullptr;     // possibleMotifs of the dispatched seeds from the GPU (optional)
