@@ -174,6 +174,7 @@ struct RibbitHandle {
     bool longest_valid = false;
     std::vector<int32_t> longest_runs;
     DevBuf<RibbitSeed> d_seeds;
+    DevBuf<RibbitSeed> d_seeds_small;     // the small-motif scan's own, so that it can run beside the consensus-row scan
     DevBuf<int32_t> d_longest;
     DevBuf<uint8_t> d_sym;
     bool sym_valid = false;                                 // d_sym holds the loaded record
@@ -1085,8 +1086,11 @@ int build_best_rows(RibbitHandle *h, const RibbitRefineParams &prm) {
 
 // possibleMotifs of every dispatched seed with m <= 10 that reaches it (parse_smallmotif_seed.cpp:234-236), one GPU
 // launch (a14 / f2); seeds the kernel flags (more than 64 classes) keep flags != 0 and the host twin runs for them
-int build_small_motifs(RibbitHandle *h, const RibbitRefineParams &prm) {
+// `stream`: where its copies and its kernel go (default: the handle's).  With another stream it may run beside build_best_rows on
+// another thread, PROVIDED the longest runs and the symbols are there already (scan_seeds_side_by_side sees to that).
+int build_small_motifs(RibbitHandle *h, const RibbitRefineParams &prm, hipStream_t stream = nullptr) {
     if (h->small_valid) return RIBBIT_OK;
+    if (!stream) stream = h->stream;
     int rc = build_longest_runs(h);
     if (rc) return rc;
     const size_t n = h->dispatch.size();
@@ -1116,31 +1120,60 @@ int build_small_motifs(RibbitHandle *h, const RibbitRefineParams &prm) {
         // survivor, and all classes only for the seeds with two or more) and a million more; a seed that finds the arena
         // full is left to the host
         const size_t cap = std::min<size_t>(4 * jobs.size() + (1u << 20), 0x7fffffffu);
-        if ((rc = h->d_sym.ensure((size_t)h->length + 16)) || (rc = h->d_seeds.ensure(jobs.size())) || (rc = h->d_small_head.ensure(4 * n)) ||
+        if ((rc = h->d_sym.ensure((size_t)h->length + 16)) || (rc = h->d_seeds_small.ensure(jobs.size())) || (rc = h->d_small_head.ensure(4 * n)) ||
             (rc = h->d_small_records.ensure(4 * cap)) || (rc = h->d_small_count.ensure(4)))
             return rc;
-        if (!h->sym_valid) { rb::launch_sym(h->dev_ascii_src, h->length, h->d_sym.p, h->stream); HIP_TRY(hipGetLastError()); h->sym_valid = true; }
-        HIP_TRY(hipMemcpyAsync(h->d_seeds.p, jobs.data(), jobs.size() * sizeof(RibbitSeed), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemsetAsync(h->d_small_count.p, 0, 4 * sizeof(uint32_t), h->stream));
-        HIP_TRY(hipMemsetAsync(h->d_small_head.p, 0xff, 4 * n * sizeof(int32_t), h->stream));      // flags -1: no device result
-        rb::launch_small_motifs(h->d_sym.p, h->length, h->d_seeds.p, (int64_t)jobs.size(), lim, h->d_small_records.p, (uint32_t)cap, h->d_small_count.p,
-                                h->d_small_head.p, h->stream);
+        if (!h->sym_valid) { rb::launch_sym(h->dev_ascii_src, h->length, h->d_sym.p, stream); HIP_TRY(hipGetLastError()); h->sym_valid = true; }
+        HIP_TRY(hipMemcpyAsync(h->d_seeds_small.p, jobs.data(), jobs.size() * sizeof(RibbitSeed), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync(h->d_small_count.p, 0, 4 * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(h->d_small_head.p, 0xff, 4 * n * sizeof(int32_t), stream));      // flags -1: no device result
+        rb::launch_small_motifs(h->d_sym.p, h->length, h->d_seeds_small.p, (int64_t)jobs.size(), lim, h->d_small_records.p, (uint32_t)cap, h->d_small_count.p,
+                                h->d_small_head.p, stream);
         HIP_TRY(hipGetLastError());
         uint32_t used = 0;
-        HIP_TRY(hipMemcpyAsync(h->small_head.p, h->d_small_head.p, 4 * n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(&used, h->d_small_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpyAsync(h->small_head.p, h->d_small_head.p, 4 * n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&used, h->d_small_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
         used = (uint32_t)std::min<size_t>(used, cap);
         if ((rc = h->small_records.ensure(std::max<size_t>(4 * (size_t)used, 4)))) return rc;
         if (used) {
-            HIP_TRY(hipMemcpyAsync(h->small_records.p, h->d_small_records.p, 4 * (size_t)used * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
+            HIP_TRY(hipMemcpyAsync(h->small_records.p, h->d_small_records.p, 4 * (size_t)used * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
         }
         h->n_small_records = used;
     }
     static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
     if (profile) std::fprintf(stderr, "[small motifs] %zu seeds on the GPU, %zu records, %.1f ms incl. transfers\n", jobs.size(), h->n_small_records, now_ms() - t0);
     h->small_valid = true;
+    return RIBBIT_OK;
+}
+
+// The two scans of the dispatched seeds that refinement starts with -- consensus rows of the long-motif seeds, possibleMotifs of
+// the small-motif ones -- side by side: each prepares its seeds on the host, copies, launches, copies back and post-processes
+// (80-90 ms apiece at chromosome-1 size), and neither needs anything of the other.  The small-motif scan goes to a helper
+// thread and the copy stream; what both read (longest runs, one symbol per base) is made first.
+int scan_seeds_side_by_side(RibbitHandle *h, const RibbitRefineParams &prm) {
+    int rc = build_longest_runs(h);
+    if (rc) return rc;
+    if (h->best_rows_valid || h->small_valid || h->dispatch.size() < 200000) {      // (a small record: not worth a thread)
+        if ((rc = build_best_rows(h, prm))) return rc;
+        return build_small_motifs(h, prm);
+    }
+    if ((rc = bind_device(h))) return rc;
+    if ((rc = h->d_sym.ensure((size_t)h->length + 16))) return rc;
+    if (!h->sym_valid) { rb::launch_sym(h->dev_ascii_src, h->length, h->d_sym.p, h->stream); HIP_TRY(hipGetLastError()); h->sym_valid = true; }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int small_rc = RIBBIT_OK;
+    std::string small_error;
+    std::thread side([&]() {
+        try { small_rc = build_small_motifs(h, prm, h->copy_stream); if (small_rc) small_error = g_last_error; }
+        catch (const std::bad_alloc &) { small_rc = RIBBIT_E_NOMEM; small_error = "out of host memory in the small-motif scan"; }
+    });
+    try { rc = build_best_rows(h, prm); }
+    catch (...) { side.join(); throw; }
+    side.join();
+    if (rc) return rc;
+    if (small_rc) { g_last_error = small_error; return small_rc; }
     return RIBBIT_OK;
 }
 
@@ -1234,7 +1267,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     h->d_ascii.release(); h->d_hi.release(); h->d_lo.release(); h->d_brk.release();
-    h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release(); h->d_slices.release();
+    h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_seeds_small.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release(); h->d_slices.release();
     h->d_ssw_jobs.release(); h->d_ssw_order.release(); h->d_ssw_out.release(); h->d_ssw_pool.release();
     h->d_path_items.release(); h->d_path_result.release(); h->d_path_cell_off.release(); h->d_path_ops_off.release(); h->d_path_cells.release();
     h->d_path_scratch.release(); h->d_path_ops.release(); h->d_path_count.release(); h->h_path_ops.release();
@@ -1950,9 +1983,8 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
     auto add_ms = [](std::atomic<int64_t> &acc, double ms) { acc.fetch_add((int64_t)(ms * 1000.0), std::memory_order_relaxed); };
     static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
     double t0 = now_ms();
-    int rc = build_best_rows(h, *prm);
+    int rc = scan_seeds_side_by_side(h, *prm);
     if (rc) return rc;
-    if ((rc = build_small_motifs(h, *prm))) return rc;
     const rb::SmallMotifTable small{h->small_head.p, h->small_records.p};
     add_ms(t_rows_us, now_ms() - t0);
     t0 = now_ms();
