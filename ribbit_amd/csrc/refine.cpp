@@ -37,7 +37,8 @@ struct Bases {
     int L;
     std::shared_ptr<const std::vector<uint8_t>> hold;
     const uint8_t *sym;
-    explicit Bases(const HostPlanes &hp, unsigned threads = 0) : L((int)hp.length), hold(hp.symbols(threads)), sym(hold->data()) {}
+    const uint32_t *brk;      // the N mask as a bit plane (32 positions a word; bits past L are set: padding)
+    explicit Bases(const HostPlanes &hp, unsigned threads = 0) : L((int)hp.length), hold(hp.symbols(threads)), sym(hold->data()), brk(hp.brk.data()) {}
     // N encodes as 00 (fasta_utils.cpp:111-113).  D4: a position below 0 -- reachable only after a motif window that
     // starts before the record, where the reference has already terminated in substr -- reads as base A, not N.
     unsigned code(int p) const { return p < 0 ? 0u : sym[(size_t)p] & 3u; }
@@ -95,11 +96,22 @@ std::string spell(const Wide &unit, int m, int take) {       // calculateMotif(.
 int padded_length(int a, int m, int b, float purity) { return (int)((float)(a + m) + (1 - purity) * (float)b); }
 
 // the seed's sequence length: seed + one motif, cut at the first N (parse_seed.cpp:342-349)
-int usable_length(const Bases &b, int start, int end, int m) {
-    for (int s = start; s < end + m; ++s)
-        if (b.is_n(s)) return s - start;
+// (The first N at or after `start`, below end + m, from the N mask's words: a walk over the bases, 45 of them for the average
+// seed, was done for every dispatched seed by the job set-up, again by the workers and once more before the consensus-row
+// scan.  Positions below 0 and from L on are never N for this test, and the plane's padding bits past L are set.)
+int first_n_cut(const uint32_t *brk, int L, int start, int end, int m) {
+    const int stop = std::min(end + m, L);
+    for (int s = std::max(start, 0); s < stop;) {
+        const uint32_t bits = brk[(size_t)(s >> 5)] >> (s & 31);
+        if (bits) {
+            const int p = s + __builtin_ctz(bits);
+            return p < stop ? p - start : (end - start) + m;
+        }
+        s = ((s >> 5) + 1) << 5;
+    }
     return (end - start) + m;
 }
+int usable_length(const Bases &b, int start, int end, int m) { return first_n_cut(b.brk, b.L, start, end, m); }
 
 struct Tracked { int first, last_end, units, anchor; uint32_t expect; };
 
@@ -265,12 +277,7 @@ int longest_run_host(const HostPlanes &hp, int mlen, int start, int end) {
     return best;
 }
 
-int usable_length_host(const HostPlanes &hp, int start, int end, int m) {
-    const int L = (int)hp.length;
-    for (int s = start; s < end + m; ++s)
-        if (s < L && ((hp.brk[(size_t)(s >> 5)] >> (s & 31)) & 1u)) return s - start;
-    return (end - start) + m;
-}
+int usable_length_host(const HostPlanes &hp, int start, int end, int m) { return first_n_cut(hp.brk.data(), (int)hp.length, start, end, m); }
 
 namespace {
 thread_local double tl_build_join_ms = 0.0;      // profile: joining the chunks' jobs and pools, on the calling thread (sequential)
