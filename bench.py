@@ -305,11 +305,30 @@ def sharded_full_path(ribbit_amd, dist, torch, sc, seq: bytes, bases: int, rank:
     part = sharded.scan_part(sc, record, plan)
     torch.cuda.synchronize()
     t_scan = time.perf_counter() - t0
+    # the exchange, over both transports when the ranks share a node (as the headline leg does): the collective backend
+    # (RCCL on GPUs: host -> device -> gather -> host, since what a chunk keeps is host data by now), and the node-shared segment
+    # (every rank copies into its own cell: N memcpys side by side).  The leg's total uses the faster one; both are in the line.
+    from ribbit_amd.distributed import same_node
+    backend = "rccl" if xdev is not None else "gloo"
     sync()
     t1 = time.perf_counter()
     gathered = sharded.gather_parts(part, xdev)
     sync()
-    t_exchange = time.perf_counter() - t1
+    by_transport = {backend: time.perf_counter() - t1}
+    shm_identical = None
+    if same_node():
+        sync()
+        t1 = time.perf_counter()
+        ok, shared = sharded.gather_parts_shm(part)
+        sync()
+        if ok:
+            by_transport["shm"] = time.perf_counter() - t1
+            if rank == 0:
+                shm_identical = all((a[k] is None) == (b[k] is None) and (a[k] is None or np.ndim(a[k]) == 0 and a[k] == b[k] or
+                                                                            np.ndim(a[k]) > 0 and np.asarray(a[k]).tobytes() == np.asarray(b[k]).tobytes())
+                                    for a, b in zip(gathered, shared) for k in a)
+    headline_transport = min(by_transport, key=by_transport.get)
+    t_exchange = by_transport[headline_transport]
     t = torch.tensor([t_scan], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     sent = sharded.part_bytes(part)
@@ -328,6 +347,8 @@ def sharded_full_path(ribbit_amd, dist, torch, sc, seq: bytes, bases: int, rank:
     total = float(t.item()) + t_exchange + t_merge
     return {"bases": L, "bases_per_gpu": bases, "seconds": total, "value": L / total / 1e9, "unit": "Gbases/s",
             "scan_seconds_max_over_ranks": float(t.item()), "exchange_seconds": t_exchange, "merge_seconds_rank0": t_merge,
+            "exchange": {"headline": headline_transport, "headline_rule": "the faster of the transports timed in this run",
+                         "seconds": by_transport, "shm_identical_to_collective": shm_identical},
             "identical_to_single_gpu_scan": bool(same),
             "seeds": {"perfect": int(len(lists["perfect"])), "substitution": int(len(lists["subst"])), "anchored": int(len(lists["anchored"]))},
             "dispatched": int(len(lists["dispatch"])), "sent_per_rank": all_sent,

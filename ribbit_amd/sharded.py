@@ -149,3 +149,57 @@ def gather_parts(part: dict, device=None, dst: int = 0):
     if rank != dst:
         return None
     return out
+
+
+def gather_parts_shm(part: dict, dst: int = 0):
+    """The same gather through host memory shared by the ranks of ONE node (ribbit_amd.node_gather) instead of the collective
+    backend: every rank writes its part -- a header of the scalars and the arrays' sizes, then the arrays back to back -- into
+    its own cell of a segment all ranks map, and rank `dst` (which must be 0, the segment's consumer) reads them there.  What a
+    chunk keeps is host data when it gets here (scan_part copied it off the GPU), so this is N memcpys side by side where
+    gather_parts goes host -> device -> gather -> host.  Collective.  -> (ok, parts): ok is the same on every rank (False: the
+    segment could not be made or attached, e.g. /dev/shm too small -- use gather_parts); parts as gather_parts returns them."""
+    import torch.distributed as dist
+
+    from .distributed import open_node_gather
+    assert dst == 0
+    world, rank = dist.get_world_size(), dist.get_rank()
+    raws = []
+    for k, _ in _ARRAYS:
+        a = part.get(k)
+        raws.append(None if a is None else np.ascontiguousarray(a).view(np.uint8).reshape(-1))
+    header = np.array([int(part[k]) for k in _SCALARS] + [-1 if r is None else int(r.size) for r in raws], dtype=np.int64)
+    blob = np.concatenate([header.view(np.uint8)] + [r for r in raws if r is not None and r.size])
+    sizes = [None] * world
+    dist.all_gather_object(sizes, int(blob.size))
+    ng = open_node_gather(np.dtype(np.uint8), max(sizes) + 64, 1, nslots=1)
+    if ng is None:
+        return False, None
+    out = None
+    try:
+        ng.wait_free(1)
+        cell, _ = ng.mine(1)
+        cell[:blob.size] = blob
+        ng.publish(1, int(blob.size), 0)
+        if rank == dst:
+            cells, _ = ng.collect(1)
+            out = []
+            nh = len(_SCALARS) + len(_ARRAYS)
+            for r in range(world):
+                raw = np.asarray(cells[r])
+                head = raw[:8 * nh].view(np.int64)
+                one = {k: int(head[j]) for j, k in enumerate(_SCALARS)}
+                at = 8 * nh
+                for j, (k, dt) in enumerate(_ARRAYS):
+                    n = int(head[len(_SCALARS) + j])
+                    if n < 0:
+                        one[k] = None
+                    else:
+                        one[k] = raw[at:at + n].copy().view(dt)
+                        at += n
+                out.append(one)
+            ng.release(1)
+        dist.barrier()
+    finally:
+        ng.close()
+    return True, out
+

@@ -89,5 +89,12 @@ def test_two_ranks_on_one_gpu_reproduce_the_unsharded_runs(exchange):
     fp = d["full_path_sharded"]
     assert fp["identical_to_single_gpu_scan"] is True and fp["bases"] == 2 * 2_000_000 and fp["seeds"]["anchored"] > 0
     assert len(fp["sent_per_rank"]) == 2
+    # the kept calls' exchange over both transports (the collective backend: gloo in this rehearsal, RCCL on a node's GPUs; and
+    # the node-shared segment), both in the line, the leg's total with the faster one
+    fx = fp["exchange"]
+    assert "gloo" in fx["seconds"] and fx["headline"] in fx["seconds"] and fp["exchange_seconds"] == fx["seconds"][fx["headline"]]
+    assert fx["seconds"][fx["headline"]] == min(fx["seconds"].values())
+    if "shm" in fx["seconds"]:
+        assert fx["shm_identical_to_collective"] is True
     for sent in fp["sent_per_rank"]:
         assert sent["window_call_bytes"] == 16 * sent["kept_window_calls"] and sent["planes"] > 0

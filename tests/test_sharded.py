@@ -103,6 +103,19 @@ def _worker(rank, world, port, out_dir):
         got = sharded.merge_parts(m_lo, m_hi, len(seq), gathered)
         _same(got, want)
         np.save(os.path.join(out_dir, "dispatch0.npy"), got["dispatch"])
+    # the same parts through the node-shared segment: the same lists (or, everywhere alike, "no segment here")
+    ok, shared = sharded.gather_parts_shm(parts[rank])
+    assert (shared is None) == (rank != 0 or not ok)
+    if rank == 0 and ok:
+        for a, b in zip(gathered, shared):
+            assert a.keys() == b.keys()
+            for k in a:
+                if a[k] is None or b[k] is None or np.ndim(a[k]) == 0:
+                    assert a[k] == b[k], k
+                else:
+                    assert np.asarray(a[k]).tobytes() == np.asarray(b[k]).tobytes(), k
+        _same(sharded.merge_parts(m_lo, m_hi, len(seq), shared), want)
+        np.save(os.path.join(out_dir, "shm_ok.npy"), np.ones(1))
     dist.barrier()
     dist.destroy_process_group()
 
