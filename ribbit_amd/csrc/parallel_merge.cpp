@@ -218,8 +218,7 @@ void run_ranges(size_t n_ranges, unsigned threads, Work work) {
 // constructs what the list grows by (nothing, for a handle whose previous record was as large), instead of writing half a
 // gigabyte of zeros on one thread that the copies overwrite at once; the copies run on the host threads.
 template <class States>
-void join_ranges(const States &state, SeedVec &out, unsigned threads) {
-    const size_t nr = state.size();
+void join_ranges(const States &state, size_t nr, SeedVec &out, unsigned threads) {
     std::vector<size_t> at(nr + 1, 0);
     for (size_t k = 0; k < nr; ++k) at[k + 1] = at[k] + state[k].own.size() - (k > 0 ? 1 : 0);
     out.resize(at[nr]);
@@ -350,6 +349,10 @@ struct RangeState {
     }
 };
 
+// (The ranges' states are made anew for every stage.  Keeping them from record to record -- their lists are half a gigabyte
+// for a chromosome's anchored stage, released when the stage returns -- was tried at the end of round 3 and made the stages
+// SLOWER by 50 ms at chromosome-1 size, as much as not freeing the record's own lists at load time gains: a kept list stays
+// on the socket whose thread touched it first, and the range that reuses it runs wherever the scheduler puts it.)
 // Runs body(k, state) for every range on `threads` threads, then walks the ranges in order and redoes those that read
 // the type of an earlier range's seed before that range retired it.  Returns the number of ranges redone.
 template <class Body>
@@ -423,7 +426,7 @@ void merge_subst_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, 
         subst_in_order(lists, kc);
         st.redone_in_order = true;
     } else {
-        join_ranges(state, lists.subst, threads);
+        join_ranges(state, nr, lists.subst, threads);
         for (size_t k = 0; k < nr; ++k) lists.guard_hits += state[k].guard_hits;
         SubstReplay<SeedLists> r{lists, state[nr - 1].cursor.perfect};
         r.pending_end = kc.tail_pend;
@@ -612,7 +615,7 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
         st.redone_in_order = true;
     } else {
         const double tc = now_ms();
-        join_ranges(state, lists.anchored, threads);
+        join_ranges(state, nr, lists.anchored, threads);
         for (size_t k = 0; k < nr; ++k) lists.guard_hits += state[k].guard_hits;
         st.concat_ms = now_ms() - tc;
         const double tf = now_ms();
@@ -648,23 +651,23 @@ unsigned dispatch_order_ranges(const SeedLists &sl, const std::vector<int> &cut_
             split[x][k] = lo;
         }
     }
+    // the ranges' outputs, reserved for the most a range can yield (no regrowth); the slices of the three lists are read in place
     std::vector<SeedVec> part(nr);
     std::atomic<bool> out_of_place{false};
     std::atomic<size_t> next{0};
     auto loop = [&]() {
         for (size_t k; (k = next.fetch_add(1)) < nr && !out_of_place;) {
             const int64_t lo = k > 0 ? (int64_t)cut_pos[k] : -1, hi = k + 1 < nr ? (int64_t)cut_pos[k + 1] : INT64_MAX;
-            SeedLists sub;      // slices of the three lists (copies: the merge reads every entry once anyway)
-            SeedVec *dst[3] = {&sub.perfect, &sub.subst, &sub.anchored};
             for (int x = 0; x < 3 && !out_of_place; ++x) {
                 const SeedVec &l = *lists[x];
                 const size_t a = split[x][k], b = split[x][k + 1];
                 for (size_t i = a; i < b; ++i)
                     if (!((int64_t)l[i].start > lo && (int64_t)l[i].start < hi)) { out_of_place = true; break; }
-                dst[x]->assign(l.begin() + (long)a, l.begin() + (long)b);
             }
             if (out_of_place) return;
-            dispatch_order(sub, part[k]);
+            part[k].reserve((split[0][k + 1] - split[0][k]) + (split[1][k + 1] - split[1][k]) + (split[2][k + 1] - split[2][k]));
+            dispatch_order_slices(sl.perfect.data() + split[0][k], split[0][k + 1] - split[0][k], sl.subst.data() + split[1][k], split[1][k + 1] - split[1][k],
+                                  sl.anchored.data() + split[2][k], split[2][k + 1] - split[2][k], part[k]);
         }
     };
     {

@@ -552,26 +552,30 @@ Cursor2 anchored_add(ListRefs &sl, int seed_start, int seed_end, int mlen, const
     }
 }
 
-void dispatch_order(const SeedLists &sl, SeedVec &out) {
-    // fasta_utils.cpp:187-224.  `smallest` is a uint64_t compared with int starts; the picked list
-    // persists across iterations when no head is smaller (cannot happen for starts >= 0).
-    const SeedVec &P = sl.perfect, &S = sl.subst, &A = sl.anchored;
+// fasta_utils.cpp:187-224 on three slices given by pointer (the range-parallel form reads its slices of the lists in place).
+// `smallest` is a uint64_t compared with int starts; the picked list persists across iterations when no head is smaller
+// (cannot happen for starts >= 0).
+void dispatch_order_slices(const RibbitSeed *P, size_t np, const RibbitSeed *S, size_t ns, const RibbitSeed *A, size_t na, SeedVec &out) {
     size_t ip = 0, is = 0, ia = 0;
     int pick = -1;
     out.clear();
-    while (ip < P.size() || is < S.size() || ia < A.size()) {
+    while (ip < np || is < ns || ia < na) {
         uint64_t smallest = ~(uint64_t)0;
-        if (ip < P.size() && smallest > (uint64_t)(int64_t)P[ip].start) { smallest = (uint64_t)(int64_t)P[ip].start; pick = 0; }
-        if (is < S.size() && smallest > (uint64_t)(int64_t)S[is].start) { smallest = (uint64_t)(int64_t)S[is].start; pick = 1; }
-        if (ia < A.size() && smallest > (uint64_t)(int64_t)A[ia].start) { smallest = (uint64_t)(int64_t)A[ia].start; pick = 2; }
+        if (ip < np && smallest > (uint64_t)(int64_t)P[ip].start) { smallest = (uint64_t)(int64_t)P[ip].start; pick = 0; }
+        if (is < ns && smallest > (uint64_t)(int64_t)S[is].start) { smallest = (uint64_t)(int64_t)S[is].start; pick = 1; }
+        if (ia < na && smallest > (uint64_t)(int64_t)A[ia].start) { smallest = (uint64_t)(int64_t)A[ia].start; pick = 2; }
         RibbitSeed seed;
-        if (pick == 0 && ip < P.size()) seed = P[ip++];
-        else if (pick == 1 && is < S.size()) seed = S[is++];
-        else if (pick == 2 && ia < A.size()) seed = A[ia++];
+        if (pick == 0 && ip < np) seed = P[ip++];
+        else if (pick == 1 && is < ns) seed = S[is++];
+        else if (pick == 2 && ia < na) seed = A[ia++];
         else break;
         if (seed.type == RIBBIT_RANK_N) continue;                                            // :213
         if (seed.end - seed.start >= 0.9 * seed.mlen) out.push_back(seed);                   // :224
     }
+}
+
+void dispatch_order(const SeedLists &sl, SeedVec &out) {
+    dispatch_order_slices(sl.perfect.data(), sl.perfect.size(), sl.subst.data(), sl.subst.size(), sl.anchored.data(), sl.anchored.size(), out);
 }
 
 }  // namespace rb

@@ -120,5 +120,7 @@ inline Cursor2 anchored_add(SeedLists &sl, int seed_start, int seed_end, int mle
 
 // 3-way merge by start + filters of fasta_utils.cpp:187-224: the seeds that reach refinement, in order
 void dispatch_order(const SeedLists &sl, SeedVec &out);
+// ... of three slices given by pointer
+void dispatch_order_slices(const RibbitSeed *P, size_t np, const RibbitSeed *S, size_t ns, const RibbitSeed *A, size_t na, SeedVec &out);
 
 }  // namespace rb
