@@ -351,8 +351,10 @@ struct RangeState {
 
 // (The ranges' states are made anew for every stage.  Keeping them from record to record -- their lists are half a gigabyte
 // for a chromosome's anchored stage, released when the stage returns -- was tried at the end of round 3 and made the stages
-// SLOWER by 50 ms at chromosome-1 size, as much as not freeing the record's own lists at load time gains: a kept list stays
-// on the socket whose thread touched it first, and the range that reuses it runs wherever the scheduler puts it.)
+// SLOWER by 50 ms at chromosome-1 size in the bench (as much as not freeing the record's own lists at load time gains), with
+// the preparation and the dispatch merge paying for fresh memory instead.  Why a reused list should be slower than a fresh one
+// was not found: memory placement across the host's two sockets was the suspicion, but confining the process to one socket's
+// cores (taskset) made nothing faster.)
 // Runs body(k, state) for every range on `threads` threads, then walks the ranges in order and redoes those that read
 // the type of an earlier range's seed before that range retired it.  Returns the number of ranges redone.
 template <class Body>
