@@ -256,6 +256,11 @@ typedef struct RibbitAlignment {
 } RibbitAlignment;
 int ribbit_ssw_align(const char *query, int32_t query_len, const char *ref, int32_t ref_len, int32_t mask_len,
                      RibbitAlignment *out, char *cigar, size_t cap);
+/* Test hook, host only: the same alignment against `motif` (atom bases) repeated past ref_len, made the way refinement finishes an
+ * alignment whose end points and path come from the GPU -- passes, path as run-length operations, then the finish that reads the
+ * reference through the motif's period instead of a spelt-out string.  Must equal ribbit_ssw_align on that string. */
+int ribbit_debug_ssw_align_periodic(const char *query, int32_t query_len, const char *motif, int32_t atom, int32_t ref_len, int32_t mask_len,
+                                    RibbitAlignment *out, char *cigar, size_t cap);
 
 /* Whole alignments of n jobs on the loaded record with as much on the GPU as it takes (striped passes: ssw_kernels.hip; the
  * banded path search of ssw.c:590-775: ssw_path.hip; the host writes the CIGAR text and aligns what the kernels leave alone):

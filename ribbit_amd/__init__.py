@@ -14,7 +14,7 @@ import sys
 import numpy as np
 
 __all__ = ["RibbitHipError", "ScanParams", "Scanner", "library_path", "load_library", "host_replay_calls", "pack_planes", "pack_bit_planes",
-           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "ENDS_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "host_refine_bed", "host_merge_chunks", "host_perfect_runs_from_events", "pair_halves", "ssw_align", "merge_chunk_runs", "join_run_halves",
+           "RUN_DT", "CALL_DT", "SEED_DT", "JOB_DT", "ENDS_DT", "RANK", "TERM", "RefineParams", "host_refine_jobs", "host_refine_bed", "host_merge_chunks", "host_perfect_runs_from_events", "pair_halves", "ssw_align", "ssw_align_periodic", "merge_chunk_runs", "join_run_halves",
            "RUN_NOT_OWNED", "RUN_HALF_START", "RUN_HALF_END"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_anchored_calls", "ribbit_hip_seeds_anchored", "ribbit_hip_dispatch_seeds", "ribbit_hip_guard_hits",
     "ribbit_hip_debug_stream_read",
     "ribbit_refine_params_default", "ribbit_hip_seed_longest_runs", "ribbit_hip_refine_jobs",
-    "ribbit_host_refine_jobs", "ribbit_refine_jobs_free", "ribbit_ssw_align",
+    "ribbit_host_refine_jobs", "ribbit_refine_jobs_free", "ribbit_ssw_align", "ribbit_debug_ssw_align_periodic",
     "ribbit_hip_refine_bed", "ribbit_host_refine_bed", "ribbit_text_free",
     "ribbit_hip_xa_words",
     "ribbit_host_perfect_runs_from_events", "ribbit_runs_free", "ribbit_hip_perfect_runs_partial",
@@ -205,6 +205,7 @@ def load_library():
     L.ribbit_runs_free.restype = None
     L.ribbit_runs_free.argtypes = [vp]
     L.ribbit_ssw_align.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, C.POINTER(Alignment), C.c_char_p, C.c_size_t]
+    L.ribbit_debug_ssw_align_periodic.argtypes = [C.c_char_p, i32, C.c_char_p, i32, i32, i32, C.POINTER(Alignment), C.c_char_p, C.c_size_t]
     L.ribbit_hip_stage_calls_chunk.argtypes = [vp, C.c_int, i64, i64, i64, i64, C.POINTER(ChunkCalls)]
     L.ribbit_hip_xa_words_strided.argtypes = [vp, i64, i64, vp, i64]
     L.ribbit_host_merge_chunks.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(ChunkPart), C.c_size_t,
@@ -349,6 +350,19 @@ def ssw_align(query: bytes, ref: bytes, ref_len: int | None = None, mask_len: in
     rc = L.ribbit_ssw_align(query, len(query), ref, len(ref) if ref_len is None else ref_len, mask_len, C.byref(out), buf, cap)
     if rc != 0:
         raise RibbitHipError(f"ribbit_ssw_align error {rc}: {L.ribbit_hip_last_error().decode()}")
+    return {n: getattr(out, n) for n, _ in Alignment._fields_}, buf.value.decode()
+
+
+def ssw_align_periodic(query: bytes, motif: bytes, ref_len: int, mask_len: int = 15):
+    """ribbit_debug_ssw_align_periodic (test hook): the alignment against `motif` repeated past ref_len, finished the way
+    refinement finishes an alignment whose path is known -> (dict of alignment fields, cigar string)"""
+    L = load_library()
+    out = Alignment()
+    cap = 16 * (len(query) + ref_len + len(motif)) + 64
+    buf = C.create_string_buffer(cap)
+    rc = L.ribbit_debug_ssw_align_periodic(query, len(query), motif, len(motif), ref_len, mask_len, C.byref(out), buf, cap)
+    if rc != 0:
+        raise RibbitHipError(f"ribbit_debug_ssw_align_periodic error {rc}: {L.ribbit_hip_last_error().decode()}")
     return {n: getattr(out, n) for n, _ in Alignment._fields_}, buf.value.decode()
 
 

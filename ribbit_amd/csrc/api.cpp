@@ -2466,6 +2466,24 @@ int ribbit_ssw_align(const char *query, int32_t query_len, const char *ref, int3
     return RIBBIT_OK;
 }
 
+int ribbit_debug_ssw_align_periodic(const char *query, int32_t query_len, const char *motif, int32_t atom, int32_t ref_len, int32_t mask_len,
+                                    RibbitAlignment *out, char *cigar, size_t cap) {
+    if (!query || !motif || !out || (cap && !cigar) || query_len < 0 || ref_len < 0 || atom <= 0) return fail(RIBBIT_E_ARG, "bad argument");
+    rb::SswResult r;
+    rb::ssw_align_periodic(query, query_len, motif, atom, ref_len, mask_len, r);
+    out->sw_score = r.score; out->sw_score_next_best = r.score2;
+    out->ref_begin = r.ref_begin; out->ref_end = r.ref_end;
+    out->query_begin = r.query_begin; out->query_end = r.query_end;
+    out->ref_end_next_best = r.ref_end2; out->mismatches = r.mismatches;
+    out->flag = r.flag;
+    out->cigar_len = (int32_t)r.cigar.size();
+    if (cap) {
+        std::strncpy(cigar, r.cigar.c_str(), cap - 1);
+        cigar[cap - 1] = 0;
+    }
+    return RIBBIT_OK;
+}
+
 int64_t ribbit_hip_guard_hits(const RibbitHandle *h) { return h ? h->lists.guard_hits : 0; }
 
 int ribbit_hip_perfect_runs_partial(RibbitHandle *h, int64_t own_lo, int64_t own_hi, int64_t pos_offset,

@@ -468,6 +468,39 @@ void ssw_finish_with_path_periodic(const char *query, int query_len, const char 
     if (tail > 0) put(tail, 'S');
 }
 
+// Host twin of what the GPU hands refinement for an alignment -- end points, and the path as run-length operations (op 0 'M',
+// 1 'I', 2 'D'; length << 2) -- finished by ssw_finish_with_path_periodic: the whole alignment against `motif` repeated, without
+// a GPU, so that the CPU tests can hold the periodic finish against ssw_align on the spelt-out reference (tests/test_ssw.py).
+void ssw_align_periodic(const char *query, int query_len, const char *motif, int atom, int ref_len, int mask_len, SswResult &out) {
+    if (query_len <= 0 || atom <= 0) {
+        out = SswResult{};
+        out.ref_begin = -1; out.query_begin = -1;
+        out.skipped = true;
+        return;
+    }
+    std::string ref;
+    while ((long)ref.size() <= (long)ref_len) ref.append(motif, (size_t)atom);
+    SswEnds ends;
+    ssw_passes(query, query_len, ref.data(), ref_len, mask_len, ends);
+    std::vector<uint32_t> packed;
+    SswPath path;
+    if (ends.score != 0 && ends.ref_end >= 0) {
+        const bool too_far = ends.ref_end - ends.ref_begin > DISTANCE_FILTER || ends.query_end - ends.query_begin > DISTANCE_FILTER;
+        if (!too_far) {
+            std::vector<int8_t> q((size_t)query_len), r((size_t)std::max(ref_len, 1));
+            for (int i = 0; i < query_len; ++i) q[(size_t)i] = translate(query[i]);
+            for (int i = 0; i < ref_len; ++i) r[(size_t)i] = translate(ref[(size_t)i]);
+            const int rl = ends.ref_end - ends.ref_begin + 1, ql = ends.query_end - ends.query_begin + 1;
+            std::vector<Op> ops;
+            if (!banded_path(r.data() + ends.ref_begin, q.data() + ends.query_begin, rl, ql, ends.score, std::abs(rl - ql) + 1, ops)) path.failed = true;
+            else for (const Op &o : ops) packed.push_back(((uint32_t)o.len << 2) | (o.op == 'M' ? 0u : o.op == 'I' ? 1u : 2u));
+        }
+    }
+    path.ops = packed.empty() ? nullptr : packed.data();
+    path.n_ops = (int32_t)packed.size();
+    ssw_finish_with_path_periodic(query, query_len, motif, atom, ends, path, out);
+}
+
 void ssw_align(const char *query, int query_len, const char *ref, int ref_len, int mask_len, SswResult &out) {
     if (query_len <= 0) {       // Aligner::Align returns before touching `alignment`
         out = SswResult{};

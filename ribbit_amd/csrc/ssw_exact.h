@@ -42,6 +42,8 @@ struct SswPath {
 void ssw_finish_with_path(const char *query, int query_len, const char *ref, int ref_len, const SswEnds &ends, const SswPath &path, SswResult &out);
 // ... for a reference that is `motif` (atom bases) repeated, without spelling it out: same result, reads the aligned windows only
 void ssw_finish_with_path_periodic(const char *query, int query_len, const char *motif, int atom, const SswEnds &ends, const SswPath &path, SswResult &out);
+// the whole alignment against `motif` repeated, host only: passes, banded path, then the periodic finish (a test twin of the GPU path)
+void ssw_align_periodic(const char *query, int query_len, const char *motif, int atom, int ref_len, int mask_len, SswResult &out);
 
 // Aligner().Align(query, ref, ref_len, Filter(), &alignment, mask_len) with the default scores
 // (match 2, mismatch 2, gap open 3, gap extend 1; ssw_cpp.cpp:230-242).

@@ -88,6 +88,33 @@ def test_repeat_like_jobs_match_reference(seed):
         _check(query, ref, ppr_len)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_the_periodic_finish_equals_the_alignment_on_the_spelt_out_reference(seed):
+    """Refinement finishes an alignment whose end points and path come from the GPU without its reference string: the
+    reference base at position j is motif[j % atom] (ssw_finish_with_path_periodic).  Host twin of that route (passes, path as
+    run-length operations, periodic finish) against ribbit_ssw_align -- which the tests above pin to the reference library -- on
+    the spelt-out string: every field and the CIGAR, for the shape ribbit produces and for queries unrelated to the motif,
+    with unknown bases, lower case, motifs of one base and queries shorter than the motif."""
+    rs = np.random.RandomState(4100 + seed)
+    for k in range(150):
+        m = int(rs.randint(1, 40))
+        motif = _rand(rs, m, b"ACGTN" if rs.random_sample() < 0.1 else b"ACGT")
+        if k % 3 == 2:
+            query = _rand(rs, int(rs.randint(1, 200)), b"ACGTNacgt" if rs.random_sample() < 0.3 else b"ACGT")
+        else:
+            units = int(rs.randint(1, 40))
+            rot = int(rs.randint(0, m))
+            pure = (motif * (units + 2))[rot:rot + m * units + int(rs.randint(0, m))]
+            query = _mutate(rs, pure, float(rs.choice([0.0, 0.03, 0.1, 0.25])))
+        if not query:
+            continue
+        ppr_len = len(query) + m + int(0.15 * len(query))
+        ref = motif * (ppr_len // m + 2)
+        want, want_cigar = ribbit_amd.ssw_align(query, ref, ppr_len)
+        got, got_cigar = ribbit_amd.ssw_align_periodic(query, motif, ppr_len)
+        assert got_cigar == want_cigar and got == want, (query, motif, ppr_len, got, got_cigar, want, want_cigar)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_pairs_match_reference(seed):
     rs = np.random.RandomState(500 + seed)
