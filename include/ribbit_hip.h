@@ -531,7 +531,7 @@ int ribbit_hip_small_motifs(RibbitHandle *h, const RibbitRefineParams *prm, cons
 /* Test hook: cumulative, process-wide: small-motif seeds that refinement took from the GPU's table / computed on the host. */
 void ribbit_debug_small_motif_counters(int64_t out[2]);
 /* Test hook: cumulative, process-wide: alignments refinement made / of them with the striped passes from the GPU / with the
- * path from the GPU (ribbit_hip_refine_bed batches them on the GPU for records with two million dispatched seeds or more;
+ * path from the GPU (ribbit_hip_refine_bed batches them on the GPU for records with 400,000 dispatched seeds or more;
  * RIBBIT_GPU_SSW=0 / 1 forces it off / on). */
 void ribbit_debug_alignment_counters(int64_t out[3]);
 

@@ -2022,14 +2022,17 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         if (const char *env = std::getenv("RIBBIT_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
     bool done = false;
     if (gpu_ssw && !h->dispatch.empty()) {
-        // All first-level alignment jobs of the record are set up at once (host threads), then:
-        //   * the LONG ones (queries beyond 512 bases: a few thousand per 64 Mbp, but each holds a wavefront for tens of
-        //     milliseconds, and the longest of a batch is that batch's critical path) go to the GPU as ONE batch on a helper
-        //     handle's streams, and the seeds they belong to are set aside;
-        //   * the rest goes through in slices of the seed list: a feeder thread runs a slice's striped passes and path searches
-        //     while the worker threads refine the previous slice with the results of its own batch.  Without the long jobs a
-        //     batch has no tail to wait for, so the slices can be small and the workers start early;
-        //   * the seeds set aside are refined last, when the long batch has landed, and their rows are put in their places.
+        // The pipeline (DESIGN.md 7 has the measurements behind every step):
+        //   * the seeds that can have a LONG job (queries beyond 512 bases) are set up first; their long jobs go to the GPU as ONE
+        //     batch on a helper handle's streams (a workgroup per alignment, ssw_group.hip) and those seeds are set aside; a seed
+        //     with a job no kernel takes (queries beyond 8192 bases) is refined on a few host threads from the start;
+        //   * the rest goes through in slices of the seed list.  A slice owns its jobs, motif strings and results; the main thread
+        //     sets the slices up one after the other on the host threads, a helper makes each slice's tables, and two feeder
+        //     threads (the second on another helper handle) take alternating slices as they are set up: striped passes and path
+        //     search on the GPU, the tails of one slice's launches behind the other's work;
+        //   * when all slices are set up the host threads refine them in order as their batches land, each slice with the
+        //     results of its own batch;
+        //   * the seeds set aside are refined last, longest first, when the long batch has landed, and all rows are put in place.
         // (Round 2 ran the long classes inside every slice: ~150 ms of tail per slice, which is why two slices were the optimum
         // and the workers sat idle for the whole first one -- tools/refine_slices_probe.sh.)
         const size_t n_seeds = h->dispatch.size();
