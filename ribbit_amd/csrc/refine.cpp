@@ -159,6 +159,15 @@ void discover_small_motifs(const Bases &b, int seed_start, int seq_len, int m, i
 // The same list from the GPU's records of seed i (small_motifs.hip): the early reports as they are, then the classes
 // that survive to the seed's end in the iteration order of the reference's unordered_map, which the keys' insertion
 // order (= order of first appearance = record order) determines.  False: the seed has no device result.
+// The records of seed i lie wherever the kernel's wavefronts happened to append them (an arena filled through one atomic
+// counter): a cache miss per seed for a loop that walks the seeds in order, 13.6 M times a chromosome in the job set-up and
+// again in the workers.  The head table IS in seed order, so the records of a seed a few places ahead can be asked for early.
+inline void prefetch_small_records(const SmallMotifTable *table, size_t i, size_t n) {
+    if (!table || !table->head || i >= n) return;
+    const int32_t *hd = table->head + 4 * i;
+    if (hd[3] == 0) __builtin_prefetch(table->records + 4 * (size_t)(uint32_t)hd[0], 0, 1);
+}
+
 bool small_motifs_from_table(const SmallMotifTable *table, size_t i, int min_len, int min_units,
                              std::vector<uint32_t> &classes, std::vector<int> &starts, std::vector<int> &ends) {
     if (!table || !table->head) return false;
@@ -280,13 +289,15 @@ int longest_run_host(const HostPlanes &hp, int mlen, int start, int end) {
 int usable_length_host(const HostPlanes &hp, int start, int end, int m) { return first_n_cut(hp.brk.data(), (int)hp.length, start, end, m); }
 
 namespace {
-thread_local double tl_build_join_ms = 0.0;      // profile: joining the chunks' jobs and pools, on the calling thread (sequential)
+thread_local double tl_build_join_ms = 0.0;      // profile: joining the chunks' jobs and pools
+thread_local double tl_build_par_ms = 0.0;       // profile: the chunks' parallel region (threads started to threads joined)
 void build_align_jobs_range(const Bases &b, const RibbitRefineParams &prm, const SeedVec &dispatch,
                             const int32_t *longest_runs, const int32_t *best_rows, size_t lo, size_t hi,
                             std::vector<RibbitAlignJob> &jobs, std::string &motif_pool, const SmallMotifTable *small) {
     std::vector<uint32_t> classes;
     std::vector<int> starts, ends;
     for (size_t i = lo; i < hi; ++i) {
+        prefetch_small_records(small, i + 12, dispatch.size());
         const RibbitSeed &seed = dispatch[i];
         const int m = seed.mlen;
         if (m > 10 && seed.end - seed.start < 0.9 * m) continue;                    // parse_seed.cpp:360
@@ -340,6 +351,7 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
     const unsigned threads = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads ? host_threads : 1, n / 1024 + 1));
     if (threads == 1) { build_align_jobs_range(b, prm, dispatch, longest_runs, best_rows, seed_lo, seed_hi, jobs, motif_pool, small); return; }
     // seeds are independent here: chunks on worker threads, concatenated in seed order with the motif offsets rebased
+    const auto tp0 = std::chrono::steady_clock::now();
     const size_t chunk = 2048, nchunks = (n + chunk - 1) / chunk;
     std::vector<std::vector<RibbitAlignJob>> part_jobs(nchunks);
     std::vector<std::string> part_pool(nchunks);
@@ -353,6 +365,7 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
     for (std::thread &th : pool) th.join();
     // the chunks' jobs and motif strings into place, on the threads again (one thread did this for a fifth of the set-up's time)
     const auto tj0 = std::chrono::steady_clock::now();
+    tl_build_par_ms += std::chrono::duration<double, std::milli>(tj0 - tp0).count();
     std::vector<size_t> job_at(nchunks + 1, 0), pool_at(nchunks + 1, 0);
     for (size_t c = 0; c < nchunks; ++c) { job_at[c + 1] = job_at[c] + part_jobs[c].size(); pool_at[c + 1] = pool_at[c] + part_pool[c].size(); }
     jobs.resize(job_at[nchunks]);
@@ -374,6 +387,7 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
 }
 
 double build_align_jobs_join_ms(bool reset) { const double v = tl_build_join_ms; if (reset) tl_build_join_ms = 0.0; return v; }
+double build_align_jobs_parallel_ms(bool reset) { const double v = tl_build_par_ms; if (reset) tl_build_par_ms = 0.0; return v; }
 
 void build_align_jobs_of(const HostPlanes &hp, const RibbitRefineParams &prm, const SeedVec &dispatch, const int32_t *longest_runs,
                          const int32_t *best_rows, const std::vector<uint32_t> &which, std::vector<RibbitAlignJob> &jobs, std::string &motif_pool,
@@ -735,6 +749,7 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
             seg_start = next_start;
         };
         for (size_t i = lo; i < hi; ++i) {
+            prefetch_small_records(small, i + 12, dispatch.size());
             if (skip && skip[i]) { close_segment(i + 1); continue; }
             one_seed(i, w);
         }

@@ -37,6 +37,7 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
 // The same for the listed seeds only (increasing indices into dispatch); a seed's jobs are the same, in the same order, as in any other call
 // profile: milliseconds the calling thread's build_align_jobs calls spent joining their chunks' results (sequential part)
 double build_align_jobs_join_ms(bool reset);
+double build_align_jobs_parallel_ms(bool reset);     // ... in their chunks' parallel region
 void build_align_jobs_of(const HostPlanes &hp, const RibbitRefineParams &prm, const SeedVec &dispatch, const int32_t *longest_runs,
                          const int32_t *best_rows, const std::vector<uint32_t> &which, std::vector<RibbitAlignJob> &jobs, std::string &motif_pool,
                          unsigned host_threads, const SmallMotifTable *small);
