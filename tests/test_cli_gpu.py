@@ -78,8 +78,8 @@ def test_cli_records_dealt_over_several_devices(tmp_path):
 
 @pytest.mark.parametrize("label,m_lo,m_hi", [("edge_cases", 2, 12), ("fuzz_batch", 2, 40)])
 def test_cli_with_every_alignment_forced_onto_the_gpu(tmp_path, label, m_lo, m_hi):
-    """RIBBIT_GPU_SSW=1: the alignments of EVERY record go through the GPU batches (by default only records with two
-    million dispatched seeds do).  Edge cases (empty-ish records, N blocks, runs at both record ends) and one batch of
+    """RIBBIT_GPU_SSW=1: the alignments of EVERY record go through the GPU batches (by default only records with 400,000
+    dispatched seeds or more do).  Edge cases (empty-ish records, N blocks, runs at both record ends) and one batch of
     fuzz records, BED against the oracle pipeline."""
     if label == "edge_cases":
         records = [(n, s) for n, s, _, _ in edge_cases() if len(s) > 0]
@@ -94,6 +94,39 @@ def test_cli_with_every_alignment_forced_onto_the_gpu(tmp_path, label, m_lo, m_h
     assert r.returncode == 0, r.stderr[-2000:]
     assert bed.read_text() == _oracle_bed(records, m_lo, m_hi)
     assert "alignment jobs (" in r.stderr, "no record took the GPU alignment path"
+
+
+def test_the_comparison_switches_of_the_alignment_pipeline_give_the_same_bed(tmp_path):
+    """The pipeline keeps two switches for measuring it against its older forms: RIBBIT_SSW_FEEDERS=1 (one feeder thread instead
+    of two on alternating slices) and RIBBIT_SSW_GROUP=0 (the long classes on one wavefront per alignment instead of a workgroup;
+    queries beyond 4096 bases then stay on the host).  They are read once per process, so this goes through the command line: one
+    record with long repeats (alignments of every size class, several slices), alignments forced onto the GPU, BED identical under
+    every setting and equal to the oracle's."""
+    import numpy as np
+    from ribbit_amd.simulate import simulate_sequence
+    seq, _ = simulate_sequence(1_500_000, 23, 2, 60)
+    rs = np.random.RandomState(5)
+    long_repeats = b""
+    for unit_len, copies in ((7, 300), (23, 180), (41, 150), (13, 500)):        # queries of 2..6.5 kb: the three workgroup classes
+        unit = bytes(rs.choice(list(b"ACGT"), unit_len).astype(np.uint8))
+        body = bytearray(unit * copies)
+        for k in rs.choice(len(body), len(body) // 40, replace=False):          # a mutation every 40 bases
+            body[k] = b"ACGT"[(b"ACGT".index(body[k]) + 1 + int(rs.randint(3))) % 4]
+        long_repeats += bytes(rs.choice(list(b"ACGT"), 500).astype(np.uint8)) + bytes(body)
+    records = [("long_repeats", seq[:700_000] + long_repeats + seq[700_000:])]
+    fa = tmp_path / "in.fa"
+    write_fasta(str(fa), records)
+    beds = {}
+    for label, env in (("default", {}), ("one_feeder", {"RIBBIT_SSW_FEEDERS": "1"}), ("wavefront_kernels", {"RIBBIT_SSW_GROUP": "0"}),
+                       ("both", {"RIBBIT_SSW_FEEDERS": "1", "RIBBIT_SSW_GROUP": "0"})):
+        bed = tmp_path / f"{label}.bed"
+        r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "60"], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, RIBBIT_GPU_SSW="1", RIBBIT_SSW_SLICES="5", RIBBIT_PROFILE="1", **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "alignment jobs (" in r.stderr and "5 slices" in r.stderr, r.stderr[-1500:]
+        beds[label] = bed.read_text()
+    assert beds["default"] == _oracle_bed(records, 2, 60)
+    assert all(b == beds["default"] for b in beds.values()), [k for k, b in beds.items() if b != beds["default"]]
 
 
 def test_cli_long_reads_at_M_500(tmp_path):
