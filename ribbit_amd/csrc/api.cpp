@@ -2173,13 +2173,6 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         // test's arithmetic, not in the result -- its seed is aligned on the host at the end
         std::vector<uint32_t> stragglers;
         size_t n_jobs = 0;
-        rb::build_align_jobs_join_ms(true);
-        rb::build_align_jobs_parallel_ms(true);
-        auto build_slice = [&](size_t c) {
-            Slice &sl = slices[c];
-            rb::build_align_jobs(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sl.jobs, sl.pool, threads, sl.lo, sl.hi, &small);
-            n_jobs += sl.jobs.size();
-        };
         // a slice's tables: first job of every seed, the results' places, the safety net.  Needed when its batch has landed, not
         // before: made by a helper thread of their own, neither between two slices' set-ups on the main thread (56 ms of the
         // set-up's 400 at chromosome-1 size) nor by the feeder (whose slices the workers then waited for)
@@ -2267,14 +2260,19 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         struct Feeder2Guard { std::atomic<bool> &stop; std::condition_variable &cv; std::thread &t; ~Feeder2Guard() { stop = true; cv.notify_all(); if (t.joinable()) t.join(); } } feeder2_guard{stop, cv, feeder2};
         feeder = std::thread([&]() { feeder_loop(0, h); });
         if (n_feeders == 2) feeder2 = std::thread([&]() { feeder_loop(1, h->aux2); });
-        for (size_t c = 0; c < n_slices; ++c) {
-            build_slice(c);
-            { std::lock_guard<std::mutex> lk(mu); slices[c].built = true; }
-            cv.notify_all();
+        {
+            // all slices in one parallel region (refine.cpp): a slice is handed over by the thread that finished its last chunk
+            std::vector<std::pair<size_t, size_t>> bounds(n_slices);
+            for (size_t c = 0; c < n_slices; ++c) bounds[c] = {slices[c].lo, slices[c].hi};
+            rb::build_align_jobs_slices(h->host, *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), threads, &small, bounds,
+                                        [&](size_t c, std::vector<RibbitAlignJob> &&jobs, std::string &&pool) {
+                                            slices[c].jobs = std::move(jobs);
+                                            slices[c].pool = std::move(pool);
+                                            { std::lock_guard<std::mutex> lk(mu); n_jobs += slices[c].jobs.size(); slices[c].built = true; }
+                                            cv.notify_all();
+                                        });
         }
         const double t_setup = now_ms() - t_setup0;
-        const double t_setup_join = rb::build_align_jobs_join_ms(true);
-        const double t_setup_par = rb::build_align_jobs_parallel_ms(true);
         bool order_dependent = false;
         double t_wait = 0, t_passes = 0, t_paths = 0, t_feed = 0, t_work = 0, t_later = 0, t_join = 0;
         std::vector<rb::BedPiece> pieces;
@@ -2368,11 +2366,11 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             for (const rb::BedPiece &pc : pieces) h->bed += pc.text;
         } else h->bed.clear();                         // an empty query somewhere (or no batches): the whole record in one call (below)
         t_join = now_ms() - tj0;
-        if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs (%zu long ones in their own batch: %.1f ms, set up first in %.1f ms; %zu seeds set aside), set-up in all %.1f ms (of it the chunks' parallel regions %.1f ms, joining the chunks' jobs %.1f ms); %zu slices: "
+        if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs (%zu long ones in their own batch: %.1f ms, set up first in %.1f ms; %zu seeds set aside), set-up in all %.1f ms; %zu slices: "
                                   "feeder %.1f ms in all (GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms); workers: %.1f ms in their calls, waited %.1f ms "
                                   "for slices, %.1f ms for the long batch; seeds set aside for it %.1f ms; %zu seeds with jobs beyond the kernels' reach refined on the host beside all that in %.1f ms; "
                                   "rows put together %.1f ms; since the call began %.1f ms\n",
-                                  n_jobs, long_jobs.size(), t_long, t_setup_long, later.size(), t_setup, t_setup_par, t_setup_join, n_slices, t_feed, t_passes, t_paths, t_work, t_wait, t_wait_long, t_later, giants.size(), t_later_thread, t_join,
+                                  n_jobs, long_jobs.size(), t_long, t_setup_long, later.size(), t_setup, n_slices, t_feed, t_passes, t_paths, t_work, t_wait, t_wait_long, t_later, giants.size(), t_later_thread, t_join,
                                   now_ms() - t_begin);
         add_ms(t_jobs_us, t_wait + t_wait_long);
     }

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <sstream>
 #include <cstring>
+#include <functional>
 #include <thread>
 #include <unordered_map>
 
@@ -384,6 +385,72 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
     place();
     for (std::thread &th : pool) th.join();
     tl_build_join_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj0).count();
+}
+
+// The jobs of several slices of the seed list in ONE parallel region: the chunks of all slices are handed out in order to the
+// same threads, and the thread that finishes a slice's last chunk puts that slice's jobs and motif strings in place and hands
+// them to `done` (called on that thread; slices are done roughly, not strictly, in order) while the others go on with the next
+// slice's chunks.  Slice by slice through build_align_jobs this was two teams of threads and two barriers per slice: 512
+// thread starts and a third of the set-up's time outside its parallel work at chromosome-1 size.
+void build_align_jobs_slices(const HostPlanes &hp, const RibbitRefineParams &prm, const SeedVec &dispatch, const int32_t *longest_runs,
+                             const int32_t *best_rows, unsigned host_threads, const SmallMotifTable *small,
+                             const std::vector<std::pair<size_t, size_t>> &bounds,
+                             const std::function<void(size_t, std::vector<RibbitAlignJob> &&, std::string &&)> &done) {
+    const Bases b(hp, host_threads);
+    constexpr size_t chunk = 2048;
+    struct Slice {
+        size_t lo = 0, hi = 0, first_chunk = 0, nchunks = 0;
+        std::vector<std::vector<RibbitAlignJob>> jobs;
+        std::vector<std::string> pool;
+        std::atomic<size_t> left{0};
+    };
+    std::vector<Slice> sl(bounds.size());
+    size_t total = 0;
+    for (size_t c = 0; c < bounds.size(); ++c) {
+        sl[c].lo = std::min(bounds[c].first, dispatch.size());
+        sl[c].hi = std::max(sl[c].lo, std::min(bounds[c].second, dispatch.size()));
+        sl[c].first_chunk = total;
+        sl[c].nchunks = (sl[c].hi - sl[c].lo + chunk - 1) / chunk;
+        sl[c].jobs.resize(sl[c].nchunks);
+        sl[c].pool.resize(sl[c].nchunks);
+        sl[c].left = sl[c].nchunks;
+        total += sl[c].nchunks;
+    }
+    auto finish = [&](size_t c) {
+        Slice &s = sl[c];
+        std::vector<RibbitAlignJob> jobs;
+        std::string pool;
+        size_t nj = 0, np = 0;
+        for (size_t k = 0; k < s.nchunks; ++k) { nj += s.jobs[k].size(); np += s.pool[k].size(); }
+        jobs.reserve(nj);
+        pool.reserve(np);
+        for (size_t k = 0; k < s.nchunks; ++k) {
+            const int32_t base = (int32_t)pool.size();
+            for (RibbitAlignJob j : s.jobs[k]) { j.motif_offset += base; jobs.push_back(j); }
+            pool += s.pool[k];
+            std::vector<RibbitAlignJob>().swap(s.jobs[k]);
+            std::string().swap(s.pool[k]);
+        }
+        done(c, std::move(jobs), std::move(pool));
+    };
+    for (size_t c = 0; c < sl.size(); ++c)
+        if (sl[c].nchunks == 0) finish(c);            // an empty slice is done at once
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        size_t c = 0;
+        for (size_t id; (id = next.fetch_add(1)) < total;) {
+            while (c + 1 < sl.size() && id >= sl[c].first_chunk + sl[c].nchunks) ++c;      // ids only grow for one thread
+            Slice &s = sl[c];
+            const size_t k = id - s.first_chunk;
+            build_align_jobs_range(b, prm, dispatch, longest_runs, best_rows, s.lo + k * chunk, std::min(s.hi, s.lo + (k + 1) * chunk), s.jobs[k], s.pool[k], small);
+            if (s.left.fetch_sub(1) == 1) finish(c);
+        }
+    };
+    const unsigned threads = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads ? host_threads : 1, total));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread &th : pool) th.join();
 }
 
 double build_align_jobs_join_ms(bool reset) { const double v = tl_build_join_ms; if (reset) tl_build_join_ms = 0.0; return v; }

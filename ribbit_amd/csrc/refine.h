@@ -8,6 +8,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,12 @@ void build_align_jobs(const HostPlanes &hp, const RibbitRefineParams &prm, const
 // profile: milliseconds the calling thread's build_align_jobs calls spent joining their chunks' results (sequential part)
 double build_align_jobs_join_ms(bool reset);
 double build_align_jobs_parallel_ms(bool reset);     // ... in their chunks' parallel region
+// ... of several slices of the seed list (bounds[c] = [lo, hi) of slice c) in one parallel region; done(c, jobs, motif_pool) is called,
+// on one of the worker threads, as soon as slice c is complete (roughly in order)
+void build_align_jobs_slices(const HostPlanes &hp, const RibbitRefineParams &prm, const SeedVec &dispatch, const int32_t *longest_runs,
+                             const int32_t *best_rows, unsigned host_threads, const SmallMotifTable *small,
+                             const std::vector<std::pair<size_t, size_t>> &bounds,
+                             const std::function<void(size_t, std::vector<RibbitAlignJob> &&, std::string &&)> &done);
 void build_align_jobs_of(const HostPlanes &hp, const RibbitRefineParams &prm, const SeedVec &dispatch, const int32_t *longest_runs,
                          const int32_t *best_rows, const std::vector<uint32_t> &which, std::vector<RibbitAlignJob> &jobs, std::string &motif_pool,
                          unsigned host_threads, const SmallMotifTable *small);
