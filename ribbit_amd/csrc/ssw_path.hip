@@ -37,16 +37,29 @@ __device__ __forceinline__ int path_code(uint8_t c) {      // kBaseTranslation (
     }
 }
 
-// exclusive prefix maximum over the 64 lanes (lane 0 receives `identity`)
+template <int CTRL>
+__device__ __forceinline__ int pdpp(int v, int old) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
+
+// exclusive prefix maximum over the 64 lanes (lane 0 receives `identity`).  Inside a row of 16 lanes by DPP row shifts (lanes a
+// shift does not reach keep their value), across the four rows through the rows' last lanes -- register operations, where six
+// __shfl_up steps were six dependent trips through the LDS crossbar in every row of every alignment.
 __device__ __forceinline__ int wave_exclusive_max(int v, int identity, int lane) {
     int x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int y = __shfl_up(x, d);
-        if (lane >= d) x = max(x, y);
-    }
-    const int prev = __shfl_up(x, 1);
+    x = max(x, pdpp<0x111>(x, x));      // row_shr:1
+    x = max(x, pdpp<0x112>(x, x));      // row_shr:2
+    x = max(x, pdpp<0x114>(x, x));      // row_shr:4
+    x = max(x, pdpp<0x118>(x, x));      // row_shr:8: inclusive maximum inside the row
+    const int r0 = __builtin_amdgcn_readlane(x, 15), r1 = __builtin_amdgcn_readlane(x, 31), r2 = __builtin_amdgcn_readlane(x, 47);
+    const int row = lane >> 4;
+    const int before_row = row == 0 ? INT32_MIN : row == 1 ? r0 : row == 2 ? max(r0, r1) : max(max(r0, r1), r2);
+    x = max(x, before_row);                                 // inclusive over the wavefront
+    const int prev = pdpp<0x138>(x, identity);              // wave_shr:1 (lane 0 keeps `identity`)
     return lane == 0 ? identity : prev;
+}
+// the value of the lane below (lane 0 receives `first`)
+__device__ __forceinline__ int from_lane_below(int v, int first, int lane) {
+    const int prev = pdpp<0x138>(v, first);                 // wave_shr:1
+    return lane == 0 ? first : prev;
 }
 
 }  // namespace
@@ -79,6 +92,11 @@ __global__ __launch_bounds__(64) void ssw_path_kernel(const uint8_t *__restrict_
     for (int i = lane; i < 3 * (slots + 1); i += 64) lds[i] = 0;
     __builtin_amdgcn_wave_barrier();
     uint8_t *cell = cells + cell_off[t];
+    // the reference base of column j is motif[(ref_begin + j) % atom]: one modulo per lane here instead of one per cell (a lane's
+    // column is first + k0 + lane, and first and k0 are uniform
+    // ... and the uniform part is carried from row to row: `first` grows by one per row once the row index passes the band)
+    const int lane_mod = lane % atom, chunk_mod = 64 % atom;
+    int row_mod = ref_begin % atom;            // (ref_begin + first) % atom of the current row
     const uint8_t *q_at = ascii + qstart + query_begin;      // query position i of the rectangle
     int best = 0;
     for (int i = 0; i < read_len; ++i) {
@@ -91,7 +109,9 @@ __global__ __launch_bounds__(64) void ssw_path_kernel(const uint8_t *__restrict_
         uint8_t *row = cell + (size_t)row_cells * i;
         int h_left = 0, f_left = 0;            // h and f of the cell left of the chunk (out of band: 0, 0)
         const int n_in_row = last - first + 1;
-        for (int k0 = 0; k0 < n_in_row; k0 += 64) {
+        if (i > band) { if (++row_mod == atom) row_mod = 0; }   // first = i - band is one more than in the row above
+        int base_mod = row_mod;                                 // (ref_begin + first + k0) % atom, uniform
+        for (int k0 = 0; k0 < n_in_row; k0 += 64, base_mod = base_mod + chunk_mod >= atom ? base_mod + chunk_mod - atom : base_mod + chunk_mod) {
             const int k = k0 + lane;
             const bool live = k < n_in_row;
             const int j = first + k, u = k + 1;
@@ -103,7 +123,9 @@ __global__ __launch_bounds__(64) void ssw_path_kernel(const uint8_t *__restrict_
                 const int e_ext = i == 0 ? -GAP_E : e_above[above] - GAP_E;
                 e = max(e_open, e_ext);
                 if (e_open > e_ext) code |= E_OPENS;
-                const int rc = path_code(motif[(ref_begin + j) % atom]);
+                int jm = base_mod + lane_mod;
+                if (jm >= atom) jm -= atom;
+                const int rc = path_code(motif[jm]);
                 diag = h_above[above - 1] + ((rc == qc && rc < 4) ? 2 : -2);
                 g = max(max(e, 0), diag);
             }
@@ -115,8 +137,7 @@ __global__ __launch_bounds__(64) void ssw_path_kernel(const uint8_t *__restrict_
             const int f = max(f_first, before) - lane * GAP_E;
             const int h = max(g, f);
             // neighbours for the F direction bit
-            int h_prev = __shfl_up(h, 1), f_prev = __shfl_up(f, 1);
-            if (lane == 0) { h_prev = h_left; f_prev = f_left; }
+            const int h_prev = from_lane_below(h, h_left, lane), f_prev = from_lane_below(f, f_left, lane);
             if (live) {
                 if (h_prev - GAP_O > f_prev - GAP_E) code |= F_OPENS;
                 const int e0 = max(e, 0), f0 = max(f, 0);
@@ -128,9 +149,9 @@ __global__ __launch_bounds__(64) void ssw_path_kernel(const uint8_t *__restrict_
                 best = max(best, h);
             }
             // carry to the next chunk: the last live lane of this one
-            const int last_lane = min(63, n_in_row - 1 - k0);
-            h_left = __shfl(h, last_lane);
-            f_left = __shfl(f, last_lane);
+            const int last_lane = __builtin_amdgcn_readfirstlane(min(63, n_in_row - 1 - k0));
+            h_left = __builtin_amdgcn_readlane(h, last_lane);
+            f_left = __builtin_amdgcn_readlane(f, last_lane);
         }
         for (int k = n_in_row + lane; k < row_cells; k += 64) row[k] = NO_CELL;      // columns past the reference
         __builtin_amdgcn_wave_barrier();
