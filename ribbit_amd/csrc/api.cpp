@@ -1604,8 +1604,20 @@ static int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, 
     std::vector<uint64_t> cell_off, ops_off;
     std::vector<Open> next;
     constexpr uint64_t ARENA = (uint64_t)6 << 30;            // cell bytes per launch
+    // Alignments with a narrow band (nineteen in twenty) run four to a wavefront (ssw_path4_kernel): they come first among a
+    // round's items, in seed order, the others behind them, in seed order too; RIBBIT_PATH_PACKED=0: all on the one-per-wavefront
+    // kernel, as until the end of round 3.
+    static const bool packed_paths = !(std::getenv("RIBBIT_PATH_PACKED") && std::atoi(std::getenv("RIBBIT_PATH_PACKED")) == 0);
     while (!open.empty()) {
         // one launch per arena-full of items
+        size_t n_narrow_all = 0;
+        if (packed_paths) {
+            next.clear();
+            for (const Open &o : open) if (o.band <= rb::SSW_PATH_NARROW_BAND) next.push_back(o);
+            n_narrow_all = next.size();
+            for (const Open &o : open) if (o.band > rb::SSW_PATH_NARROW_BAND) next.push_back(o);
+            open.swap(next);
+        }
         size_t at = 0;
         next.clear();
         while (at < open.size()) {
@@ -1621,9 +1633,10 @@ static int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, 
                 items.push_back(open[at].job); items.push_back(open[at].band); items.push_back(0); items.push_back(0);
                 cell_off.push_back(cells); ops_off.push_back(ops);
                 cells += need; ops += (uint64_t)(rl + ql + 2);
-                max_band = std::max(max_band, open[at].band);
+                if (at >= n_narrow_all) max_band = std::max(max_band, open[at].band);        // (the LDS of the one-per-wavefront launch)
             }
             const size_t ni = at - first;
+            const size_t n_narrow = first < n_narrow_all ? std::min(ni, n_narrow_all - first) : 0;
             if ((rc = h->d_path_items.ensure(items.size())) || (rc = h->d_path_cell_off.ensure(ni)) || (rc = h->d_path_ops_off.ensure(ni)) ||
                 (rc = h->d_path_cells.ensure((size_t)std::max<uint64_t>(cells, 16))) || (rc = h->d_path_scratch.ensure((size_t)ops)))
                 return rc;
@@ -1632,7 +1645,7 @@ static int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, 
             HIP_TRY(hipMemcpyAsync(h->d_path_ops_off.p, ops_off.data(), ni * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
             rb::launch_ssw_paths(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_out.p, h->d_path_items.p, h->d_path_cell_off.p,
                                  h->d_path_ops_off.p, (int)ni, max_band, h->d_path_cells.p, h->d_path_scratch.p, h->d_path_ops.p, (uint32_t)path_cap,
-                                 h->d_path_count.p, h->d_path_result.p, h->stream);
+                                 h->d_path_count.p, h->d_path_result.p, h->stream, (int)n_narrow);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(h->stream));       // the item arrays above are reused by the next launch
         }

@@ -190,7 +190,10 @@ constexpr int SSW_PATH_MAX_BAND = 2048;
 void launch_ssw_paths(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs, const int32_t *ends,
                       const int32_t *items, const uint64_t *cell_off, const uint64_t *ops_off, int n_items, int max_band,
                       uint8_t *cells, uint32_t *ops, uint32_t *path_ops, uint32_t path_cap, uint32_t *path_count, int32_t *result,
-                      hipStream_t stream);
+                      hipStream_t stream, int n_narrow = 0);
+// n_narrow: the first n_narrow items have a band of at most SSW_PATH_NARROW_BAND and run four to a wavefront (ssw_path4_kernel);
+// max_band then is the largest band among the OTHERS.
+constexpr int SSW_PATH_NARROW_BAND = 7;
 
 // profiling aid: reads nwords dwords of src with one coalesced dword per lane (known byte count)
 void launch_calib_stream_read(const uint32_t *src, int64_t nwords, uint32_t *sink, hipStream_t stream);

@@ -62,6 +62,48 @@ __device__ __forceinline__ int from_lane_below(int v, int first, int lane) {
     return lane == 0 ? first : prev;
 }
 
+// The walk back from the end-point corner (ssw.c:731-775; same walker as the host twin), by ONE lane: the path as run-length
+// operations, written backwards into the item's scratch `out` (ref_len + read_len + 2 entries) and appended to path_ops.
+__device__ __forceinline__ void walk_back(const uint8_t *cell, int row_cells, int band, int ref_len, int read_len, uint32_t *out,
+                                          uint32_t *__restrict__ path_ops, uint32_t path_cap, uint32_t *__restrict__ path_count, int32_t *res) {
+    const int cap = ref_len + read_len + 2;
+    int at_out = cap;                          // operations are written from the end backwards
+    const long n_cells = (long)row_cells * read_len;
+    int i = read_len - 1, j = ref_len - 1, count = 0;
+    int state = 2;                             // 0 in E, 1 in F, 2 in H
+    int op = 0, prev = 0;                      // 0 'M', 1 'I', 2 'D'
+    bool ok = true;
+    auto push = [&](int o, int n) { if (at_out > 0) out[--at_out] = ((uint32_t)n << 2) | (uint32_t)o; else ok = false; };
+    while (i >= 0 && j > 0) {
+        const long at = (long)row_cells * i + (j - max(0, i - band));
+        if (at < 0 || at >= n_cells) { ok = false; break; }
+        const uint8_t code = cell[at];
+        if (code == NO_CELL) { ok = false; break; }
+        const int via = state != 2 ? state : ((code & SRC_MASK) == FROM_DIAG ? 2 : (code & SRC_MASK) == FROM_E ? 0 : 1);
+        if (via == 2) { --i; --j; state = 2; op = 0; }
+        else if (via == 0) { --i; state = (code & E_OPENS) ? 2 : 0; op = 1; }
+        else { --j; state = (code & F_OPENS) ? 2 : 1; op = 2; }
+        if (op == prev) ++count;
+        else { push(prev, count); prev = op; count = 1; }
+    }
+    if (ok) {
+        // the library's tail: the operation in progress is closed, and a path that ends in a gap gets one more 'M'
+        if (op == 0) push(0, count + 1);
+        else { push(op, count); push(0, 1); }
+    }
+    uint32_t base = 0;
+    const uint32_t n_ops = ok ? (uint32_t)(cap - at_out) : 0u;
+    if (n_ops) {
+        base = atomicAdd(path_count, n_ops);
+        if ((uint64_t)base + n_ops <= path_cap)
+            for (uint32_t k = 0; k < n_ops; ++k) path_ops[base + k] = out[at_out + (int)k];
+    }
+    res[0] = ok ? 0 : 1;
+    res[1] = band;
+    res[2] = (int32_t)base;
+    res[3] = (int32_t)n_ops;
+}
+
 }  // namespace
 
 // items[4*t .. +4) = {job, band, unused, unused}; cell_off[t] (bytes into `cells`), ops_off[t] (entries into the round's
@@ -169,54 +211,130 @@ __global__ __launch_bounds__(64) void ssw_path_kernel(const uint8_t *__restrict_
     }
     __threadfence();                           // the cells this wave wrote, visible to its own loads below
     if (lane != 0) return;
-    // walk back from the end-point corner (ssw.c:731-775; same walker as the host twin)
-    uint32_t *out = ops + ops_off[t];
-    const int cap = ref_len + read_len + 2;
-    int at_out = cap;                          // operations are written from the end backwards
-    const long n_cells = (long)row_cells * read_len;
-    int i = read_len - 1, j = ref_len - 1, count = 0;
-    int state = 2;                             // 0 in E, 1 in F, 2 in H
-    int op = 0, prev = 0;                      // 0 'M', 1 'I', 2 'D'
-    bool ok = true;
-    auto push = [&](int o, int n) { if (at_out > 0) out[--at_out] = ((uint32_t)n << 2) | (uint32_t)o; else ok = false; };
-    while (i >= 0 && j > 0) {
-        const long at = (long)row_cells * i + (j - max(0, i - band));
-        if (at < 0 || at >= n_cells) { ok = false; break; }
-        const uint8_t code = cell[at];
-        if (code == NO_CELL) { ok = false; break; }
-        const int via = state != 2 ? state : ((code & SRC_MASK) == FROM_DIAG ? 2 : (code & SRC_MASK) == FROM_E ? 0 : 1);
-        if (via == 2) { --i; --j; state = 2; op = 0; }
-        else if (via == 0) { --i; state = (code & E_OPENS) ? 2 : 0; op = 1; }
-        else { --j; state = (code & F_OPENS) ? 2 : 1; op = 2; }
-        if (op == prev) ++count;
-        else { push(prev, count); prev = op; count = 1; }
-    }
-    if (ok) {
-        // the library's tail: the operation in progress is closed, and a path that ends in a gap gets one more 'M'
-        if (op == 0) push(0, count + 1);
-        else { push(op, count); push(0, 1); }
-    }
-    uint32_t base = 0;
-    const uint32_t n_ops = ok ? (uint32_t)(cap - at_out) : 0u;
-    if (n_ops) {
-        base = atomicAdd(path_count, n_ops);
-        if ((uint64_t)base + n_ops <= path_cap)
-            for (uint32_t k = 0; k < n_ops; ++k) path_ops[base + k] = out[at_out + (int)k];
-    }
-    res[0] = ok ? 0 : 1;
-    res[1] = band;
-    res[2] = (int32_t)base;
-    res[3] = (int32_t)n_ops;
+    walk_back(cell, row_cells, band, ref_len, read_len, ops + ops_off[t], path_ops, path_cap, path_count, res);
 }
 
+// The same search for alignments with a NARROW band (at most SSW_PATH_NARROW_BAND cells either side: a row of at most 15 cells),
+// four to a wavefront: an alignment has one DPP row of 16 lanes, so the scan along its row is four row shifts with nothing to
+// carry between rows or chunks, and four lanes walk their paths back at once.  Nineteen alignments in twenty are of this kind,
+// and with a wavefront each they used fewer than a quarter of its lanes (the kernel above: bound by the throughput of a slice's
+// first launch).  Items as above; the four of a wavefront run for as many rows as the longest of them has.
+__global__ __launch_bounds__(64) void ssw_path4_kernel(const uint8_t *__restrict__ ascii, int64_t length, const uint8_t *__restrict__ motif_pool,
+                                                       const int32_t *__restrict__ jobs /* 9 ints each */, const int32_t *__restrict__ ends /* 8 ints each */,
+                                                       const int32_t *__restrict__ items, const uint64_t *__restrict__ cell_off,
+                                                       const uint64_t *__restrict__ ops_off, int n_items, uint8_t *__restrict__ cells,
+                                                       uint32_t *__restrict__ ops, uint32_t *__restrict__ path_ops, uint32_t path_cap,
+                                                       uint32_t *__restrict__ path_count, int32_t *__restrict__ result) {
+    constexpr int SLOTS = 2 * SSW_PATH_NARROW_BAND + 1 + 2;          // the widest row + its two edge slots
+    __shared__ int32_t lds4[4][3 * (SLOTS + 1)];
+    const int lane = (int)threadIdx.x, grp = lane >> 4, gl = lane & 15;
+    const int t = 4 * (int)blockIdx.x + grp;
+    const bool have = t < n_items;
+    int job = 0, band = 1, atom = 1, qstart = 0, score = 0, ref_begin = 0, query_begin = 0, ref_len = 0, read_len = 0;
+    const uint8_t *motif = motif_pool;
+    if (have) {
+        job = items[4 * t]; band = items[4 * t + 1];
+        const int32_t *jb = jobs + 9 * (int64_t)job;
+        const int32_t *en = ends + 8 * (int64_t)job;
+        atom = jb[3];
+        qstart = jb[4] < 0 ? 0 : jb[4];            // the host's slice(): a negative start clamps
+        motif = motif_pool + jb[8];
+        score = en[0]; ref_begin = en[5]; query_begin = en[6];
+        ref_len = en[1] - en[5] + 1; read_len = en[2] - en[6] + 1;
+    }
+    const int row_cells = 2 * band + 1, slots = row_cells + 2;
+    int32_t *h_above = lds4[grp], *e_above = h_above + (SLOTS + 1), *h_row = e_above + (SLOTS + 1);
+    for (int i = gl; i < 3 * (SLOTS + 1); i += 16) lds4[grp][i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    uint8_t *cell = have ? cells + cell_off[t] : cells;
+    const uint8_t *q_at = ascii + qstart + query_begin;
+    const int lane_mod = gl % max(atom, 1);
+    int row_mod = ref_begin % max(atom, 1);
+    const int my_rows = have ? read_len : 0;
+    const int most_rows = max(max(__builtin_amdgcn_readlane(my_rows, 0), __builtin_amdgcn_readlane(my_rows, 16)),
+                              max(__builtin_amdgcn_readlane(my_rows, 32), __builtin_amdgcn_readlane(my_rows, 48)));
+    int best = 0;
+    for (int i = 0; i < most_rows; ++i) {
+        const bool act = i < my_rows;                  // uniform over the 16 lanes of an alignment
+        const int first = max(0, i - band), last = min(ref_len - 1, i + band);
+        const int first_above = max(0, i - 1 - band);
+        const int edge = min(last + 1, slots - 1);
+        if (act && gl == 0) { h_above[0] = 0; e_above[0] = 0; h_above[edge] = 0; e_above[edge] = 0; h_row[0] = 0; }
+        __builtin_amdgcn_wave_barrier();
+        if (act && i > band) { if (++row_mod == atom) row_mod = 0; }
+        const int n_in_row = last - first + 1;         // <= row_cells <= 15
+        const bool live = act && gl < n_in_row;
+        const int j = first + gl, u = gl + 1;
+        const int above = j - first_above + 1;
+        int e = 0, g = 0, diag = 0;
+        uint8_t code = 0;
+        if (live) {
+            const int qc = path_code(q_at[i]);
+            const int e_open = i == 0 ? -GAP_O : h_above[above] - GAP_O;
+            const int e_ext = i == 0 ? -GAP_E : e_above[above] - GAP_E;
+            e = max(e_open, e_ext);
+            if (e_open > e_ext) code |= E_OPENS;
+            int jm = row_mod + lane_mod;
+            if (jm >= atom) jm -= atom;
+            const int rc = path_code(motif[jm]);
+            diag = h_above[above - 1] + ((rc == qc && rc < 4) ? 2 : -2);
+            g = max(max(e, 0), diag);
+        }
+        // F along the row, inside the alignment's 16 lanes: the cell left of the row is out of band (h = f = 0)
+        const int f_first = max(0 - GAP_O, 0 - GAP_E);
+        int x = live ? g - GAP_O + (gl + 1) * GAP_E : INT32_MIN / 2;
+        x = max(x, pdpp<0x111>(x, x));
+        x = max(x, pdpp<0x112>(x, x));
+        x = max(x, pdpp<0x114>(x, x));
+        x = max(x, pdpp<0x118>(x, x));
+        const int before = pdpp<0x111>(x, INT32_MIN / 2);          // row_shr:1: the first lane of a row keeps the identity
+        const int f = max(f_first, before) - gl * GAP_E;
+        const int h = max(g, f);
+        const int h_prev = pdpp<0x111>(h, 0), f_prev = pdpp<0x111>(f, 0);      // left of the first cell: 0, 0
+        if (live) {
+            if (h_prev - GAP_O > f_prev - GAP_E) code |= F_OPENS;
+            const int e0 = max(e, 0), f0 = max(f, 0);
+            const int gap = max(e0, f0);
+            code |= gap <= diag ? FROM_DIAG : (e0 > f0 ? FROM_E : FROM_F);
+            uint8_t *row = cell + (size_t)row_cells * i;
+            row[gl] = code;
+            e_above[u] = e;
+            h_row[u] = h;
+            best = max(best, h);
+        }
+        if (act && gl >= n_in_row && gl < row_cells) cell[(size_t)row_cells * i + gl] = NO_CELL;      // columns past the reference
+        __builtin_amdgcn_wave_barrier();
+        if (live) h_above[u] = h_row[u];
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the alignment's maximum of best: over its 16 lanes
+    best = max(best, pdpp<0x128>(best, best));       // row_ror:8
+    best = max(best, pdpp<0x124>(best, best));       // row_ror:4
+    best = max(best, pdpp<0x122>(best, best));       // row_ror:2
+    best = max(best, pdpp<0x121>(best, best));       // row_ror:1
+    __threadfence();                                 // the cells this wavefront wrote, visible to its own loads below
+    if (!have || gl != 0) return;
+    const int longest = max(ref_len, read_len);
+    int32_t *res = result + 4 * (int64_t)job;
+    if (best < score && band * 2 <= longest) { res[0] = 2; res[1] = band; res[2] = 0; res[3] = 0; return; }
+    walk_back(cell, row_cells, band, ref_len, read_len, ops + ops_off[t], path_ops, path_cap, path_count, res);
+}
+
+// n_narrow: the first n_narrow items have a band of at most SSW_PATH_NARROW_BAND (four to a wavefront); max_band: of the others
 void launch_ssw_paths(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs, const int32_t *ends,
                       const int32_t *items, const uint64_t *cell_off, const uint64_t *ops_off, int n_items, int max_band,
                       uint8_t *cells, uint32_t *ops, uint32_t *path_ops, uint32_t path_cap, uint32_t *path_count, int32_t *result,
-                      hipStream_t stream) {
+                      hipStream_t stream, int n_narrow) {
     if (n_items <= 0) return;
-    const size_t lds = 3 * (size_t)(2 * max_band + 1 + 2 + 1) * sizeof(int32_t);
-    hipLaunchKernelGGL(ssw_path_kernel, dim3((unsigned)n_items), dim3(64), lds, stream, ascii, length, motif_pool, jobs, ends, items, cell_off,
-                       ops_off, n_items, cells, ops, path_ops, path_cap, path_count, result);
+    n_narrow = max(0, min(n_narrow, n_items));
+    if (n_narrow > 0)
+        hipLaunchKernelGGL(ssw_path4_kernel, dim3((unsigned)((n_narrow + 3) / 4)), dim3(64), 0, stream, ascii, length, motif_pool, jobs, ends, items, cell_off,
+                           ops_off, n_narrow, cells, ops, path_ops, path_cap, path_count, result);
+    if (n_items > n_narrow) {
+        const size_t lds = 3 * (size_t)(2 * max_band + 1 + 2 + 1) * sizeof(int32_t);
+        hipLaunchKernelGGL(ssw_path_kernel, dim3((unsigned)(n_items - n_narrow)), dim3(64), lds, stream, ascii, length, motif_pool, jobs, ends,
+                           items + 4 * (size_t)n_narrow, cell_off + n_narrow, ops_off + n_narrow, n_items - n_narrow, cells, ops, path_ops, path_cap, path_count, result);
+    }
 }
 
 }  // namespace rb
