@@ -2056,9 +2056,21 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         // reference 15 % more plus a motif: below 500 bases of seed + motif (and a motif of at most 400) both stay inside
         // the short classes -- so that the long batch is on the GPU while the other four million seeds are still being set up.
         std::vector<uint32_t> cand;
-        for (size_t i = 0; i < n_seeds; ++i) {
-            const RibbitSeed &sd = h->dispatch[i];
-            if ((int64_t)sd.end - sd.start + sd.mlen > 500 || sd.mlen > 400) cand.push_back((uint32_t)i);
+        {   // (on the threads, pieces joined in order: seventeen million seeds on one thread were a quarter of this step)
+            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n_seeds / 262144 + 1));
+            std::vector<std::vector<uint32_t>> part(nt);
+            auto scan = [&](unsigned t) {
+                const size_t lo = n_seeds * t / nt, hi = n_seeds * (t + 1) / nt;
+                for (size_t i = lo; i < hi; ++i) {
+                    const RibbitSeed &sd = h->dispatch[i];
+                    if ((int64_t)sd.end - sd.start + sd.mlen > 500 || sd.mlen > 400) part[t].push_back((uint32_t)i);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nt; ++t) pool.emplace_back(scan, t);
+            scan(0);
+            for (std::thread &th : pool) th.join();
+            for (const std::vector<uint32_t> &pt : part) cand.insert(cand.end(), pt.begin(), pt.end());
         }
         std::vector<RibbitAlignJob> cand_jobs;
         std::string cand_pool;
@@ -2373,10 +2385,21 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         const double tj0 = now_ms();
         if (done) {
             std::sort(pieces.begin(), pieces.end(), [](const rb::BedPiece &x, const rb::BedPiece &y) { return x.first_seed < y.first_seed; });
-            size_t total = 0;
-            for (const rb::BedPiece &pc : pieces) total += pc.text.size();
-            h->bed.reserve(total);
-            for (const rb::BedPiece &pc : pieces) h->bed += pc.text;
+            // the pieces' text into place on the threads (150 MB for a chromosome)
+            std::vector<size_t> at(pieces.size() + 1, 0);
+            for (size_t k = 0; k < pieces.size(); ++k) at[k + 1] = at[k] + pieces[k].text.size();
+            h->bed.resize(at[pieces.size()]);
+            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, at[pieces.size()] / (4u << 20) + 1));
+            std::atomic<size_t> next_piece{0};
+            auto place = [&]() {
+                for (size_t k; (k = next_piece.fetch_add(64)) < pieces.size();)
+                    for (size_t q = k; q < std::min(pieces.size(), k + 64); ++q)
+                        if (!pieces[q].text.empty()) std::memcpy(&h->bed[at[q]], pieces[q].text.data(), pieces[q].text.size());
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nt; ++t) pool.emplace_back(place);
+            place();
+            for (std::thread &th : pool) th.join();
         } else h->bed.clear();                         // an empty query somewhere (or no batches): the whole record in one call (below)
         t_join = now_ms() - tj0;
         if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs (%zu long ones in their own batch: %.1f ms, set up first in %.1f ms; %zu seeds set aside), set-up in all %.1f ms; %zu slices: "
