@@ -1782,7 +1782,33 @@ int ribbit_host_refine_jobs(const RibbitScanParams *params, const RibbitRefinePa
     for (size_t i = 0; i < n_dispatch; ++i) longest[i] = rb::longest_run_host(hp, seeds[i].mlen, seeds[i].start, seeds[i].end);
     std::vector<RibbitAlignJob> out;
     std::string pool;
-    rb::build_align_jobs(hp, *prm, seeds, longest.data(), nullptr, out, pool);
+    // Test hook RIBBIT_DEBUG_JOB_SLICES=n: the jobs through the GPU pipeline's builder instead (n slices of the seed list in one
+    // parallel region, each handed over by the thread that finished it: refine.cpp) and put together in seed order -- they must
+    // be the same jobs, and this entry point needs no GPU (tests/test_refine.py).
+    const char *slices_env = std::getenv("RIBBIT_DEBUG_JOB_SLICES");
+    const size_t n_slices = slices_env ? (size_t)std::max(1, std::atoi(slices_env)) : 0;
+    if (n_slices == 0) {
+        rb::build_align_jobs(hp, *prm, seeds, longest.data(), nullptr, out, pool);
+    } else {
+        std::vector<std::pair<size_t, size_t>> bounds(n_slices);
+        for (size_t c = 0; c < n_slices; ++c) bounds[c] = {n_dispatch * c / n_slices, n_dispatch * (c + 1) / n_slices};
+        std::vector<std::vector<RibbitAlignJob>> slice_jobs(n_slices);
+        std::vector<std::string> slice_pool(n_slices);
+        std::mutex mu;
+        unsigned nt = std::min(std::thread::hardware_concurrency(), 16u);
+        if (const char *env = std::getenv("RIBBIT_THREADS")) nt = (unsigned)std::max(1, std::atoi(env));
+        rb::build_align_jobs_slices(hp, *prm, seeds, longest.data(), nullptr, nt, nullptr, bounds,
+                                    [&](size_t c, std::vector<RibbitAlignJob> &&j, std::string &&p) {
+                                        std::lock_guard<std::mutex> lk(mu);
+                                        slice_jobs[c] = std::move(j);
+                                        slice_pool[c] = std::move(p);
+                                    });
+        for (size_t c = 0; c < n_slices; ++c) {
+            const int32_t base = (int32_t)pool.size();
+            for (RibbitAlignJob j : slice_jobs[c]) { j.motif_offset += base; out.push_back(j); }
+            pool += slice_pool[c];
+        }
+    }
     *n_jobs = out.size();
     *pool_len = pool.size();
     *jobs = (RibbitAlignJob *)std::malloc(std::max<size_t>(out.size(), 1) * sizeof(RibbitAlignJob));

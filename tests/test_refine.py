@@ -32,6 +32,30 @@ def test_refine_jobs_match_oracle(name, seq, m_lo, m_hi):
     _same_jobs(got, gpool, want, wpool)
 
 
+@pytest.mark.parametrize("slices", [1, 3, 7])
+def test_the_pipelines_slice_builder_makes_the_same_jobs(slices):
+    """The GPU refinement pipeline sets its jobs up with build_align_jobs_slices (all slices of the seed list in one parallel
+    region, a slice assembled and handed over by the thread that finished its last chunk); the host-only entry point uses the
+    plain builder.  RIBBIT_DEBUG_JOB_SLICES routes the host entry point through the pipeline's builder: the same jobs, the same
+    motif strings, in seed order, whatever the number of slices and threads -- checked against the oracle's jobs on the larger
+    simulated records (a few thousand seeds each, so that slices hold several chunks' worth and several threads take part)."""
+    import os
+    cases = [c for c in ALL if len(c[1]) >= 100_000][:4]
+    assert cases
+    for name, seq, m_lo, m_hi in cases:
+        with Oracle(seq, m_lo, m_hi) as o:
+            o.run_all()
+            want, wpool = o.refine_jobs()
+            xa, stride = ribbit_amd.pack_bit_planes([o.plane(m) for m in range(m_lo, m_hi + 1)], len(seq))
+            os.environ["RIBBIT_DEBUG_JOB_SLICES"] = str(slices)
+            os.environ["RIBBIT_THREADS"] = "5"
+            try:
+                got, gpool = ribbit_amd.host_refine_jobs(m_lo, m_hi, seq, xa, stride, o.dispatch())
+            finally:
+                del os.environ["RIBBIT_DEBUG_JOB_SLICES"], os.environ["RIBBIT_THREADS"]
+        _same_jobs(got, gpool, want, wpool)
+
+
 def test_defaults_follow_ribbit_cpp():
     for m_lo, m_hi in ((2, 100), (5, 40), (3, 9), (30, 100)):
         a = RefineParams()
