@@ -169,17 +169,10 @@ def pack_hbm(ribbit_amd, torch, seq: bytes, dev, device: int):
 
 def chr1_record(bases: int) -> bytes:
     """SURVEY.md 8(d) cfg3 stand-in, largest record: generator seed 4, N blocks at both ends and one 3-Mbp
-    centromere-like N block"""
-    from ribbit_amd.simulate import simulate_sequence
-    seq, _ = simulate_sequence(bases, 4, M_LO, M_HI)
-    b = bytearray(seq)
-    edge = min(10_000, bases // 100)
-    b[:edge] = b"N" * edge
-    b[bases - edge:] = b"N" * edge
-    cen = min(3_000_000, bases // 50)
-    mid = bases // 2
-    b[mid:mid + cen] = b"N" * cen
-    return bytes(b)
+    centromere-like N block (record 0 of ribbit_amd.simulate.grch38_shaped_record, the definition the committed
+    digests of tests/golden/grch38_shape_digests.json were made from)"""
+    from ribbit_amd.simulate import grch38_shaped_record
+    return grch38_shaped_record(0, bases, M_LO, M_HI)
 
 
 def chr1_full_path(ribbit_amd, bases: int, device: int, traffic: dict):

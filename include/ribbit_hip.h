@@ -450,7 +450,9 @@ int ribbit_hip_scan_perfect_end_device(RibbitHandle *h, const void **dev_runs, s
  *   right: 4 * (max_motif + 2) + 16 bases beyond own_hi (unless it ends where the record ends): checked, RIBBIT_E_ARG;
  *   left:  far enough that (a) an evaluated window lies between the first exact position (2 * (max_motif + 2) + 8 bases
  *          into the piece) + 16 and own_lo - 8, and (b) no owned call's group starts within 8 positions of that first exact
- *          position.  Both are CHECKED on every call: *inexact = 1 means a repeat or a block of N reaches further left than
+ *          position; own_lo itself must lie at least 2 * (max_motif + 2) + 8 + 32 + 16 bases into the piece (RIBBIT_E_ARG
+ *          otherwise: the last 16 are the span of the anchored scan's group filter, whose dropped groups (b) never sees).
+ *          (a) and (b) are CHECKED on every call: *inexact = 1 means a repeat or a block of N reaches further left than
  *          the halo (nothing else can) and the caller loads the chunk again with a longer left halo (the results of such a
  *          call must not be used).  A piece that starts where the record starts (pos_offset == 0) is always exact.
  * calls / pend / flush: handle-owned page-locked memory, valid until the next call for the same stage on this handle;
@@ -509,7 +511,8 @@ int ribbit_hip_debug_set_event_capacity(RibbitHandle *h, size_t events);
  * min(cores, 16)) wherever the call sequence can be cut; this sets the smallest number of calls per range (default 4096). */
 void ribbit_debug_set_merge_min_range(size_t calls);
 /* Test hook: what the last merge of a stage (0 substitution, 1 anchored) on the calling thread did: out = {ranges, ranges
- * merged again (after validation, or because their writes to list heads change an entry), whole stage redone in order (0/1)
+ * merged again (after validation, or because their writes to list heads change an entry; low 16 bits) | ranges run again
+ * behind a list-head change only because the changed entry lay within sight of their walks << 16, whole stage redone in order (0/1)
  * | range runs of the anchored stage's parallel passes, all passes together << 1,
  * list-head writes that changed an entry, first range empty (0/1) | parallel passes of the stage << 8}. */
 void ribbit_debug_last_merge(int stage, int32_t out[5]);

@@ -5,9 +5,13 @@
  * golden vectors exist and the reference cannot be built in this image.
  *
  * Every function cites the reference lines (SowpatiLab/ribbit @ 2024_10_08) it
- * restates.  The code is deliberately naive: one byte per base, one loop
- * iteration per (base, motif) -- the same shape as the reference, so that it can
- * be audited against it, not so that it is fast.
+ * restates.  The code is deliberately naive: one loop iteration per (base, motif),
+ * the same shape as the reference, so that it can be audited against it, not so
+ * that it is fast.  Codes and the N mask are one byte per base; the shift-XOR
+ * planes are one BIT per base behind pl_get / pl_set (round 4: they were bytes,
+ * 204 of them per base at -M 100 -- 62 GB for a chromosome-1-sized record and a
+ * kilobyte per base at -M 500, which kept full-size checks off the build box).
+ * rbo_plane() still hands the tests a byte-per-base view, made on request.
  *
  * Defined divergences from the reference (both are undefined behaviour there):
  *   D1  merge_types.cpp:47-68 reads seed_positions_substut[idx] even when that
@@ -65,8 +69,9 @@ struct rbo_ctx {
     int m_lo, m_hi, nmotifs;            /* MINIMUM_MLEN, MAXIMUM_MLEN, NMOTIFS */
     int min_shift, max_shift, nshifts;  /* ribbit.cpp:240-243 */
     uint8_t *code, *nmask;
-    uint8_t **plane;                    /* [nshifts] lshift_xor_bsets */
-    uint8_t **anchor;                   /* [nshifts] lsxor_anchor_bsets */
+    uint64_t **plane;                   /* [nshifts] lshift_xor_bsets, bit p & 63 of word p >> 6 */
+    uint64_t **anchor;                  /* [nshifts] lsxor_anchor_bsets */
+    uint8_t **view[2];                  /* byte-per-base copies handed out by rbo_plane / rbo_anchor_plane */
     seedvec lists[3];
     callvec calls[3];
     seedvec dispatch;
@@ -74,18 +79,44 @@ struct rbo_ctx {
     int64_t range_queries;      /* how often the merges asked for a range popcount (statistics only) */
 };
 
+static inline int pl_get(const uint64_t *x, int64_t p) { return (int)((x[p >> 6] >> (p & 63)) & 1); }
+static inline void pl_set(uint64_t *x, int64_t p) { x[p >> 6] |= (uint64_t)1 << (p & 63); }
+static size_t pl_words(int64_t len) { return (size_t)(len / 64 + 1); }
+
+/* byte-per-base copy of a bit plane, kept until the planes change or the context is closed */
+static const uint8_t *byte_view(rbo_ctx *c, int which, int idx, const uint64_t *bits) {
+    if (!c->view[which]) c->view[which] = (uint8_t **)calloc((size_t)c->nshifts, sizeof(uint8_t *));
+    if (!c->view[which][idx]) {
+        uint8_t *v = (uint8_t *)malloc((size_t)c->L + 1);
+        for (int64_t p = 0; p < c->L; p++) v[p] = (uint8_t)pl_get(bits, p);
+        c->view[which][idx] = v;
+    }
+    return c->view[which][idx];
+}
+static void drop_views(rbo_ctx *c) {
+    for (int w = 0; w < 2; w++) {
+        if (!c->view[w]) continue;
+        for (int i = 0; i < c->nshifts; i++) free(c->view[w][i]);
+        free(c->view[w]); c->view[w] = NULL;
+    }
+}
+
 int rbo_min_shift(const rbo_ctx *c) { return c->min_shift; }
 int rbo_max_shift(const rbo_ctx *c) { return c->max_shift; }
 int64_t rbo_length(const rbo_ctx *c) { return c->L; }
 const uint8_t *rbo_nmask(const rbo_ctx *c) { return c->nmask; }
 const uint8_t *rbo_codes(const rbo_ctx *c) { return c->code; }
-const uint8_t *rbo_plane(const rbo_ctx *c, int shift) {
+const uint8_t *rbo_plane(rbo_ctx *c, int shift) {
+    if (shift < c->min_shift || shift > c->max_shift) return NULL;
+    return byte_view(c, 0, shift - c->min_shift, c->plane[shift - c->min_shift]);
+}
+const uint8_t *rbo_anchor_plane(rbo_ctx *c, int shift) {
+    if (!c->anchor || shift < c->min_shift || shift > c->max_shift) return NULL;
+    return byte_view(c, 1, shift - c->min_shift, c->anchor[shift - c->min_shift]);
+}
+const uint64_t *rbo_plane_bits(const rbo_ctx *c, int shift) {
     if (shift < c->min_shift || shift > c->max_shift) return NULL;
     return c->plane[shift - c->min_shift];
-}
-const uint8_t *rbo_anchor_plane(const rbo_ctx *c, int shift) {
-    if (!c->anchor || shift < c->min_shift || shift > c->max_shift) return NULL;
-    return c->anchor[shift - c->min_shift];
 }
 int64_t rbo_seeds(const rbo_ctx *c, int which, const rbo_seed_t **out) {
     *out = c->lists[which].a; return c->lists[which].n;
@@ -128,13 +159,13 @@ rbo_ctx *rbo_open(const char *seq, int64_t len, int m_lo, int m_hi) {
         }
         c->code[p] = code; c->nmask[p] = n;
     }
-    c->plane = (uint8_t **)calloc((size_t)c->nshifts, sizeof(uint8_t *));
+    c->plane = (uint64_t **)calloc((size_t)c->nshifts, sizeof(uint64_t *));
     for (int i = 0; i < c->nshifts; i++) {
         int s = c->min_shift + i;
-        uint8_t *x = (uint8_t *)malloc((size_t)len + 1);
+        uint64_t *x = (uint64_t *)calloc(pl_words(len), sizeof(uint64_t));
         for (int64_t p = 0; p < len; p++) {
             uint8_t partner = (p + s <= len - 1) ? c->code[p + s] : 0;
-            x[p] = (c->code[p] == partner);
+            if (c->code[p] == partner) pl_set(x, p);
         }
         c->plane[i] = x;
     }
@@ -147,6 +178,7 @@ void rbo_close(rbo_ctx *c) {
         free(c->plane[i]);
         if (c->anchor) free(c->anchor[i]);
     }
+    drop_views(c);
     free(c->plane); free(c->anchor); free(c->code); free(c->nmask);
     for (int k = 0; k < 3; k++) { free(c->lists[k].a); free(c->calls[k].a); }
     free(c->dispatch.a);
@@ -155,9 +187,9 @@ void rbo_close(rbo_ctx *c) {
 
 /* parse_perfect_shiftxor.cpp:18-29 / parse_anchored_shiftxor.cpp:59-70: the counting loop only */
 int rbo_range_count(const rbo_ctx *c, int shift, int start, int end) {
-    const uint8_t *x = c->plane[shift - c->min_shift];
+    const uint64_t *x = c->plane[shift - c->min_shift];
     int n = 0;
-    for (int i = start; i < end; i++) if (x[i] == 1) n++;
+    for (int i = start; i < end; i++) if (pl_get(x, i) == 1) n++;
     return n;
 }
 
@@ -267,7 +299,7 @@ int rbo_run_perfect(rbo_ctx *c) {
             for (int d = 0; d < nm; d++) {                                      /* :191 */
                 const int midx = min_idx + d, mlen = c->min_shift + midx;
                 const int cutoff = (mlen <= 6) ? 12 - mlen : mlen;              /* :193 */
-                if (c->plane[midx][p]) {
+                if (pl_get(c->plane[midx], p)) {
                     if (open_start[d] == -1) open_start[d] = pos;
                 } else {
                     if (open_start[d] != -1) {
@@ -550,7 +582,7 @@ static void window_scan(rbo_ctx *c, int anchored, int window_length, int thresho
         } else {
             valid += 1;
             for (int d = 0; d < nm; d++)                                   /* :463-467 */
-                window[d] = ((window[d] << 1) | c->plane[min_idx + d][p]) & wmask;
+                window[d] = ((window[d] << 1) | (unsigned)pl_get(c->plane[min_idx + d], p)) & wmask;
 
             if (valid >= window_length) {                                  /* :469 */
                 for (int d = 0; d < nm; d++) {
@@ -623,19 +655,20 @@ int rbo_run_subst(rbo_ctx *c) {
 int rbo_run_anchor_planes(rbo_ctx *c) {
     const int L = (int)c->L;
     const int anchor_size = 3;                                      /* ribbit.cpp:191 */
-    c->anchor = (uint8_t **)calloc((size_t)c->nshifts, sizeof(uint8_t *));
+    drop_views(c);                                                  /* plane m becomes XA_m below */
+    c->anchor = (uint64_t **)calloc((size_t)c->nshifts, sizeof(uint64_t *));
     for (int i = 0; i < c->nshifts; i++) {
         const int shift = c->min_shift + i;
-        uint8_t *a = (uint8_t *)calloc((size_t)L + 1, 1);
+        uint64_t *a = (uint64_t *)calloc(pl_words(L), sizeof(uint64_t));
         int run_start = -1;                                         /* anchor_start, in p space */
         for (int p = 0; p <= L - 1 - shift; p++) {                  /* :37 */
-            if (c->plane[i][p] == 1) {
+            if (pl_get(c->plane[i], p) == 1) {
                 if (run_start == -1) run_start = p;
             } else {
                 /* :44 `anchor_start - xor_idx` is the run length; with anchor_start == -1 it is negative */
                 const int run_len = (run_start == -1) ? -1 : p - run_start;
                 if (run_len >= anchor_size && run_len < 2 * shift)
-                    memset(a + run_start, 1, (size_t)run_len);
+                    for (int q = run_start; q < p; q++) pl_set(a, q);      /* set(pos, len, true), :46 */
                 run_start = -1;
             }
         }
@@ -643,14 +676,15 @@ int rbo_run_anchor_planes(rbo_ctx *c) {
     }
 
     /* fasta_utils.cpp:146-160: XA_m = X_m | anchor_i for i in [max(1,m-2) .. m+2], i != m */
-    uint8_t *acc = (uint8_t *)malloc((size_t)L + 1);
+    const size_t nw = pl_words(L);
+    uint64_t *acc = (uint64_t *)malloc(nw * sizeof(uint64_t));
     for (int mlen = c->m_lo; mlen <= c->m_hi; mlen++) {
-        memset(acc, 0, (size_t)L + 1);
+        memset(acc, 0, nw * sizeof(uint64_t));
         for (int i = (mlen > 2) ? mlen - 2 : 1; i <= mlen + 2; i++) {
-            const uint8_t *src = (i == mlen) ? c->plane[i - c->min_shift] : c->anchor[i - c->min_shift];
-            for (int p = 0; p < L; p++) acc[p] |= src[p];
+            const uint64_t *src = (i == mlen) ? c->plane[i - c->min_shift] : c->anchor[i - c->min_shift];
+            for (size_t w = 0; w < nw; w++) acc[w] |= src[w];          /* the bitsets' |=, :152-158 */
         }
-        memcpy(c->plane[mlen - c->min_shift], acc, (size_t)L);
+        memcpy(c->plane[mlen - c->min_shift], acc, nw * sizeof(uint64_t));
     }
     free(acc);
     return 0;

@@ -15,7 +15,8 @@
  *
  * Coordinates: everything is in sequence space p = 0..L-1.  The reference
  * stores position p at bit index L-1-p (fasta_utils.cpp:93); that reversal is a
- * storage detail and is not reproduced.  Planes are one byte per base.
+ * storage detail and is not reproduced.  Planes are one bit per base inside the
+ * oracle; rbo_plane / rbo_anchor_plane hand out byte-per-base copies.
  */
 #ifndef RIBBIT_ORACLE_H
 #define RIBBIT_ORACLE_H
@@ -51,8 +52,10 @@ int64_t rbo_length(const rbo_ctx *c);
 
 /* byte-per-base views (valid until rbo_close); plane(shift) is X_shift, or XA_shift once
  * rbo_run_anchor_planes has run and shift is a motif length */
-const uint8_t *rbo_plane(const rbo_ctx *c, int shift);
-const uint8_t *rbo_anchor_plane(const rbo_ctx *c, int shift);  /* valid after rbo_run_anchor_planes */
+const uint8_t *rbo_plane(rbo_ctx *c, int shift);
+const uint8_t *rbo_anchor_plane(rbo_ctx *c, int shift);        /* valid after rbo_run_anchor_planes */
+/* the plane as the oracle holds it: bit p & 63 of word p >> 6 (what the refinement half reads) */
+const uint64_t *rbo_plane_bits(const rbo_ctx *c, int shift);
 const uint8_t *rbo_nmask(const rbo_ctx *c);
 const uint8_t *rbo_codes(const rbo_ctx *c);                    /* 2-bit code per base, N -> 0 */
 

@@ -62,8 +62,14 @@ struct View {
     uint8_t code_at(int p) const { return p < 0 ? 0 : code[p]; }
 };
 
+/* one shift-XOR plane of the oracle (one bit per base, ribbit_oracle.c) read like the reference's bitset */
+struct Plane {
+    const uint64_t *w;
+    int operator[](int p) const { return (int)((w[p >> 6] >> (p & 63)) & 1); }
+};
+
 /* longestContinuousMatches, parse_seed.cpp:26-44 (on the bits of plane[start..end)) */
-int longest_run(const uint8_t *plane, int start, int end) {
+int longest_run(const Plane &plane, int start, int end) {
     int l = 0, best = 0;
     for (int j = start; j < end; j++) {
         if (plane[j] == 1) l += 1;
@@ -279,7 +285,7 @@ int64_t rbo_refine_jobs(rbo_ctx *c, const rbo_refine_params_t *prm, const rbo_jo
     View v{rbo_codes(c), rbo_nmask(c), (int)rbo_length(c)};
     for (int64_t si = 0; si < n; si++) {
         const int start = seeds[si].start, end = seeds[si].end, m = seeds[si].mlen, type = seeds[si].type;
-        const uint8_t *plane = rbo_plane(c, m);
+        const Plane plane{rbo_plane_bits(c, m)};
         const int ssl = seed_sequence_length(v, start, end, m);
         if (m <= 10) {                                                       /* processSeedMotifWise */
             if (longest_run(plane, start, end) < prm->continuous_ones_threshold) continue;     /* :234-235 */
@@ -494,7 +500,7 @@ std::string repeat_past(const std::string &motif, int ppr_len) {            /* w
 }
 
 /* processSeedMotifWise, parse_smallmotif_seed.cpp:190-288 */
-void refine_small(const View &v, const char *seq, const uint8_t *plane, int start, int end, int m, int type,
+void refine_small(const View &v, const char *seq, const Plane &plane, int start, int end, int m, int type,
                   const rbo_refine_params_t &prm, BedOut &out) {
     const int ssl = seed_sequence_length(v, start, end, m);
     if (longest_run(plane, start, end) < prm.continuous_ones_threshold) return;
@@ -516,7 +522,7 @@ void refine_small(const View &v, const char *seq, const uint8_t *plane, int star
 }
 
 /* processSeed, parse_seed.cpp:318-464 (recursive on the flanks of the aligned repeat) */
-void refine_long(const View &v, const char *seq, const uint8_t *plane, int start, int end, int m, int type,
+void refine_long(const View &v, const char *seq, const Plane &plane, int start, int end, int m, int type,
                  const rbo_refine_params_t &prm, BedOut &out, int depth) {
     if (depth > 10000) return;
     const int ssl = seed_sequence_length(v, start, end, m);
@@ -569,7 +575,7 @@ const char *rbo_refine_bed(rbo_ctx *c, const rbo_refine_params_t *prm, const cha
     View v{rbo_codes(c), rbo_nmask(c), (int)rbo_length(c)};
     for (int64_t si = 0; si < n; si++) {
         const rbo_seed_t &s = seeds[si];
-        const uint8_t *plane = rbo_plane(c, s.mlen);
+        const Plane plane{rbo_plane_bits(c, s.mlen)};
         if (s.mlen <= 10) refine_small(v, seq, plane, s.start, s.end, s.mlen, s.type, *prm, out);
         else refine_long(v, seq, plane, s.start, s.end, s.mlen, s.type, *prm, out, 0);
     }

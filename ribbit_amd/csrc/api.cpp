@@ -653,7 +653,9 @@ int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks, int (
         pp.ev_cap = (uint32_t)cap;
         pr.region_cap = pp.ev_cap / (uint32_t)rb::EV_SHARDS;
         HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-        HIP_TRY(hipEventRecord(h->ev_stage[which - 1][0], h->stream));
+        // (two-kernel anchored stage: the planes kernel runs on the first attempt only, so the stage's start mark stays where it
+        // was put then -- timer 7 is "both kernels", also when the window scan had to run again with more room)
+        if (attempt == 0 || which == 1 || fused_anchored) HIP_TRY(hipEventRecord(h->ev_stage[which - 1][0], h->stream));
         if (which == 1) rb::launch_scan_window(pl, pp, 1, h->d_events.p, h->d_counters.p, h->stream);
         else if (fused_anchored) rb::launch_scan_anchored(pl, pp, h->d_xa.p, h->xa_stride, h->d_events.p, h->d_counters.p, filter ? h->d_tj.p : nullptr,
                                                           filter ? h->d_dropmap.p : nullptr, h->stream);
@@ -2139,11 +2141,18 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         std::mutex mu;
         std::condition_variable cv;
         std::atomic<bool> stop{false};
-        std::thread long_thread, later_thread, feeder;
+        // (a guard is declared AFTER everything its threads touch: locals die in reverse order, so the guard joins first.  Until
+        // round 4 one guard up here held all three threads, and an exception after they had started freed the slices and
+        // `later_pieces` under a feeder still running.)
+        std::vector<rb::BedPiece> later_pieces;
+        bool later_order_dependent = false, later_done = false;
+        double t_later_thread = 0;
+        if ((rc = bind_device(h))) return rc;       // before any helper thread exists: nothing to join on this way out
+        std::thread long_thread, later_thread;
         struct JoinGuard {
-            std::atomic<bool> &stop; std::condition_variable &cv; std::thread &a, &b, &c;
-            ~JoinGuard() { stop = true; cv.notify_all(); if (a.joinable()) a.join(); if (b.joinable()) b.join(); if (c.joinable()) c.join(); }
-        } join_guard{stop, cv, feeder, later_thread, long_thread};
+            std::atomic<bool> &stop; std::condition_variable &cv; std::thread &a, &b;
+            ~JoinGuard() { stop = true; cv.notify_all(); if (a.joinable()) a.join(); if (b.joinable()) b.join(); }
+        } join_guard{stop, cv, later_thread, long_thread};
         static const bool fail_later_slices = std::getenv("RIBBIT_DEBUG_FAIL_BATCHES") != nullptr;      // test hook: see below
         if (!long_jobs.empty()) {
             if (!h->aux && (rc = ribbit_hip_open(&h->params, h->device, &h->aux))) return rc;
@@ -2167,9 +2176,6 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         // the seeds set aside are refined as soon as the long batch AND the slice that holds their short jobs have landed, on a
         // few threads beside the workers (who are mostly waiting for the feeder): not after everything else, where their long
         // host-side tails (queries beyond the kernels' reach, flank recursion) were 120 of 715 ms at 64 Mbp
-        std::vector<rb::BedPiece> later_pieces;
-        bool later_order_dependent = false, later_done = false;
-        double t_later_thread = 0;
         // seeds with a job beyond the kernels' reach (queries over 8192 bases; over 4096 until the end of round 3: 5-60 ms of host
         // alignment each) need nothing from
         // the GPU: they are refined on a few host threads from the start, beside everything else, instead of as a tail
@@ -2276,7 +2282,6 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             }
             sl.t_feed = now_ms() - tf0;
         };
-        if ((rc = bind_device(h))) return rc;
         std::thread tabler;
         struct TablerGuard { std::atomic<bool> &stop; std::condition_variable &cv; std::thread &t; ~TablerGuard() { stop = true; cv.notify_all(); if (t.joinable()) t.join(); } } tabler_guard{stop, cv, tabler};
         tabler = std::thread([&]() {
@@ -2307,8 +2312,11 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                 if (slices[c].rc) break;
             }
         };
-        std::thread feeder2;
-        struct Feeder2Guard { std::atomic<bool> &stop; std::condition_variable &cv; std::thread &t; ~Feeder2Guard() { stop = true; cv.notify_all(); if (t.joinable()) t.join(); } } feeder2_guard{stop, cv, feeder2};
+        std::thread feeder, feeder2;
+        struct FeederGuard {
+            std::atomic<bool> &stop; std::condition_variable &cv; std::thread &a, &b;
+            ~FeederGuard() { stop = true; cv.notify_all(); if (a.joinable()) a.join(); if (b.joinable()) b.join(); }
+        } feeder_guard{stop, cv, feeder, feeder2};
         feeder = std::thread([&]() { feeder_loop(0, h); });
         if (n_feeders == 2) feeder2 = std::thread([&]() { feeder_loop(1, h->aux2); });
         {
@@ -2703,7 +2711,7 @@ int32_t ribbit_debug_last_dispatch_ranges(void) { return (int32_t)rb::last_dispa
 
 void ribbit_debug_last_merge(int stage, int32_t out[5]) {
     const rb::MergeStats st = rb::last_merge_stats(stage);
-    out[0] = (int32_t)st.ranges; out[1] = (int32_t)st.ranges_redone; out[2] = (st.redone_in_order ? 1 : 0) | (int32_t)(st.ranges_run << 1);
+    out[0] = (int32_t)st.ranges; out[1] = (int32_t)std::min(st.ranges_redone, 0xffffu) | (int32_t)(std::min(st.stale_by_sight, 0x7fffu) << 16); out[2] = (st.redone_in_order ? 1 : 0) | (int32_t)(st.ranges_run << 1);
     out[3] = (int32_t)std::min<long long>(st.head_writes, INT32_MAX); out[4] = (st.first_range_empty ? 1 : 0) | (int32_t)(st.passes << 8);
 }
 
@@ -2776,7 +2784,11 @@ int ribbit_hip_stage_calls_chunk(RibbitHandle *h, int stage, int64_t own_lo, int
     const int64_t reach_left = 2 * s + 8, reach_right = 4 * s + 16;       // how far a streak event depends on the sequence (the anchored kernel's are the larger)
     if (!last && own_hi > h->length - reach_right)
         return fail(RIBBIT_E_ARG, "the piece must reach %lld bases beyond the chunk's own range (own_hi %lld, piece %lld)", (long long)reach_right, (long long)own_hi, (long long)h->length);
-    if (!first && own_lo < reach_left + 32) return fail(RIBBIT_E_ARG, "the piece must start at least %lld bases before the chunk's own range", (long long)(reach_left + 32));
+    // (+ GROUP_FILTER_MAX: a group the anchored scan's group filter drops never reaches window_calls_kernel, where condition
+    // (b) is tested; a group cut by the piece's artificial left end can only be dropped wrongly if it also ends within the
+    // filter's span of the first exact position -- with this margin its call cannot be an owned one)
+    const int64_t min_left = reach_left + 32 + rb::GROUP_FILTER_MAX;
+    if (!first && own_lo < min_left) return fail(RIBBIT_E_ARG, "the piece must start at least %lld bases before the chunk's own range", (long long)min_left);
     std::memset(out, 0, sizeof *out);
     out->tail_pend = -1;
     int rc;

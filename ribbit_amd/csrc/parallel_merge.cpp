@@ -582,20 +582,18 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
                 // it was or where the write put it -- can be met by the range's ordinary walks: those stay right of the range's
                 // left cut, so an entry that ends more than a motif before the cut is out of their sight, like every other seed
                 // of the ranges before.  Bit 63 stands for every entry from the 64th on: then all ranges behind run again.
+                // (Round 3 marked ranges only when some range had READ a changed entry by counter: a range with the entry
+                // in sight of its walks but no such read kept a result made against the old entry -- a range does not log
+                // reads inside its own territory as foreign, so nothing else caught it.  Each range is judged on its own now.)
                 const bool wide = rerun_all || ((ch[0] | ch[1]) >> 63) != 0;
                 bool any = false;
                 for (size_t j = k + 1; j < nr; ++j) {
                     const bool reads = ((state[j].head_reads[0] & ch[0]) | (state[j].head_reads[1] & ch[1])) != 0;
-                    any |= reads;
+                    const bool in_sight = (int64_t)cut_pos[j] <= (int64_t)reach + lists.max_motif + 2;
+                    if (wide || reads || in_sight) { stale[j] = 1; any = true; }
+                    if (in_sight && !reads && !wide) ++st.stale_by_sight;
                 }
-                if (any) {
-                    for (size_t j = k + 1; j < nr; ++j) {
-                        const bool reads = ((state[j].head_reads[0] & ch[0]) | (state[j].head_reads[1] & ch[1])) != 0;
-                        const bool in_sight = (int64_t)cut_pos[j] <= (int64_t)reach + lists.max_motif + 2;
-                        if (wide || reads || in_sight) stale[j] = 1;
-                    }
-                    done = k + 1; again = true; break;
-                }
+                if (any) { done = k + 1; again = true; break; }
             }
         }
         st.walk_ms += now_ms() - tw;

@@ -54,6 +54,7 @@ struct MergeStats {
     long long head_writes = 0;     // Q8 writes to list heads that would change an entry (their ranges are done again with the writes made)
     unsigned passes = 1;           // parallel passes of the anchored stage (one more per head change that a later range read)
     unsigned ranges_run = 0;       // ranges run in those passes, all passes together (== ranges when there was one pass)
+    unsigned stale_by_sight = 0;   // ranges run again behind a head change ONLY because the changed entry lay within sight of their walks (no by-counter read of it)
     bool first_range_empty = false;
     double prepare_ms = 0.0, merge_ms = 0.0, concat_ms = 0.0;      // concat_ms: the part of merge_ms spent joining the ranges' lists
     // anchored stage, inside merge_ms: wall time of the parallel passes, of the in-order walks behind them (with the ranges

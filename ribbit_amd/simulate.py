@@ -178,3 +178,27 @@ def write_fasta(path: str, records: list[tuple[str, bytes]], width: int = 80) ->
             fh.write(b">" + name.encode() + b"\n")
             for i in range(0, len(seq), width):
                 fh.write(seq[i:i + width] + b"\n")
+
+
+# BASELINE.json configs[2] / configs[3] stand-in (GRCh38 itself is on no box): 24 records with the primary
+# assembly's lengths.  One definition for everything that makes or checks these records -- bench.py's chr1_full_path leg,
+# tools/grch38_shape.py, tools/full_size_digests.py and the digests under tests/golden/ -- so that they cannot drift apart.
+GRCH38_RECORDS = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555), ("chr5", 181538259), ("chr6", 170805979),
+                  ("chr7", 159345973), ("chr8", 145138636), ("chr9", 138394717), ("chr10", 133797422), ("chr11", 135086622), ("chr12", 133275309),
+                  ("chr13", 114364328), ("chr14", 107043718), ("chr15", 101991189), ("chr16", 90338345), ("chr17", 83257441), ("chr18", 80373285),
+                  ("chr19", 58617616), ("chr20", 64444167), ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415)]
+
+
+def grch38_shaped_record(k: int, bases: int | None = None, m_lo: int = 2, m_hi: int = 100) -> bytes:
+    """Record k of the GRCh38-shaped set (k = 0: the chromosome-1-sized record of bench.py): generator seed 4 + 1000 k, blocks
+    of N at both ends and one 3-Mbp centromere-like block of N in the middle.  `bases` overrides the length (scaled sets)."""
+    if bases is None:
+        bases = GRCH38_RECORDS[k][1]
+    seq, _ = simulate_sequence(bases, 4 + 1000 * k, m_lo, m_hi)
+    b = np.frombuffer(seq, dtype=np.uint8).copy()
+    edge = min(10_000, bases // 100)
+    b[:edge] = ord("N")
+    b[bases - edge:] = ord("N")
+    cen = min(3_000_000, bases // 50)
+    b[bases // 2:bases // 2 + cen] = ord("N")
+    return b.tobytes()

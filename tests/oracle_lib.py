@@ -181,9 +181,17 @@ class Oracle:
         if rp is None:
             rp = RefineParams()
             self._L.rbo_refine_params_default(C.byref(rp), self.m_lo, self.m_hi)
+        return self.refine_bed_bytes(seq_id, rp).decode()
+
+    def refine_bed_bytes(self, seq_id: str = "seq", params=None) -> bytes:
+        """the same text as bytes (full-size records: 150 MB, hashed rather than compared as a str)"""
+        rp = params
+        if rp is None:
+            rp = RefineParams()
+            self._L.rbo_refine_params_default(C.byref(rp), self.m_lo, self.m_hi)
         n = C.c_int64()
         p = self._L.rbo_refine_bed(self._h, C.byref(rp), self.seq, seq_id.encode(), C.byref(n))
-        return C.string_at(p, n.value).decode()
+        return C.string_at(p, n.value)
 
     def range_count(self, shift, start, end):
         return self._L.rbo_range_count(self._h, shift, start, end)

@@ -19,23 +19,15 @@ from concurrent.futures import ProcessPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-GRCH38 = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555), ("chr5", 181538259), ("chr6", 170805979),
-          ("chr7", 159345973), ("chr8", 145138636), ("chr9", 138394717), ("chr10", 133797422), ("chr11", 135086622), ("chr12", 133275309),
-          ("chr13", 114364328), ("chr14", 107043718), ("chr15", 101991189), ("chr16", 90338345), ("chr17", 83257441), ("chr18", 80373285),
-          ("chr19", 58617616), ("chr20", 64444167), ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415)]
+from ribbit_amd.simulate import GRCH38_RECORDS as GRCH38
 
 
 def make_record(args):
     """-> path of a file holding the record's FASTA text (header + 80-column lines)"""
     import numpy as np
-    from ribbit_amd.simulate import simulate_sequence
+    from ribbit_amd.simulate import grch38_shaped_record
     k, name, bases, out_dir = args
-    seq, _ = simulate_sequence(bases, 4 + 1000 * k, 2, 100)
-    b = np.frombuffer(seq, dtype=np.uint8).copy()
-    edge = min(10_000, bases // 100)
-    b[:edge] = ord("N"); b[bases - edge:] = ord("N")
-    cen = min(3_000_000, bases // 50)
-    b[bases // 2:bases // 2 + cen] = ord("N")
+    b = np.frombuffer(grch38_shaped_record(k, bases), dtype=np.uint8)
     # 80-column lines without a Python loop over the lines
     full = bases // 80 * 80
     body = np.empty((full // 80, 81), dtype=np.uint8)
