@@ -537,6 +537,10 @@ void ribbit_debug_small_motif_counters(int64_t out[2]);
  * path from the GPU (ribbit_hip_refine_bed batches them on the GPU for records with 400,000 dispatched seeds or more;
  * RIBBIT_GPU_SSW=0 / 1 forces it off / on). */
 void ribbit_debug_alignment_counters(int64_t out[3]);
+/* Test hook: cumulative, process-wide: {levels run, nodes put off, alignments of those nodes} of the level-by-level GPU
+ * refinement of long-motif seeds' recursion trees (processSeed's recursion on the flanks, parse_seed.cpp:443-463: nodes of
+ * RIBBIT_DEFER_MIN bases and more, default 700, are not refined where they are met but batched on the GPU, level by level). */
+void ribbit_debug_level_counters(int64_t out[3]);
 
 /* HIP events behind ribbit_hip_last_timing_ms are recorded by default; every record is a barrier packet between two
  * kernels of the stream (~6 us each on MI355X).  A caller that streams many records can switch them off per handle

@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_last_timing_ms", "ribbit_hip_last_event_count",
     "ribbit_hip_subst_calls", "ribbit_hip_seeds_substitutions",
     "ribbit_host_replay_calls", "ribbit_seed_lists_free", "ribbit_host_longest_runs", "ribbit_debug_set_merge_min_range", "ribbit_debug_last_merge",
-    "ribbit_hip_small_motifs", "ribbit_debug_small_motif_counters", "ribbit_debug_last_dispatch_ranges", "ribbit_debug_alignment_counters",
+    "ribbit_hip_small_motifs", "ribbit_debug_small_motif_counters", "ribbit_debug_last_dispatch_ranges", "ribbit_debug_alignment_counters", "ribbit_debug_level_counters",
     "ribbit_hip_anchored_calls", "ribbit_hip_seeds_anchored", "ribbit_hip_dispatch_seeds", "ribbit_hip_guard_hits",
     "ribbit_hip_debug_stream_read",
     "ribbit_refine_params_default", "ribbit_hip_seed_longest_runs", "ribbit_hip_refine_jobs",
@@ -158,6 +158,8 @@ def load_library():
     L.ribbit_debug_last_dispatch_ranges.argtypes = []
     L.ribbit_debug_alignment_counters.restype = None
     L.ribbit_debug_alignment_counters.argtypes = [C.POINTER(C.c_int64 * 3)]
+    L.ribbit_debug_level_counters.restype = None
+    L.ribbit_debug_level_counters.argtypes = [C.POINTER(C.c_int64 * 3)]
     L.ribbit_debug_small_motif_counters.restype = None
     L.ribbit_debug_small_motif_counters.argtypes = [C.POINTER(C.c_int64 * 2)]
     L.ribbit_hip_small_motifs.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -376,6 +378,15 @@ def alignment_counters():
     L = load_library()
     out = (C.c_int64 * 3)()
     L.ribbit_debug_alignment_counters(C.byref(out))
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def level_counters():
+    """(levels run, nodes put off, alignments of those nodes) of the level-by-level GPU refinement of long-motif seeds'
+    recursion trees, cumulative"""
+    L = load_library()
+    out = (C.c_int64 * 3)()
+    L.ribbit_debug_level_counters(C.byref(out))
     return int(out[0]), int(out[1]), int(out[2])
 
 

@@ -1036,13 +1036,12 @@ int build_longest_runs(RibbitHandle *h) {
 
 // mostFrequentLongerMotif's row selection for every dispatched seed with m > 10 that will reach it
 // (parse_seed.cpp:360-386), one GPU launch (a15)
-int build_best_rows(RibbitHandle *h, const RibbitRefineParams &prm) {
-    if (h->best_rows_valid) return RIBBIT_OK;
-    int rc = build_longest_runs(h);
-    if (rc) return rc;
-    const size_t n = h->dispatch.size();
-    h->best_rows.assign(n, -1);
-    rb::SeedVec jobs;          // reused as int4 {seed_start, seed_sequence_length, m, dispatch index}
+// best[i] (where it is -1 on entry and seed i reaches mostFrequentLongerMotif) = the row it selects, for any list of seeds of
+// the loaded record: the dispatched seeds, or nodes of their recursion trees put off for a GPU batch (refine.h)
+int best_rows_of(RibbitHandle *h, const RibbitRefineParams &prm, const rb::SeedVec &seeds, const int32_t *longest, int32_t *best) {
+    int rc;
+    const size_t n = seeds.size();
+    rb::SeedVec jobs;          // reused as int4 {seed_start, seed_sequence_length, m, index}
     {
         // the usable length of every long-motif seed (a walk over its bases up to the first N) on the host threads: 0.8 M seeds of
         // a hundred bases per 64 Mbp were 80 ms on one
@@ -1054,8 +1053,8 @@ int build_best_rows(RibbitHandle *h, const RibbitRefineParams &prm) {
         auto work = [&](unsigned t) {
             const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
             for (size_t i = lo; i < hi; ++i) {
-                const RibbitSeed &s = h->dispatch[i];
-                if (s.mlen <= 10 || s.end - s.start < 0.9 * s.mlen || h->longest_runs[i] < prm.continuous_ones_threshold) continue;
+                const RibbitSeed &s = seeds[i];
+                if (best[i] >= 0 || s.mlen <= 10 || s.end - s.start < 0.9 * s.mlen || longest[i] < prm.continuous_ones_threshold) continue;
                 part[t].push_back(RibbitSeed{s.start, rb::usable_length_host(h->host, s.start, s.end, s.mlen), s.mlen, (int32_t)i});
             }
         };
@@ -1086,12 +1085,21 @@ int build_best_rows(RibbitHandle *h, const RibbitRefineParams &prm) {
         rb::launch_long_motif_rows(h->d_sym.p, h->length, h->d_seeds.p, (int64_t)jobs.size(), h->d_slices.p,
                                    (int64_t)(slices.size() / 2), h->d_best.p, h->stream);
         HIP_TRY(hipGetLastError());
-        std::vector<unsigned long long> best(jobs.size());
-        HIP_TRY(hipMemcpyAsync(best.data(), h->d_best.p, jobs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        std::vector<unsigned long long> got(jobs.size());
+        HIP_TRY(hipMemcpyAsync(got.data(), h->d_best.p, jobs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         for (size_t j = 0; j < jobs.size(); ++j)      // no positive score: mmotif_index keeps its initial 0 (parse_seed.cpp:165)
-            h->best_rows[(size_t)jobs[j].type] = best[j] ? (int32_t)(0xffffffffu - (uint32_t)best[j]) : 0;
+            best[(size_t)jobs[j].type] = got[j] ? (int32_t)(0xffffffffu - (uint32_t)got[j]) : 0;
     }
+    return RIBBIT_OK;
+}
+
+int build_best_rows(RibbitHandle *h, const RibbitRefineParams &prm) {
+    if (h->best_rows_valid) return RIBBIT_OK;
+    int rc = build_longest_runs(h);
+    if (rc) return rc;
+    h->best_rows.assign(h->dispatch.size(), -1);
+    if ((rc = best_rows_of(h, prm, h->dispatch, h->longest_runs.data(), h->best_rows.data()))) return rc;
     h->best_rows_valid = true;
     return RIBBIT_OK;
 }
@@ -1847,6 +1855,7 @@ struct AlignSubmission {
     const char *pool = nullptr; size_t pool_len = 0;
     const uint8_t *dev_bases = nullptr; int64_t length = 0;        // the record's bases on the batcher's device
     std::vector<rb::SswEnds> ends; std::vector<rb::SswPath> paths; std::vector<uint32_t> ops;      // results
+    unsigned classes = 0x3u;              // size classes of the submission's jobs that are to run (run_ssw_passes)
     int rc = RIBBIT_OK; std::string error;
     bool done = false;
 };
@@ -1905,7 +1914,9 @@ struct RibbitAlignBatcher {
             }
             if (!rc) {
                 bh->dev_ascii_src = stage.p; bh->length = total; bh->loaded = true;
-                rc = run_ssw_passes(bh, jobs.data(), jobs.size(), pool.data(), pool.size(), 15, ends, 0x3u);
+                unsigned classes = 0;       // (a job of a class its own submission did not ask for is aligned all the same: same result)
+                for (const AlignSubmission *sb : subs) classes |= sb->classes;
+                rc = run_ssw_passes(bh, jobs.data(), jobs.size(), pool.data(), pool.size(), 15, ends, classes);
             }
             // RIBBIT_BATCH_PATHS=0: striped passes only; the banded path search of these short alignments stays on the records'
             // host threads (a batch then is one launch and one synchronisation instead of a round per band width)
@@ -2022,6 +2033,133 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
         return fail(RIBBIT_E_NOMEM, "out of host memory in refinement");
     }
 }
+
+// Nodes of long-motif seeds' recursion trees that were put off for the GPU (refine.h: DeferredNode): their usable length from
+// this many bases on (RIBBIT_DEFER_MIN; 0 = nothing is put off, every node is done where it is met, as until round 4).
+static int defer_min_length() {
+    const char *env = std::getenv("RIBBIT_DEFER_MIN");      // (read per record: the tests change it)
+    return env ? std::max(0, std::atoi(env)) : 700;
+}
+
+static rb::Deferral make_deferral(std::vector<rb::DeferredNode> *out, std::mutex *lock) {
+    rb::Deferral d;
+    d.out = out; d.lock = lock; d.min_length = defer_min_length();
+    d.max_query = rb::SSW_COLOSSAL_Q; d.max_ref = rb::SSW_COLOSSAL_R;
+    return d;
+}
+
+// The nodes put off, level by level, each level like a first level of its own: consensus rows (long_motif_rows_kernel), job
+// set-up, striped passes and path search of all of them in one batch on the handle's streams, then the host threads finish
+// the alignments, print the rows into pieces that sort into place and put off the next level's nodes (the flanks of this
+// level's that are worth it; the others are done on the spot).  *order_dependent: an empty query was met (the caller redoes
+// the record in call order, on the host).
+//
+// A level's batch goes where it is large enough to pay: on this handle's own streams from LEVEL_OWN_BATCH nodes on (a
+// chromosome's first levels: 46 K, 28 K, 15 K ... alignments at -M 500); into the GPU's SHARED batches if the handle has a
+// batcher (a read among many in flight: its levels hold 5-30 alignments, and a batch of one record's costs as much as a batch
+// of everybody's); else the level -- and with it everything below it -- is finished on the host threads by plain recursion.
+// Measured (chromosome-1-sized record at -M 500): the trees are deep chains (128 levels, one flank trimmed at a time), and a
+// level of a hundred alignments costs 40 ms of latency on the GPU -- a long alignment holds its workgroup that long however few
+// there are -- where the host threads need 20: levels own-batched all the way down took 6.6 s, 3.5 of them below level 8.
+constexpr size_t LEVEL_OWN_BATCH = 400;
+static int refine_levels(RibbitHandle *h, const RibbitRefineParams &prm, const std::string &sequence_id, std::vector<rb::DeferredNode> &nodes,
+                         std::vector<rb::BedPiece> &pieces, unsigned threads, bool *order_dependent, int64_t counts[3]) {
+    static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
+    static const bool level_lines = profile && std::getenv("RIBBIT_PROFILE_LEVELS") != nullptr;
+    std::vector<rb::DeferredNode> next;
+    std::mutex lock;
+    std::string unused;
+    double t_rows = 0, t_passes = 0, t_paths = 0, t_finish = 0, t_host = 0;
+    size_t n_nodes = 0, n_host = 0;
+    int level = 1;
+    for (; !nodes.empty(); ++level) {
+        const double t0 = now_ms();
+        const size_t n = nodes.size();
+        rb::SeedVec seeds(n);
+        std::vector<int32_t> longest(n), best(n);
+        std::vector<uint32_t> all(n);
+        for (size_t i = 0; i < n; ++i) {
+            seeds[i] = RibbitSeed{nodes[i].start, nodes[i].end, nodes[i].mlen, nodes[i].type};
+            longest[i] = nodes[i].longest; best[i] = nodes[i].known_row; all[i] = (uint32_t)i;
+        }
+        const bool shared = h->batcher != nullptr && n < 8 * LEVEL_OWN_BATCH;
+        bool od = false;
+        if (!shared && n < LEVEL_OWN_BATCH) {
+            // too few for a batch of their own: here, by recursion, nothing put off any further
+            rb::Deferral d;
+            d.nodes = nodes.data();
+            rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), prm, seeds, longest.data(), best.data(), sequence_id, unused, threads,
+                              nullptr, nullptr, nullptr, 0, n, &od, nullptr, nullptr, nullptr, &pieces, &all, 0, &d);
+            if (od) { *order_dependent = true; return RIBBIT_OK; }
+            t_host += now_ms() - t0; n_host += n;
+            nodes.clear();
+            break;
+        }
+        int rc;
+        if ((rc = best_rows_of(h, prm, seeds, longest.data(), best.data()))) return rc;
+        const double t1 = now_ms();
+        std::vector<RibbitAlignJob> jobs;
+        std::string pool;
+        rb::build_align_jobs(h->host, prm, seeds, longest.data(), best.data(), jobs, pool, threads, 0, n, nullptr);
+        std::vector<rb::SswEnds> ends;
+        std::vector<rb::SswPath> paths;
+        AlignSubmission sb;
+        double t2, t3;
+        if (shared) {
+            sb.jobs = jobs.data(); sb.n = jobs.size(); sb.pool = pool.data(); sb.pool_len = pool.size();
+            sb.dev_bases = h->dev_ascii_src; sb.length = h->length; sb.classes = 0x1fu;
+            if (!jobs.empty()) h->batcher->submit(sb);
+            if (sb.rc) { g_last_error = sb.error; return sb.rc; }
+            if (jobs.empty()) { sb.ends.clear(); sb.paths.clear(); }
+            ends.swap(sb.ends); paths.swap(sb.paths);       // (the paths' operations live in sb.ops)
+            t2 = t3 = now_ms();
+        } else {
+            if ((rc = run_ssw_passes(h, jobs.data(), jobs.size(), pool.data(), pool.size(), 15, ends, 0x1fu))) return rc;
+            t2 = now_ms();
+            if ((rc = run_ssw_paths(h, jobs.data(), jobs.size(), ends, paths))) return rc;
+            t3 = now_ms();
+        }
+        next.clear();
+        rb::Deferral d = make_deferral(&next, &lock);
+        d.nodes = nodes.data();
+        rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), prm, seeds, longest.data(), best.data(), sequence_id, unused, threads,
+                          &jobs, &ends, &paths, 0, n, &od, nullptr, nullptr, nullptr, &pieces, &all, 0, &d);
+        if (od) { *order_dependent = true; return RIBBIT_OK; }
+        counts[0] += 1; counts[1] += (int64_t)n; counts[2] += (int64_t)jobs.size();
+        const double t4 = now_ms();
+        t_rows += t1 - t0; t_passes += t2 - t1; t_paths += t3 - t2; t_finish += t4 - t3; n_nodes += n;
+        if (level_lines)
+            std::fprintf(stderr, "[refine levels] level %d: %zu nodes put off, %zu alignments%s: consensus rows %.1f ms, set-up + striped passes %.1f ms, path search %.1f ms, "
+                                 "host finish %.1f ms; %zu nodes put off for the next level\n", level, n, jobs.size(), shared ? " (shared batch)" : "", t1 - t0, t2 - t1, t3 - t2, t4 - t3, next.size());
+        nodes.swap(next);
+    }
+    if (profile)
+        std::fprintf(stderr, "[refine levels] %zu nodes in %d GPU levels: consensus rows %.1f ms, set-up + striped passes (or shared batches) %.1f ms, path search %.1f ms, host finish %.1f ms; "
+                             "%zu nodes of the last level finished on the host threads by recursion in %.1f ms\n", n_nodes, level - 1, t_rows, t_passes, t_paths, t_finish, n_host, t_host);
+    return RIBBIT_OK;
+}
+
+// the pieces' text into h->bed, in printing order: by seed, and inside a seed's recursion tree by place (refine.h)
+static void join_pieces(RibbitHandle *h, std::vector<rb::BedPiece> &pieces, unsigned threads) {
+    std::sort(pieces.begin(), pieces.end(), [](const rb::BedPiece &x, const rb::BedPiece &y) {
+        return x.first_seed != y.first_seed ? x.first_seed < y.first_seed : x.path < y.path; });
+    std::vector<size_t> at(pieces.size() + 1, 0);
+    for (size_t k = 0; k < pieces.size(); ++k) at[k + 1] = at[k] + pieces[k].text.size();
+    h->bed.resize(at[pieces.size()]);
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, at[pieces.size()] / (4u << 20) + 1));
+    std::atomic<size_t> next_piece{0};
+    auto place = [&]() {
+        for (size_t k; (k = next_piece.fetch_add(64)) < pieces.size();)
+            for (size_t q = k; q < std::min(pieces.size(), k + 64); ++q)
+                if (!pieces[q].text.empty()) std::memcpy(&h->bed[at[q]], pieces[q].text.data(), pieces[q].text.size());
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(place);
+    place();
+    for (std::thread &th : pool) th.join();
+}
+
+static std::atomic<int64_t> g_level_counts[3];      // levels run, nodes put off, their alignments (process-wide, cumulative)
 
 static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const char *sequence_id, const char **text, size_t *len) {
     if (!h || !prm || !sequence_id || !text || !len) return fail(RIBBIT_E_ARG, "null argument");
@@ -2147,6 +2285,11 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         std::vector<rb::BedPiece> later_pieces;
         bool later_order_dependent = false, later_done = false;
         double t_later_thread = 0;
+        // nodes of the seeds' recursion trees that are put off for a GPU batch of their own (refine.h), from every call below
+        std::vector<rb::DeferredNode> put_off;
+        std::mutex put_off_lock;
+        const rb::Deferral tree = make_deferral(&put_off, &put_off_lock);
+        const rb::Deferral *const treep = tree.min_length > 0 ? &tree : nullptr;
         if ((rc = bind_device(h))) return rc;       // before any helper thread exists: nothing to join on this way out
         std::thread long_thread, later_thread;
         struct JoinGuard {
@@ -2186,7 +2329,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                     bool od = false;
                     rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
                                       sequence_id, h->bed, std::max(2u, threads / 4), nullptr, nullptr, nullptr, 0, n_seeds, &od, &small, nullptr, nullptr,
-                                      &later_pieces, &giants);
+                                      &later_pieces, &giants, 0, treep);
                     if (od) later_order_dependent = true;
                     else later_done = true;
                 } catch (const std::bad_alloc &) { later_done = false; }
@@ -2345,7 +2488,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             const double tk = now_ms();
             rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
                               sequence_id, h->bed, h->host_threads, &sl.jobs, &sl.ends, &sl.paths, sl.lo, sl.hi, &order_dependent, &small,
-                              sl.job_first.data(), set_aside.data(), &pieces, nullptr, sl.lo);
+                              sl.job_first.data(), set_aside.data(), &pieces, nullptr, sl.lo, treep);
             t_work += now_ms() - tk;
             if (order_dependent) break;
         }
@@ -2400,7 +2543,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                     return h->dispatch[x].end - h->dispatch[x].start > h->dispatch[y].end - h->dispatch[y].start; });
                 rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
                                   sequence_id, h->bed, h->host_threads, &lj, &le, &lp, 0, n_seeds, &order_dependent, &small, lfirst.data(), nullptr,
-                                  &pieces, &by_cost);
+                                  &pieces, &by_cost, 0, treep);
             }
             if (!stragglers.empty())
                 rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
@@ -2415,39 +2558,34 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             }
             t_later = now_ms() - tl0;
         }
+        double t_levels = 0;
+        if (!order_dependent && !batches_failed && !put_off.empty()) {
+            // the nodes put off by all of the above, level by level on this handle's streams (nothing else runs on them now)
+            const double tv0 = now_ms();
+            int64_t counts[3] = {0, 0, 0};
+            rc = refine_levels(h, *prm, sequence_id, put_off, pieces, threads, &order_dependent, counts);
+            for (int k = 0; k < 3; ++k) g_level_counts[k] += counts[k];
+            if (rc == RIBBIT_E_NOMEM) { rc = RIBBIT_OK; batches_failed = true; }
+            if (rc) return rc;
+            t_levels = now_ms() - tv0;
+        }
         done = !order_dependent && !batches_failed;
         const double tj0 = now_ms();
-        if (done) {
-            std::sort(pieces.begin(), pieces.end(), [](const rb::BedPiece &x, const rb::BedPiece &y) { return x.first_seed < y.first_seed; });
-            // the pieces' text into place on the threads (150 MB for a chromosome)
-            std::vector<size_t> at(pieces.size() + 1, 0);
-            for (size_t k = 0; k < pieces.size(); ++k) at[k + 1] = at[k] + pieces[k].text.size();
-            h->bed.resize(at[pieces.size()]);
-            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, at[pieces.size()] / (4u << 20) + 1));
-            std::atomic<size_t> next_piece{0};
-            auto place = [&]() {
-                for (size_t k; (k = next_piece.fetch_add(64)) < pieces.size();)
-                    for (size_t q = k; q < std::min(pieces.size(), k + 64); ++q)
-                        if (!pieces[q].text.empty()) std::memcpy(&h->bed[at[q]], pieces[q].text.data(), pieces[q].text.size());
-            };
-            std::vector<std::thread> pool;
-            for (unsigned t = 1; t < nt; ++t) pool.emplace_back(place);
-            place();
-            for (std::thread &th : pool) th.join();
-        } else h->bed.clear();                         // an empty query somewhere (or no batches): the whole record in one call (below)
+        if (done) join_pieces(h, pieces, threads);     // the pieces' text into place on the threads (150 MB for a chromosome)
+        else h->bed.clear();                           // an empty query somewhere (or no batches): the whole record in one call (below)
         t_join = now_ms() - tj0;
         if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs (%zu long ones in their own batch: %.1f ms, set up first in %.1f ms; %zu seeds set aside), set-up in all %.1f ms; %zu slices: "
                                   "feeder %.1f ms in all (GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms); workers: %.1f ms in their calls, waited %.1f ms "
                                   "for slices, %.1f ms for the long batch; seeds set aside for it %.1f ms; %zu seeds with jobs beyond the kernels' reach refined on the host beside all that in %.1f ms; "
-                                  "rows put together %.1f ms; since the call began %.1f ms\n",
-                                  n_jobs, long_jobs.size(), t_long, t_setup_long, later.size(), t_setup, n_slices, t_feed, t_passes, t_paths, t_work, t_wait, t_wait_long, t_later, giants.size(), t_later_thread, t_join,
+                                  "nodes put off, level by level %.1f ms; rows put together %.1f ms; since the call began %.1f ms\n",
+                                  n_jobs, long_jobs.size(), t_long, t_setup_long, later.size(), t_setup, n_slices, t_feed, t_passes, t_paths, t_work, t_wait, t_wait_long, t_later, giants.size(), t_later_thread, t_levels, t_join,
                                   now_ms() - t_begin);
         add_ms(t_jobs_us, t_wait + t_wait_long);
     }
     static const char *const shared_env = std::getenv("RIBBIT_SHARED_SSW");
     static const size_t shared_max_seeds = std::getenv("RIBBIT_SHARED_MAX_SEEDS") ? (size_t)std::atoll(std::getenv("RIBBIT_SHARED_MAX_SEEDS")) : 100000;
     if (!done && !gpu_ssw && h->batcher && !h->dispatch.empty() && h->dispatch.size() <= shared_max_seeds && h->dev_ascii_src &&
-        !(shared_env && std::atoi(shared_env) == 0)) {
+        shared_env && std::atoi(shared_env) != 0) {      // (the batcher is there for the levels below; first-level jobs join it only on request)
         // a short record among several in flight: its alignment jobs join the shared batch of this GPU's batcher
         std::vector<RibbitAlignJob> jobs;
         std::string pool;
@@ -2468,14 +2606,38 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             return sb.rc;
         }
     }
+    if (!done && !gpu_ssw && defer_min_length() > 0 && h->dev_ascii_src && !h->dispatch.empty()) {
+        // A short record (a read among many in flight): its seeds are refined on the host threads, but the expensive nodes of
+        // its long-motif seeds -- first level or flanks -- are put off and done in GPU batches of their own, level by level.
+        t0 = now_ms();
+        std::vector<rb::DeferredNode> put_off;
+        std::mutex put_off_lock;
+        const rb::Deferral tree = make_deferral(&put_off, &put_off_lock);
+        std::vector<rb::BedPiece> pieces;
+        bool order_dependent = false;
+        rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sequence_id, h->bed,
+                          h->host_threads, nullptr, nullptr, nullptr, 0, (size_t)-1, &order_dependent, &small, nullptr, nullptr, &pieces, nullptr, 0, &tree);
+        bool no_room = false;
+        if (!order_dependent && !put_off.empty()) {
+            int64_t counts[3] = {0, 0, 0};
+            rc = refine_levels(h, *prm, sequence_id, put_off, pieces, threads, &order_dependent, counts);
+            for (int k = 0; k < 3; ++k) g_level_counts[k] += counts[k];
+            if (rc == RIBBIT_E_NOMEM) { rc = RIBBIT_OK; no_room = true; }
+            if (rc) return rc;
+        }
+        if (!order_dependent && !no_room) { join_pieces(h, pieces, threads); done = true; }
+        else h->bed.clear();
+        add_ms(t_text_us, now_ms() - t0);
+    }
     if (!done) {
         t0 = now_ms();
         rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(), sequence_id, h->bed,
                           h->host_threads, nullptr, nullptr, nullptr, 0, (size_t)-1, nullptr, &small);
+        add_ms(t_text_us, now_ms() - t0);
     }
-    add_ms(t_text_us, now_ms() - t0);
-    if (profile) std::fprintf(stderr, "[refine_bed] cumulative: GPU scans of the seeds %.1f ms, alignment set-up + GPU striped passes %.1f ms, host refinement + BED %.1f ms\n",
-                              t_rows_us.load() / 1000.0, t_jobs_us.load() / 1000.0, t_text_us.load() / 1000.0);
+    if (profile) std::fprintf(stderr, "[refine_bed] cumulative: GPU scans of the seeds %.1f ms, alignment set-up + GPU striped passes %.1f ms, host refinement + BED %.1f ms; nodes put off for GPU batches: %lld in %lld levels (%lld alignments)\n",
+                              t_rows_us.load() / 1000.0, t_jobs_us.load() / 1000.0, t_text_us.load() / 1000.0,
+                              (long long)g_level_counts[1].load(), (long long)g_level_counts[0].load(), (long long)g_level_counts[2].load());
     *text = h->bed.c_str();
     *len = h->bed.size();
     return RIBBIT_OK;
@@ -2699,6 +2861,10 @@ void ribbit_debug_alignment_counters(int64_t out[3]) {
     long a = 0, b = 0, c = 0;
     rb::alignment_counters(a, b, c);
     out[0] = a; out[1] = b; out[2] = c;
+}
+
+void ribbit_debug_level_counters(int64_t out[3]) {
+    for (int k = 0; k < 3; ++k) out[k] = g_level_counts[k].load();
 }
 
 void ribbit_debug_small_motif_counters(int64_t out[2]) {

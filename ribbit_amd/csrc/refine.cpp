@@ -10,6 +10,7 @@
 #include <sstream>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 
@@ -651,6 +652,21 @@ struct Writer {
         return Span{sequence + start, std::min(len, b.L - start)};
     }
     bool saw_empty_query = false;   // the one order dependence between seeds: see refine_to_bed
+    // ---- pieces and the recursion tree (refine.h: BedPiece, DeferredNode).  With a sink the rows go out as pieces: a piece is
+    // closed wherever the next rows in printing order are not made here (a seed left out, a node put off).
+    std::vector<BedPiece> *sink = nullptr;
+    uint32_t seg_first = 0;         // label of the open piece
+    std::string seg_path;
+    const Deferral *tree = nullptr;
+    uint32_t cur_root = 0;          // the seed being refined and the place of the node being refined in its tree
+    std::string cur_path;
+    bool deferred_in_seed = false;
+    std::vector<DeferredNode> deferred;      // handed over by the caller when the writer is done
+    void flush_piece(uint32_t next_first) {
+        if (sink && !os.s.empty()) { sink->push_back(BedPiece{seg_first, std::move(os.s), seg_path}); os.s.clear(); }
+        seg_first = next_first;
+        seg_path.clear();
+    }
     // first-level alignments whose striped passes the GPU has done already: the jobs of the current seed, in the
     // order in which small_seed / long_seed reach them (build_align_jobs follows the same control flow)
     const RibbitAlignJob *jobs = nullptr;
@@ -691,6 +707,8 @@ struct Writer {
     }
     void row(const Repeat &r, const std::string &motif, int atom, int m, int type) {   // parse_seed.cpp:434-436
         Stopwatch sw(&tl.t_row);
+        // the first row after a node of this seed was put off opens a piece of its own, labelled with the place of its node
+        if (deferred_in_seed && os.s.empty()) { seg_first = cur_root; seg_path = cur_path; }
         // id \t start \t end \t motif \t atom | m \t length \t units \t purity \t + \t SEED-type \t cigar \n.  The purity is a float
         // through an ostream in the reference: "%g" at the default precision of 6, which is what num_put hands to printf
         std::string &t = os.s;
@@ -735,20 +753,31 @@ struct Writer {
         }
     }
 
-    void long_seed(int start, int end, int m, int type, int longest, int known_row, int depth) {       // processSeed
+    // root_call: the node is the one the caller asked for (a dispatched seed, or a node put off earlier): its alignment may be
+    // among the jobs the GPU has done
+    void long_seed(int start, int end, int m, int type, int longest, int known_row, int depth, bool root_call) {       // processSeed
         if (depth > 10000) return;
         if (end - start < 0.9 * m) return;
         if (longest < 0) longest = longest_run_host(hp, m, start, end);
         if (longest < prm.continuous_ones_threshold) return;
         const int seq_len = usable_length(b, start, end, m);
+        const int ppr_len = padded_length(seq_len, m, seq_len, prm.purity_threshold);
+        if (tree && tree->out && sink && seq_len >= tree->min_length && !(root_call && jobs) &&
+            std::min(seq_len, b.L - start) <= tree->max_query && ppr_len <= tree->max_ref && start >= 0) {
+            // worth a GPU batch: not done here.  What has been printed so far is a piece of its own; the node's rows will sort
+            // behind it, and whatever this seed prints afterwards behind them
+            flush_piece(cur_root);
+            deferred_in_seed = true;
+            deferred.push_back(DeferredNode{start, end, m, type, longest, known_row, cur_root, cur_path});
+            return;
+        }
         Wide unit;
         { Stopwatch sw(&tl.t_long); unit = unit_at(b, known_row >= 0 ? known_row : consensus_row(b, start, seq_len, m), m); }
         int atom;
         { Stopwatch swa(&tl.t_atom); atom = long_atomicity(unit, m); }
         if (m % atom != 0) return;
         const std::string motif = spell(unit, m, atom);
-        const std::string &cigar = align(slice(start, seq_len), motif, padded_length(seq_len, m, seq_len, prm.purity_threshold),
-                                         depth == 0 ? std::max(start, 0) : -1);
+        const std::string &cigar = align(slice(start, seq_len), motif, ppr_len, root_call ? std::max(start, 0) : -1);
         Repeat r;
         { Stopwatch swd(&tl.t_digest); r = digest_cigar(start, seq_len, cigar, atom, true, prm); }
         if (r.alignment_length >= prm.min_length[atom] && r.end - r.start >= prm.min_length[m]) row(r, motif, atom, m, type);
@@ -756,11 +785,19 @@ struct Writer {
         const int right_from = r.end - atom;
         if (start < r.start) {
             const int left_to = std::min(r.start, end);
-            if (r.start - start >= prm.min_length[m] && !(left_to == end)) long_seed(start, left_to, m, type, -1, -1, depth + 1);
+            if (r.start - start >= prm.min_length[m] && !(left_to == end)) {
+                cur_path.push_back('1');
+                long_seed(start, left_to, m, type, -1, -1, depth + 1, false);
+                cur_path.pop_back();
+            }
         }
         if (end - right_from >= prm.min_length[m]) {
             const int from = std::max(right_from, start);
-            if (from != start) long_seed(from, end, m, type, -1, -1, depth + 1);
+            if (from != start) {
+                cur_path.push_back('2');
+                long_seed(from, end, m, type, -1, -1, depth + 1, false);
+                cur_path.pop_back();
+            }
         }
     }
 };
@@ -773,7 +810,16 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
                    const std::vector<RibbitAlignJob> *jobs, const std::vector<SswEnds> *ends, const std::vector<SswPath> *paths,
                    size_t seed_lo, size_t seed_hi, bool *order_dependent, const SmallMotifTable *small,
                    const uint32_t *job_first_all, const uint8_t *skip, std::vector<BedPiece> *pieces, const std::vector<uint32_t> *only,
-                   size_t job_first_given_base) {
+                   size_t job_first_given_base, const Deferral *tree) {
+    if (!pieces || !order_dependent) tree = nullptr;   // rows that go straight into `bed` cannot be put in order afterwards; and a call
+                                                       // that redoes its range itself on an empty query would put its nodes off twice
+    const DeferredNode *nodes = tree ? tree->nodes : nullptr;
+    auto hand_over = [&](Writer &w) {        // the nodes a writer put off, to the caller's list
+        if (w.deferred.empty()) return;
+        std::lock_guard<std::mutex> lk(*static_cast<std::mutex *>(tree->lock));
+        for (DeferredNode &nd : w.deferred) tree->out->push_back(std::move(nd));
+        w.deferred.clear();
+    };
     const auto wall0 = std::chrono::steady_clock::now();
     const Bases b(hp, host_threads);
     seed_hi = std::min(seed_hi, dispatch.size());
@@ -800,27 +846,31 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
     auto prepare = [&](Writer &w) {
         if (have_jobs) { w.jobs = jobs->data(); w.ends = ends->data(); w.paths = (paths && paths->size() == jobs->size()) ? paths->data() : nullptr; }
         w.small = small;
+        w.tree = tree;
     };
     auto one_seed = [&](size_t i, Writer &w) {
         const RibbitSeed &seed = dispatch[i];
         if (have_jobs) w.begin_seed(job_first[i - job_first_base], job_first[i - job_first_base + 1]);
+        // where the seed's rows belong: its own index, or -- a node put off earlier -- its place in its seed's tree
+        w.cur_root = nodes ? nodes[i].root : (uint32_t)i;
+        if (nodes) w.cur_path = nodes[i].path; else w.cur_path.clear();
+        w.deferred_in_seed = false;
         if (seed.mlen <= 10) { Stopwatch sws(&tl.t_small_all); w.small_seed(seed, longest_runs[i], i); }
-        else { Stopwatch swl(&tl.t_long_all); w.long_seed(seed.start, seed.end, seed.mlen, seed.type, longest_runs[i], best_rows ? best_rows[i] : -1, 0); }
+        else { Stopwatch swl(&tl.t_long_all); w.long_seed(seed.start, seed.end, seed.mlen, seed.type, longest_runs[i], best_rows ? best_rows[i] : -1, (int)w.cur_path.size(), true); }
     };
-    // seeds lo .. hi into `out`; with `skip`, into segments cut at every seed left out
+    // seeds lo .. hi into `out`; with `segments`, into pieces cut at every seed left out and around every node put off
     auto run_range = [&](size_t lo, size_t hi, Writer &w, std::vector<BedPiece> *segments) {
         prepare(w);
-        size_t seg_start = lo;
-        auto close_segment = [&](size_t next_start) {
-            if (segments && w.os.tellp() > 0) { segments->push_back(BedPiece{(uint32_t)seg_start, w.os.str()}); w.os.str(std::string()); }
-            seg_start = next_start;
-        };
+        w.sink = segments;
+        w.seg_first = (uint32_t)lo;
         for (size_t i = lo; i < hi; ++i) {
             prefetch_small_records(small, i + 12, dispatch.size());
-            if (skip && skip[i]) { close_segment(i + 1); continue; }
+            if (skip && skip[i]) { w.flush_piece((uint32_t)(i + 1)); continue; }
             one_seed(i, w);
+            if (w.deferred_in_seed) { w.flush_piece((uint32_t)(i + 1)); w.deferred_in_seed = false; }
         }
-        if (segments) close_segment(hi);
+        if (segments) w.flush_piece((uint32_t)hi);
+        hand_over(w);
     };
     // Seeds are refined independently of each other, except that an alignment with an EMPTY query leaves the
     // reference's shared Alignment object untouched and so sees the previous seed's CIGAR.  Chunks of seeds
@@ -832,18 +882,27 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
     threads = std::max(1u, std::min(threads, 256u));
     if (only) {
         // the seeds an earlier call left out, each a piece of its own (they are few and individually expensive)
-        std::vector<BedPiece> &out = *pieces;
-        const size_t base = out.size();
-        out.resize(base + n_seeds);
+        // (a seed is one piece, or several around the nodes it put off; a thread collects its own and adds them at the end)
         std::atomic<size_t> next{0};
         std::atomic<bool> empty_seen{false};
+        std::mutex out_lock;
         auto work = [&]() {
+            std::vector<BedPiece> mine;
             for (size_t k; (k = next.fetch_add(1)) < n_seeds;) {
+                const size_t i = (*only)[k];
                 Writer w(b, hp, sequence, prm, sequence_id);
                 prepare(w);
-                one_seed((*only)[k], w);
+                w.sink = &mine;
+                w.seg_first = nodes ? nodes[i].root : (uint32_t)i;
+                if (nodes) w.seg_path = nodes[i].path;
+                one_seed(i, w);
                 if (w.saw_empty_query) empty_seen = true;
-                out[base + k] = BedPiece{(*only)[k], w.os.str()};
+                w.flush_piece(0);
+                hand_over(w);
+            }
+            if (!mine.empty()) {
+                std::lock_guard<std::mutex> lk(out_lock);
+                for (BedPiece &pc : mine) pieces->push_back(std::move(pc));
             }
             flush_counters();
         };

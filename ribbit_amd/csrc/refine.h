@@ -67,7 +67,31 @@ int longest_run_host(const HostPlanes &hp, int mlen, int start, int end);
 // and the BED rows (11 tab-separated columns) appended to `bed`.  sequence = the record's bases.
 // One run of BED rows: the rows of the seeds from `first_seed` on up to the next piece's first seed.  A record refined in
 // several calls (slices of the seed list, seeds left for a later call) is put together by ordering the pieces by first_seed.
-struct BedPiece { uint32_t first_seed; std::string text; };
+// path: empty for whole seeds; for the rows of a PART of a long-motif seed's recursion tree (below) the place of the part's
+// first node in that tree -- pieces are ordered by (first_seed, path), which is the order processSeed prints in.
+struct BedPiece { uint32_t first_seed; std::string text; std::string path; };
+
+// processSeed (parse_seed.cpp:318-464) is a recursion: align the seed, print its row, then do the same with what is left on
+// either side of the aligned repeat (:443-463).  The rows come out in pre-order (node, left subtree, right subtree), and a node
+// depends on nothing but its own interval, so a node may be put off and done later, on the GPU, with many others -- the
+// consensus-row kernel and the alignment kernels take it like any first-level seed -- as long as its rows end up in its place.
+// A node's place is its path from the seed: '1' for the left flank, '2' for the right one; pre-order is the plain
+// lexicographic order of the paths.  At -M 100 such nodes are few; at -M 500 (BASELINE.json configs[4]) the nodes of 700
+// bases and more were 98 % of the consensus time and 92 % of the alignment time of refinement, on host threads.
+struct DeferredNode {
+    int32_t start, end, mlen, type;
+    int32_t longest;        // longestContinuousMatches of the interval (computed before the node was put off: it decides whether the node exists)
+    int32_t known_row;      // consensus row if known already (a first-level seed whose row the GPU scan made), else -1
+    uint32_t root;          // dispatch index of the seed the node descends from
+    std::string path;       // "" = the seed itself
+};
+struct Deferral {
+    std::vector<DeferredNode> *out = nullptr;   // where nodes that are put off go (appended under `lock`); null: nothing is put off
+    void *lock = nullptr;                        // std::mutex *
+    int min_length = 0;                         // a node is put off when its usable length reaches this ...
+    int max_query = 0, max_ref = 0;             // ... and its alignment fits the kernels (query, padded reference)
+    const DeferredNode *nodes = nullptr;        // non-null: `dispatch` IS a list of nodes put off earlier (dispatch[k] = nodes[k]'s interval)
+};
 
 void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
                    const SeedVec &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
@@ -76,7 +100,10 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
                    const std::vector<SswPath> *paths = nullptr, size_t seed_lo = 0, size_t seed_hi = (size_t)-1,
                    bool *order_dependent = nullptr, const SmallMotifTable *small = nullptr,
                    const uint32_t *job_first = nullptr, const uint8_t *skip = nullptr, std::vector<BedPiece> *pieces = nullptr,
-                   const std::vector<uint32_t> *only = nullptr, size_t job_first_base = 0);
+                   const std::vector<uint32_t> *only = nullptr, size_t job_first_base = 0, const Deferral *tree = nullptr);
+// tree (optional, needs pieces): nodes of long-motif seeds' recursion trees that are worth a GPU batch are not done here but
+// appended to tree->out, and the rows around them are cut into pieces that sort into place; with tree->nodes the call refines
+// such nodes (one per entry of `dispatch`, with `only`).
 // job_first (optional, with jobs): job_first[i - job_first_base] = first job (index into jobs) of dispatch seed i, for every seed
 // the call refines and the one after it (else it is worked out from the jobs' seed indices on every call).  With a base, `jobs`
 // may hold the jobs of a slice of the seed list only.

@@ -182,7 +182,7 @@ def write_fasta(path: str, records: list[tuple[str, bytes]], width: int = 80) ->
 
 # BASELINE.json configs[2] / configs[3] stand-in (GRCh38 itself is on no box): 24 records with the primary
 # assembly's lengths.  One definition for everything that makes or checks these records -- bench.py's chr1_full_path leg,
-# tools/grch38_shape.py, tools/full_size_digests.py and the digests under tests/golden/ -- so that they cannot drift apart.
+# tools/grch38_shape.py, tests/golden/make_full_size_digests.py and the digests under tests/golden/ -- so that they cannot drift apart.
 GRCH38_RECORDS = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555), ("chr5", 181538259), ("chr6", 170805979),
                   ("chr7", 159345973), ("chr8", 145138636), ("chr9", 138394717), ("chr10", 133797422), ("chr11", 135086622), ("chr12", 133275309),
                   ("chr13", 114364328), ("chr14", 107043718), ("chr15", 101991189), ("chr16", 90338345), ("chr17", 83257441), ("chr18", 80373285),
