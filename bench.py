@@ -175,6 +175,24 @@ def chr1_record(bases: int) -> bytes:
     return grch38_shaped_record(0, bases, M_LO, M_HI)
 
 
+def verify_chr1_digest(bases: int, bed_rows: int, bed_sha: str) -> dict:
+    """-> {"verified": true / false / null, "verification": {...}}: the BED text of the chr1_full_path leg against the committed
+    digest of the oracle pipeline's BED for the same record (tests/golden/grch38_shape_digests.json, record "chr1": generator
+    seed 4 + N blocks, 248,956,422 bases, -m 2 -M 100).  null: no digest for this size (--chr1-bases other than the full one)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "grch38_shape_digests.json")
+    try:
+        want = json.load(open(path))["records"]["chr1"]
+    except (OSError, KeyError, ValueError) as e:
+        return {"verified": None, "verification": {"what": f"no digest available ({type(e).__name__})"}}
+    if want["bases"] != bases or (want["m_lo"], want["m_hi"]) != (M_LO, M_HI):
+        return {"verified": None, "verification": {"what": f"the committed digest is for {want['bases']} bases, -m {want['m_lo']} -M {want['m_hi']}; this run: {bases} bases"}}
+    ok = bool(want["sha256"] == bed_sha and want["bed_rows"] == bed_rows)
+    return {"verified": ok, "verification": {"bed_sha256_oracle": want["sha256"], "bed_rows_oracle": want["bed_rows"], "oracle_seconds_one_core": want["oracle_seconds"],
+                                             "what": "SHA-256 and row count of the whole BED text == the CPU oracle pipeline's for the same 248,956,422-base record "
+                                                     "(tests/golden/grch38_shape_digests.json, made by tests/golden/make_full_size_digests.py; the oracle is a "
+                                                     "restatement of the reference: parity unpinned, DESIGN.md 2)"}}
+
+
 def chr1_full_path(ribbit_amd, bases: int, device: int, traffic: dict):
     """BASELINE.json configs[2] on its largest record: perfect + substitution + anchored scans, merges, dispatch,
     refinement, BED text.  Two passes over the scans and merges (the first includes every allocation), one refinement."""
@@ -213,6 +231,11 @@ def chr1_full_path(ribbit_amd, bases: int, device: int, traffic: dict):
         bed = sc.refine_bed_view("chr1")
         t4 = time.perf_counter()
         bed_rows = int(np.count_nonzero(bed == ord("\n")))
+        # full-size identity, outside the timed region: the SHA-256 of the BED text against the digest the ORACLE pipeline
+        # (oracle/, CPU, tests/golden/make_full_size_digests.py: 18 minutes on one core of the build container) wrote for
+        # exactly this record
+        import hashlib
+        bed_sha = hashlib.sha256(np.ascontiguousarray(bed)).hexdigest()
         del bed
     scans = passes[1]["scans_and_merges_s"]
     out.update({
@@ -220,9 +243,13 @@ def chr1_full_path(ribbit_amd, bases: int, device: int, traffic: dict):
         "seconds": scans + (t4 - t3), "value": bases / (scans + (t4 - t3)) / 1e9, "unit": "Gbases/s",
         "scans_and_merges_gbases_per_s": bases / scans / 1e9,
         "seeds": {"perfect": n_lists[0], "substitution": n_lists[1], "anchored": n_lists[2]},
-        "dispatched": n_lists[3], "bed_rows": bed_rows,
-        "what": "one chromosome-1-sized record, -m 2 -M 100: FASTA record in page-locked memory -> BED text (pass 2 of the scans and "
-                "merges; pass 1, with every allocation, is listed too); the seed lists and the BED text are taken as the C ABI returns them, by pointer"})
+        "dispatched": n_lists[3], "bed_rows": bed_rows, "bed_sha256": bed_sha,
+        "pass_1_scans_and_merges_s": passes[0]["scans_and_merges_s"], "pass_2_scans_and_merges_s": passes[1]["scans_and_merges_s"],
+        "cold_seconds": passes[0]["scans_and_merges_s"] + (t4 - t3),
+        "what": "one chromosome-1-sized record, -m 2 -M 100: FASTA record in page-locked memory -> BED text.  `seconds` = pass 2 of the scans and "
+                "merges (buffers in place) + refinement; `cold_seconds` = pass 1 (every allocation, what a cold ribbit-hip pays) + refinement; "
+                "the seed lists and the BED text are taken as the C ABI returns them, by pointer"})
+    out.update(verify_chr1_digest(bases, bed_rows, bed_sha))
     roof = {}
     for name, key in (("scan_window_kernel<1>", "scan_window_kernel"), ("scan_anchored_kernel", "scan_anchored_kernel"), ("scan_perfect_kernel", None)):
         # "scan_anchored_kernel": the anchored stage's scan, i.e. its planes kernel and the window scan of the planes together

@@ -987,10 +987,17 @@ int advance_to_anchored(RibbitHandle *h) {
         h->xa_on_device = true;
     }
     if ((rc = bind_device(h))) return rc;
+    const double tx0 = now_ms();
     if ((rc = xa_copy_begin(h))) return rc;
+    const double tx1 = now_ms();
     if (subst_todo) subst_merge(h, subst_full ? nullptr : &dcs);
     const double merge_s = h->merge_ms;
+    const double tx2 = now_ms();
     if ((rc = xa_wait_host(h))) return rc;
+    static const bool profile_xa = std::getenv("RIBBIT_PROFILE") != nullptr;
+    if (profile_xa)
+        std::fprintf(stderr, "[composed planes] %.2f GB to the host for the merges' range reads: page-locked room and enqueue %.1f ms, waited %.1f ms for the copy after the substitution merge\n",
+                     (double)(h->params.max_motif - h->params.min_motif + 1) * (double)h->xa_stride * 4e-9, tx1 - tx0, now_ms() - tx2);
     // from here on "plane m" means the composed plane XA_m (fasta_utils.cpp:159)
     const rb::HostPlanes *hp = &h->host;
     h->lists.range_count = [hp](int shift, int start, int end) {
@@ -2063,8 +2070,10 @@ static rb::Deferral make_deferral(std::vector<rb::DeferredNode> *out, std::mutex
 // there are -- where the host threads need 20: levels own-batched all the way down took 6.6 s, 3.5 of them below level 8.
 constexpr size_t LEVEL_OWN_BATCH = 400;
 static int refine_levels(RibbitHandle *h, const RibbitRefineParams &prm, const std::string &sequence_id, std::vector<rb::DeferredNode> &nodes,
-                         std::vector<rb::BedPiece> &pieces, unsigned threads, bool *order_dependent, int64_t counts[3]) {
+                         std::vector<rb::BedPiece> &pieces, unsigned threads, bool *order_dependent, int64_t counts[3], bool may_share) {
     static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
+    const char *own_env = std::getenv("RIBBIT_LEVEL_MIN");          // (test hook, read per record: levels from this many nodes on get a batch of their own)
+    const size_t own_batch = own_env ? (size_t)std::max(1, std::atoi(own_env)) : LEVEL_OWN_BATCH;
     static const bool level_lines = profile && std::getenv("RIBBIT_PROFILE_LEVELS") != nullptr;
     std::vector<rb::DeferredNode> next;
     std::mutex lock;
@@ -2082,9 +2091,9 @@ static int refine_levels(RibbitHandle *h, const RibbitRefineParams &prm, const s
             seeds[i] = RibbitSeed{nodes[i].start, nodes[i].end, nodes[i].mlen, nodes[i].type};
             longest[i] = nodes[i].longest; best[i] = nodes[i].known_row; all[i] = (uint32_t)i;
         }
-        const bool shared = h->batcher != nullptr && n < 8 * LEVEL_OWN_BATCH;
+        const bool shared = may_share && h->batcher != nullptr && n < 8 * own_batch;
         bool od = false;
-        if (!shared && n < LEVEL_OWN_BATCH) {
+        if (!shared && n < own_batch) {
             // too few for a batch of their own: here, by recursion, nothing put off any further
             rb::Deferral d;
             d.nodes = nodes.data();
@@ -2563,7 +2572,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             // the nodes put off by all of the above, level by level on this handle's streams (nothing else runs on them now)
             const double tv0 = now_ms();
             int64_t counts[3] = {0, 0, 0};
-            rc = refine_levels(h, *prm, sequence_id, put_off, pieces, threads, &order_dependent, counts);
+            rc = refine_levels(h, *prm, sequence_id, put_off, pieces, threads, &order_dependent, counts, false);
             for (int k = 0; k < 3; ++k) g_level_counts[k] += counts[k];
             if (rc == RIBBIT_E_NOMEM) { rc = RIBBIT_OK; batches_failed = true; }
             if (rc) return rc;
@@ -2606,9 +2615,15 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             return sb.rc;
         }
     }
-    if (!done && !gpu_ssw && defer_min_length() > 0 && h->dev_ascii_src && !h->dispatch.empty()) {
-        // A short record (a read among many in flight): its seeds are refined on the host threads, but the expensive nodes of
-        // its long-motif seeds -- first level or flanks -- are put off and done in GPU batches of their own, level by level.
+    const char *defer_reads_env = std::getenv("RIBBIT_DEFER_READS");
+    if (!done && !gpu_ssw && defer_reads_env && std::atoi(defer_reads_env) != 0 && defer_min_length() > 0 && h->dev_ascii_src && !h->dispatch.empty()) {
+        // A short record (a read among many in flight): its seeds are refined on the host threads; with RIBBIT_DEFER_READS=1 the
+        // expensive nodes of its long-motif seeds -- first level or flanks -- are put off and done in GPU batches, level by level
+        // (the GPU's shared batches when the handle has a batcher).  OFF by default, by measurement (100 Mbp of 10-100 kb reads
+        // at -M 500, tools/m500_probe.py): 22.8 s on the host threads alone, 104 s with 8 reads in flight sharing batches, 53 s
+        // with 32 -- a read's tree is 3-7 levels deep with 5-30 nodes a level, every level waits for a batch, and a batch lasts
+        // as long as its longest alignment (tens of milliseconds on one workgroup where a host thread needs ten).  What did pay
+        // for the reads is the consensus rows with AVX-512 (refine.cpp).
         t0 = now_ms();
         std::vector<rb::DeferredNode> put_off;
         std::mutex put_off_lock;
@@ -2620,7 +2635,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         bool no_room = false;
         if (!order_dependent && !put_off.empty()) {
             int64_t counts[3] = {0, 0, 0};
-            rc = refine_levels(h, *prm, sequence_id, put_off, pieces, threads, &order_dependent, counts);
+            rc = refine_levels(h, *prm, sequence_id, put_off, pieces, threads, &order_dependent, counts, true);
             for (int k = 0; k < 3; ++k) g_level_counts[k] += counts[k];
             if (rc == RIBBIT_E_NOMEM) { rc = RIBBIT_OK; no_room = true; }
             if (rc) return rc;

@@ -8,9 +8,9 @@ namespace rb {
 
 std::shared_ptr<const std::vector<uint8_t>> HostPlanes::symbols(unsigned threads) const {
     std::lock_guard<std::mutex> lk(sym_mu_);
-    // (16 entries of padding, all 4 = N: consensus_row compares eight symbols at a time and may read a few past the record)
-    if (sym_cache_ && sym_cache_->size() == (size_t)length + 16) return sym_cache_;
-    auto sym = std::make_shared<std::vector<uint8_t>>((size_t)length + 16, (uint8_t)4);
+    // (80 entries of padding, all 4 = N: consensus_row compares up to 64 symbols at a time and may read that far past the record)
+    if (sym_cache_ && sym_cache_->size() == (size_t)length + 80) return sym_cache_;
+    auto sym = std::make_shared<std::vector<uint8_t>>((size_t)length + 80, (uint8_t)4);
     uint8_t *out = sym->data();
     const int64_t nw = (length + 31) / 32;
     auto decode = [&](int64_t w0, int64_t w1) {

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <immintrin.h>
 #include <sstream>
 #include <cstring>
 #include <functional>
@@ -201,7 +202,50 @@ Wide unit_at(const Bases &b, int row, int m) {                           // pars
     return unit;
 }
 
-int consensus_row(const Bases &b, int seed_start, int seq_len, int m) {
+// The five jittered diagonals of one step of consensus_row, 64 / 32 symbols at a time where the host has AVX-512BW / AVX2
+// (chosen once at run time; the plain 8-at-a-time form below is the fallback and the definition): at -M 500 this loop was
+// 45 % of refinement's host time on a stream of reads (1209 of 2689 thread-seconds per Gbp).
+// cnt[x]: symbols diagonal x compares (0: none), most: the largest of them.
+__attribute__((target("avx512bw,avx512vl"))) void diagonals5_avx512(const uint8_t *sym, int row0, int col0, const int (&cnt)[5], int most, int (&matches)[5]) {
+    const __m512i four = _mm512_set1_epi8(4);
+    for (int i = 0; i < most; i += 64) {
+        const __m512i rb = _mm512_loadu_si512((const void *)(sym + row0 + i));
+        for (int x = 0; x < 5; ++x) {
+            const int left = cnt[x] - i;
+            if (left <= 0) continue;
+            const __m512i a = _mm512_loadu_si512((const void *)(sym + (col0 + x - 2 + i)));
+            uint64_t eq = _mm512_cmpeq_epi8_mask(a, rb) & _mm512_cmplt_epu8_mask(a, four);
+            if (left < 64) eq &= (1ull << left) - 1ull;
+            matches[x] += __builtin_popcountll(eq);
+        }
+    }
+}
+__attribute__((target("avx2"))) void diagonals5_avx2(const uint8_t *sym, int row0, int col0, const int (&cnt)[5], int most, int (&matches)[5]) {
+    const __m256i four = _mm256_set1_epi8(4);
+    for (int i = 0; i < most; i += 32) {
+        const __m256i rb = _mm256_loadu_si256((const __m256i *)(sym + row0 + i));
+        for (int x = 0; x < 5; ++x) {
+            const int left = cnt[x] - i;
+            if (left <= 0) continue;
+            const __m256i a = _mm256_loadu_si256((const __m256i *)(sym + (col0 + x - 2 + i)));
+            const __m256i ok = _mm256_and_si256(_mm256_cmpeq_epi8(a, rb), _mm256_cmpgt_epi8(four, a));      // symbols are 0..4: signed compare is fine
+            uint32_t eq = (uint32_t)_mm256_movemask_epi8(ok);
+            if (left < 32) eq &= (1u << left) - 1u;
+            matches[x] += __builtin_popcount(eq);
+        }
+    }
+}
+int simd_level() {          // RIBBIT_HOST_SIMD=0/1/2 caps it (the tests compare the three forms)
+    static const int level = [] {
+        int have = __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") ? 2 : __builtin_cpu_supports("avx2") ? 1 : 0;
+        if (const char *env = std::getenv("RIBBIT_HOST_SIMD")) have = std::min(have, std::max(0, std::atoi(env)));
+        return have;
+    }();
+    return level;
+}
+
+int consensus_row(const Bases &b, int seed_start, int seq_len, int m, int simd = -1) {
+    if (simd < 0) simd = simd_level();
     const int seed_end = std::min(seed_start + seq_len, b.L);
     auto diagonal = [&](int row0, int col0, int lo, int hi, int n, int step) {
         // matches between rows row0, row0+step, ... and columns col0, col0+step, ...; stops at the first
@@ -227,6 +271,8 @@ int consensus_row(const Bases &b, int seed_start, int seq_len, int m) {
             most = std::max(most, cnt[x]);
             matches[x] = 0;
         }
+        if (simd == 2) { diagonals5_avx512(b.sym, row0, col0, cnt, most, matches); return; }
+        if (simd == 1) { diagonals5_avx2(b.sym, row0, col0, cnt, most, matches); return; }
         for (int i = 0; i < most; i += 8) {
             uint64_t rb8;
             std::memcpy(&rb8, b.sym + row0 + i, 8);

@@ -85,3 +85,35 @@ def test_jobs_are_plausible_on_simulated_repeats():
         rots = {motif[i:] + motif[:i] for i in range(m)}
         hits += any(int(j["query_start"]) < te and int(j["query_start"]) + int(j["query_length"]) > ts and mot in rots for j, mot in motifs)
     assert hits >= 0.85 * len(truth), (hits, len(truth))
+
+
+def test_consensus_rows_with_every_simd_form_give_the_same_bed():
+    """consensus_row (mostFrequentLongerMotif, parse_seed.cpp:153-256) compares 8 symbols at a time in plain C++, 32 with AVX2,
+    64 with AVX-512BW (chosen at run time; RIBBIT_HOST_SIMD caps the choice and is read once per process, hence the
+    subprocesses): the BED of a record with long motifs -- where the rows decide the motif strings -- must not depend on it,
+    and must be the oracle's."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = (
+        "import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\n"
+        "import ribbit_amd\n"
+        "from oracle_lib import Oracle\n"
+        "from ribbit_amd.simulate import simulate_sequence\n"
+        "seq, _ = simulate_sequence(250000, 91, 2, 300, n_block_rate=0.2)\n"
+        "with Oracle(seq, 2, 300) as o:\n"
+        "    o.run_all(); d = o.dispatch()\n"
+        "    xa, stride = ribbit_amd.pack_bit_planes([o.plane(m) for m in range(2, 301)], len(seq))\n"
+        "    want = o.refine_bed('x')\n"
+        "got = ribbit_amd.host_refine_bed(2, 300, seq, xa, stride, d, 'x')\n"
+        "print(hashlib.sha256(got.encode()).hexdigest(), got == want, got.count(chr(10)))\n" % (root, root))
+    seen = set()
+    for level in ("0", "1", "2"):
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, env=dict(os.environ, RIBBIT_HOST_SIMD=level))
+        assert r.returncode == 0, r.stderr[-1500:]
+        digest, same, rows = r.stdout.split()
+        assert same == "True" and int(rows) > 500, r.stdout
+        seen.add(digest)
+    assert len(seen) == 1

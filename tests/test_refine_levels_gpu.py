@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _bed_both(seq, m_lo, m_hi, env):
+    env = dict(env, RIBBIT_DEFER_READS="1")      # (a short record's host-thread form puts nodes off only on request)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -46,7 +47,9 @@ def long_motif_record():
 @pytest.mark.parametrize("defer_min", ["1", "150", "700", "0"])
 def test_nodes_put_off_for_the_gpu_leave_the_bed_unchanged(long_motif_record, gpu_ssw, defer_min):
     seq, want = long_motif_record
-    got, (levels, nodes, aligned) = _bed_both(seq, 2, 500, {"RIBBIT_GPU_SSW": gpu_ssw, "RIBBIT_DEFER_MIN": defer_min})
+    # (RIBBIT_LEVEL_MIN=1: every level gets a GPU batch of its own, however small; by default a level of fewer than 400 nodes
+    # is finished on the host threads)
+    got, (levels, nodes, aligned) = _bed_both(seq, 2, 500, {"RIBBIT_GPU_SSW": gpu_ssw, "RIBBIT_DEFER_MIN": defer_min, "RIBBIT_LEVEL_MIN": "1"})
     assert got == want
     if defer_min == "0":
         assert nodes == 0 and levels == 0
@@ -65,8 +68,9 @@ def test_every_case_with_every_node_put_off():
             o.run_all()
             want = o.refine_bed("rec")
         for gpu_ssw in ("0", "1"):
-            got, _ = _bed_both(seq, m_lo, m_hi, {"RIBBIT_GPU_SSW": gpu_ssw, "RIBBIT_DEFER_MIN": "1"})
-            assert got == want, (name, gpu_ssw)
+            for level_min in ("1", "3"):         # 3: the first levels batched, the tails by recursion on the host threads
+                got, _ = _bed_both(seq, m_lo, m_hi, {"RIBBIT_GPU_SSW": gpu_ssw, "RIBBIT_DEFER_MIN": "1", "RIBBIT_LEVEL_MIN": level_min})
+                assert got == want, (name, gpu_ssw, level_min)
 
 
 @pytest.mark.parametrize("block", range(4))
@@ -78,7 +82,7 @@ def test_fuzzed_records_with_every_node_put_off(block):
             o.run_all()
             want = o.refine_bed("rec")
         for gpu_ssw in ("0", "1"):
-            got, _ = _bed_both(seq, m_lo, m_hi, {"RIBBIT_GPU_SSW": gpu_ssw, "RIBBIT_DEFER_MIN": "1"})
+            got, _ = _bed_both(seq, m_lo, m_hi, {"RIBBIT_GPU_SSW": gpu_ssw, "RIBBIT_DEFER_MIN": "1", "RIBBIT_LEVEL_MIN": "1" if seed % 2 else "2"})
             assert got == want, (seed, gpu_ssw, len(seq), m_lo, m_hi)
 
 
@@ -101,7 +105,7 @@ def test_reads_in_flight_share_their_level_batches(tmp_path):
             want.append(o.refine_bed(name))
     want = "".join(want)
     for defer_min, shared in (("200", ""), ("700", ""), ("200", "0")):
-        env = dict(os.environ, RIBBIT_PROFILE="1", RIBBIT_DEFER_MIN=defer_min)
+        env = dict(os.environ, RIBBIT_PROFILE="1", RIBBIT_DEFER_MIN=defer_min, RIBBIT_DEFER_READS="1")
         if shared:
             env["RIBBIT_SHARED_SSW"] = shared
         r = subprocess.run([os.path.join(root, "ribbit_amd", "ribbit-hip"), "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "500", "--jobs", "6"],

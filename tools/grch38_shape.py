@@ -84,10 +84,35 @@ def main():
     if r.returncode != 0:
         print(r.stderr[-3000:], file=sys.stderr)
         raise SystemExit(r.returncode)
-    rows = sum(1 for _ in open(bed, "rb"))
+    # every record's rows against the digest the oracle pipeline wrote for it (tests/golden/grch38_shape_digests.json, made on
+    # the CPU by tests/golden/make_full_size_digests.py): SHA-256 and row count per record, outside the timed region
+    import hashlib
+    rows, per_record = 0, {}
+    cur, h, n = None, None, 0
+    with open(bed, "rb") as fh:
+        for line in fh:
+            name = line[:line.index(b"\t")].decode()
+            if name != cur:
+                if cur is not None:
+                    per_record[cur] = (h.hexdigest(), n)
+                cur, h, n = name, hashlib.sha256(), 0
+            h.update(line); n += 1; rows += 1
+    if cur is not None:
+        per_record[cur] = (h.hexdigest(), n)
+    digests = {}
+    try:
+        allv = json.load(open(os.path.join(ROOT, "tests", "golden", "grch38_shape_digests.json")))
+        digests = allv.get("records" if a.scale == 1.0 else f"records_scale_{a.scale}", {})
+    except (OSError, ValueError):
+        pass
+    checked = {name: (per_record.get(name, ("", 0)) == (d["sha256"], d["bed_rows"])) for (_, name, bases, _) in recs
+               for d in [digests.get(name)] if d and d["bases"] == bases}
+    verified = {"records_checked": len(checked), "records_identical": sum(checked.values()), "records_without_digest": len(recs) - len(checked),
+                "different": sorted(k for k, v in checked.items() if not v),
+                "what": "per record: SHA-256 and row count of its BED rows == the CPU oracle pipeline's (tests/golden/grch38_shape_digests.json)"}
     tail = [l for l in r.stderr.splitlines() if l.startswith("[stages") or l.startswith("[devices]") or l.startswith("[shared")]
     print(json.dumps({"workload": f"GRCh38-shaped set, {len(recs)} records, scale {a.scale}", "bases": total, "wall_s": wall, "mbases_per_s": total / wall / 1e6,
-                      "bed_rows": rows, "devices": a.devices or "0", "generate_s": t_gen, "profile": tail}), flush=True)
+                      "bed_rows": rows, "verified_records": verified, "devices": a.devices or "0", "generate_s": t_gen, "profile": tail}), flush=True)
     if not a.keep:
         os.remove(fasta); os.remove(bed)
 
