@@ -365,17 +365,20 @@ int main(int argc, char **argv) {
         handles.push_back(extra);
         handle_dev.push_back(dev);
     }
-    // Short records side by side on one GPU share alignment batches (the reference aligns seed by seed, parse_seed.cpp:404 /
+    // Short records side by side on one GPU can share alignment batches (the reference aligns seed by seed, parse_seed.cpp:404 /
     // parse_smallmotif_seed.cpp:270; a read has too few alignments to pay for batches of its own): one batcher per GPU slot,
-    // fed by all of that slot's handles.  What goes into the shared batches by default are the EXPENSIVE nodes of the reads'
-    // long-motif seeds (processSeed's recursion put off level by level, include/ribbit_hip.h: ribbit_debug_level_counters) --
-    // at -M 500 they are nine tenths of a read's refinement.  A read's thousand SHORT first-level alignments join only with
-    // RIBBIT_SHARED_SSW=1: measured on 400 reads of 50 kb at -M 100 with 8 and 16 in flight (tools/cli_reads_sweep.sh), that
-    // takes 1.84-2.2 s against 1.34-1.41 s with every record aligning them on its own two host threads.
-    // RIBBIT_SHARED_SSW=0: no batcher at all.
+    // fed by all of that slot's handles.  OFF unless asked for, by measurement:
+    //   RIBBIT_SHARED_SSW=1   the reads' short first-level alignments: 400 reads of 50 kb at -M 100 with 8 and 16 in flight
+    //                         (tools/cli_reads_sweep.sh) take 1.84-2.2 s against 1.34-1.41 s with every record aligning them on
+    //                         its own two host threads;
+    //   RIBBIT_DEFER_READS=1  the EXPENSIVE nodes of the reads' long-motif seeds (processSeed's recursion put off level by
+    //                         level, include/ribbit_hip.h: ribbit_debug_level_counters): 100 Mbp of reads at -M 500 take 53-104 s
+    //                         against 22.8 s on the host threads (tools/m500_probe.py; a batch lasts as long as its longest
+    //                         alignment and a read's tree needs 3-7 of them one after the other).
     std::vector<RibbitAlignBatcher *> batchers((size_t)ndev, nullptr);
     const char *shared_env = std::getenv("RIBBIT_SHARED_SSW");
-    if (jobs > 1 && !failed && !(shared_env && std::atoi(shared_env) == 0))
+    const char *defer_env = std::getenv("RIBBIT_DEFER_READS");
+    if (jobs > 1 && !failed && ((shared_env && std::atoi(shared_env) != 0) || (defer_env && std::atoi(defer_env) != 0)))
         for (int d = 0; d < ndev; ++d) {
             if (ribbit_hip_batcher_open(&scan, devices[(size_t)d], jobs, &batchers[(size_t)d]) != RIBBIT_OK) {
                 std::cerr << "ribbit-hip: no shared alignment batches on GPU " << devices[(size_t)d] << " (" << ribbit_hip_last_error() << ")\n";

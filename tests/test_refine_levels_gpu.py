@@ -104,16 +104,14 @@ def test_reads_in_flight_share_their_level_batches(tmp_path):
             o.run_all()
             want.append(o.refine_bed(name))
     want = "".join(want)
-    for defer_min, shared in (("200", ""), ("700", ""), ("200", "0")):
-        env = dict(os.environ, RIBBIT_PROFILE="1", RIBBIT_DEFER_MIN=defer_min, RIBBIT_DEFER_READS="1")
-        if shared:
-            env["RIBBIT_SHARED_SSW"] = shared
+    for defer_min, deferred in (("200", "1"), ("700", "1"), ("200", "0")):
+        env = dict(os.environ, RIBBIT_PROFILE="1", RIBBIT_DEFER_MIN=defer_min, RIBBIT_DEFER_READS=deferred)
         r = subprocess.run([os.path.join(root, "ribbit_amd", "ribbit-hip"), "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "500", "--jobs", "6"],
                            capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
-        assert bed.read_text() == want, (defer_min, shared)
+        assert bed.read_text() == want, (defer_min, deferred)
         m = re.search(r"\[shared alignment batches\] slot 0: (\d+) batches for (\d+) records, (\d+) alignment jobs", r.stderr)
-        if shared == "0":
-            assert m is None
+        if deferred == "0":
+            assert m is None          # the default: no batcher, every node on the read's own host threads
         else:
             assert m and int(m.group(3)) > 0 and int(m.group(2)) > int(m.group(1)), r.stderr[-1500:]      # batches held more than one record's nodes
