@@ -400,10 +400,17 @@ def main():
                     help="after the timed region, launch the known-byte-count stream-read kernel (for PMC passes)")
     ap.add_argument("--chr1-bases", type=int, default=CHR1_BASES,
                     help="size of the BASELINE configs[2] record of the chr1_full_path leg (0 = skip the leg)")
+    ap.add_argument("--max-motif", type=int, default=M_HI,
+                    help="-M of the run (default: BASELINE configs[1]'s 100).  Anything else is a profiling run -- tools/profile_bench.sh "
+                         "with 500 for configs[4]'s motif range -- and its line says so in config.workload; the headline is quoted at the default")
     ap.add_argument("--stage-kernels", action="store_true",
                     help="after the timed region, run the substitution and anchored scan kernels once on the workload record "
                          "(so that a profiler pass over this command sees all three scan kernels at the same size)")
     args = ap.parse_args()
+    global M_HI
+    if args.max_motif != M_HI:
+        M_HI = args.max_motif
+        args.chr1_bases = 0          # the chromosome leg and its digest are for -M 100
 
     # --gpus N without a launcher: start one process per GPU ourselves -- as a CHILD, before this process has touched a
     # GPU (an exec after HIP is initialised takes the machine down on this pool) -- and leave with its exit code.
@@ -711,7 +718,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 bit planes",
             "data": "synthetic (ribbit_amd.simulate, seeded restatement of data_simulation/simulate_data.py)",
-            "config": {"workload": f"{args.bases} bp synthetic record per GPU, -m {M_LO} -M {M_HI}, "
+            "config": {"workload": ("" if M_HI == 100 else "PROFILING RUN AT A NON-DEFAULT MOTIF RANGE: ") + f"{args.bases} bp synthetic record per GPU, -m {M_LO} -M {M_HI}, "
                                    "pack + perfect shift-XOR scan (BASELINE.json configs[1])",
                        "batches_in_flight": depth, "compute_streams": 1 if compute is not None else depth,
                        "kernel_timing": f"HIP events on every {depth}th launch of the timed region" if depth > 1 else "HIP events on every launch",

@@ -280,25 +280,6 @@ int ribbit_hip_ssw_align_jobs(RibbitHandle *h, const RibbitAlignJob *jobs, size_
 int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const char *sequence_id,
                           const char **text, size_t *len);
 
-/*
- * ---- alignment batches across the records in flight ----------------------------------------------------------------
- * The reference aligns every seed where it finds it (Aligner::Align at parse_seed.cpp:404, parse_smallmotif_seed.cpp:270),
- * one record after the other (ribbit.cpp:269-280).  A caller that keeps several SHORT records in flight on one GPU -- long
- * reads: thousands of 10-100 kb records -- gives each a few hundred alignments, too few to pay for batches of their own.
- * A batcher collects the first-level alignment jobs of all records that reach refinement within a short window (their
- * bases copied device-to-device into one staging buffer), runs the striped passes and the path searches of all of them in
- * one set of launches on streams of its own, and hands every record its results.  Queries of up to 512 bases go through
- * it (the rest -- a few per read -- is aligned on that record's host threads, as without a batcher); records with two
- * million dispatched seeds or more keep running batches of their own.  Results are the library's either way.
- * ribbit_hip_set_batcher attaches a handle (same device) or, with NULL, detaches it; a batcher must outlive its handles'
- * last ribbit_hip_refine_bed call and is closed after they are detached or closed.
- */
-typedef struct RibbitAlignBatcher RibbitAlignBatcher;
-int ribbit_hip_batcher_open(const RibbitScanParams *params, int device, int32_t expected_clients, RibbitAlignBatcher **out);
-int ribbit_hip_batcher_close(RibbitAlignBatcher *b);
-int ribbit_hip_set_batcher(RibbitHandle *h, RibbitAlignBatcher *b);
-/* out = {batches run, submissions served, alignment jobs received, of them aligned on the GPU} since the batcher was opened */
-void ribbit_hip_batcher_stats(const RibbitAlignBatcher *b, int64_t out[4]);
 
 /* Host-only variant (no GPU; xa may be NULL: recomputed); *text is malloc'ed, release with ribbit_text_free(). */
 int ribbit_host_refine_bed(const RibbitScanParams *params, const RibbitRefineParams *prm, const char *sequence, int64_t length,

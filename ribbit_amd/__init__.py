@@ -52,7 +52,6 @@ ABI_SYMBOLS = [
     "ribbit_hip_scan_perfect_chunk", "ribbit_hip_host_register", "ribbit_hip_host_unregister",
     "ribbit_hip_set_host_threads", "ribbit_hip_ssw_passes", "ribbit_hip_ssw_align_jobs", "ribbit_hip_set_timing", "ribbit_hip_debug_set_event_capacity", "ribbit_hip_debug_pair_events", "ribbit_hip_scan_perfect_begin", "ribbit_hip_scan_perfect_end", "ribbit_hip_scan_perfect_wait", "ribbit_hip_scan_perfect_end_device",
     "ribbit_hip_stage_calls_chunk", "ribbit_hip_xa_words_strided", "ribbit_host_merge_chunks",
-    "ribbit_hip_batcher_open", "ribbit_hip_batcher_close", "ribbit_hip_set_batcher", "ribbit_hip_batcher_stats",
 ]
 
 
@@ -212,11 +211,6 @@ def load_library():
     L.ribbit_hip_xa_words_strided.argtypes = [vp, i64, i64, vp, i64]
     L.ribbit_host_merge_chunks.argtypes = [C.POINTER(ScanParams), i64, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(ChunkPart), C.c_size_t,
                                            C.POINTER(SeedLists)]
-    L.ribbit_hip_batcher_open.argtypes = [C.POINTER(ScanParams), C.c_int, i32, C.POINTER(vp)]
-    L.ribbit_hip_batcher_close.argtypes = [vp]
-    L.ribbit_hip_set_batcher.argtypes = [vp, vp]
-    L.ribbit_hip_batcher_stats.restype = None
-    L.ribbit_hip_batcher_stats.argtypes = [vp, C.POINTER(C.c_int64 * 4)]
     L.ribbit_hip_debug_stream_read.argtypes = [vp, i64, C.POINTER(i64)]
     L.ribbit_hip_last_event_count.restype = i64
     L.ribbit_hip_last_event_count.argtypes = [vp]

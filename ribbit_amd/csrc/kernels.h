@@ -30,18 +30,15 @@ void launch_scan_perfect(const DevicePlanes &pl, const PerfectLaunch &pp, uint64
 void launch_scan_window(const DevicePlanes &pl, const PerfectLaunch &pp, int allowed_mismatches, uint64_t *events,
                         uint32_t *counters, hipStream_t stream);
 
-// generateAnchoredShiftXORs (parse_anchored_shiftxor.cpp:20-56) + the composition of
-// fasta_utils.cpp:143-161 + the window scan of processShiftXORsAnchored (:580-679), fused.
-// xa (may be null) receives the composed planes XA_m, motif-major, xa_stride words per motif.
-// Tiles are anchored_tile_words(anchored_halo_lanes(pp.m_hi)) wide.  Requires pp.m_hi <= ANCHORED_MAX_MOTIF.
-// tj_table (may be null: no filter): per motif of the launch, the number of positions a group of pass-streaks must span for
-// its call to be able to pass the stage's length filter (<= GROUP_FILTER_MAX; 0: keep every group); groups that cannot,
-// and are not kept for another reason (see the kernel), emit no events and leave their end bit in dropmap (words
-// 0 .. L/32, zeroed by the caller) instead.
+// generateAnchoredShiftXORs (parse_anchored_shiftxor.cpp:20-56) + the composition of fasta_utils.cpp:143-161: xa receives the
+// composed planes XA_m, motif-major, xa_stride words per motif.  Tiles are anchored_tile_words(anchored_halo_lanes(pp.m_hi))
+// wide.  Requires pp.m_hi <= ANCHORED_MAX_MOTIF.  launch_scan_xa_window scans the planes.
+void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint32_t *xa, int64_t xa_stride, hipStream_t stream);
+// Group filter of the window scan below.  tj_table (may be null: no filter): per motif of the launch, the number of positions a
+// group of pass-streaks must span for its call to be able to pass the stage's length filter (<= GROUP_FILTER_MAX; 0: keep every
+// group); groups that cannot, and are not kept for another reason (see the kernel), emit no events and leave their end bit in
+// dropmap (words 0 .. L/32, zeroed by the caller) instead.
 constexpr int GROUP_FILTER_MAX = 16;
-// events == nullptr: the planes only (no window scan; tj_table / dropmap unused) -- launch_scan_xa_window does the rest.
-void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint32_t *xa, int64_t xa_stride,
-                          uint64_t *events, uint32_t *counters, const int32_t *tj_table, uint32_t *dropmap, hipStream_t stream);
 // The window scan of processShiftXORsAnchored on composed planes already in HBM (xa, xa_stride words per motif, readable up to
 // word ntiles * TILE_WORDS + 2 of every plane): same events and filter as the fused kernel, tiles of TILE_WORDS words.
 void launch_scan_xa_window(const DevicePlanes &pl, const PerfectLaunch &pp, const uint32_t *xa, int64_t xa_stride, uint64_t *events,

@@ -750,22 +750,16 @@ constexpr int RUN_SAT = 1 << 20;
 // it ends, so its end bit goes to `dropmap` (one OR per lane word and wave at the end of the motif loop).
 // Every decision is a function of absolute positions inside a lane's view (its own words, one word to the left, 24 bits of
 // the right neighbour's first word), so all lanes and tiles agree on every group.
-// EMIT = false: the planes only (anchor classification + composition, XA_m written to HBM); the window scan of those planes is
-// then scan_xa_window_kernel's.  Two kernels instead of one fused one: the fused kernel holds the shifted operands, the
-// five-shift anchor ring AND the window counters' words at once (256 VGPRs, two waves per SIMD, VALUBusy 58 %); apart, the
-// planes kernel and the window kernel each keep half of that and run at twice the occupancy, for one extra read of the
-// planes (max_motif / 8 bytes per base at HBM speed).
-template <bool EMIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, EMIT ? 2 : 4))) void scan_anchored_kernel(DevicePlanes pl, PerfectLaunch pp, int motifs_per_block, int hl,
-                                                            uint32_t *__restrict__ xa, int64_t xa_stride,
-                                                            uint64_t *__restrict__ events,
-                                                            uint32_t *__restrict__ counters,
-                                                            const int32_t *__restrict__ tj_table,
-                                                            uint32_t *__restrict__ dropmap) {
+// This kernel makes the planes only (anchor classification + composition, XA_m written to HBM); the window scan of those planes,
+// with the group filter described above, is scan_xa_window_kernel's.  Rounds 1-2 did both in one fused kernel, which held the
+// shifted operands, the five-shift anchor ring AND the window counters' words at once (256 VGPRs, two waves per SIMD, VALUBusy
+// 58 %, 3.3 ms per 100 Mbp); apart, the planes kernel and the window kernel each keep half of that and run at twice the
+// occupancy (0.68 + 1.60 ms) for one extra read of the planes (max_motif / 8 bytes per base at HBM speed).  The fused form was
+// kept behind a switch through round 3 and is gone since round 4 (DESIGN.md 4 has its measurements).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void scan_anchored_kernel(DevicePlanes pl, PerfectLaunch pp, int motifs_per_block, int hl,
+                                                            uint32_t *__restrict__ xa, int64_t xa_stride) {
     __shared__ uint32_t s_hi[64 * K + LDS_EXTRA];
     __shared__ uint32_t s_lo[64 * K + LDS_EXTRA];
-    __shared__ uint32_t s_brk[64 * K + 8];
-    __shared__ uint64_t s_stage[4][EV_STAGE];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform on purpose: keeps the motif loop scalar
@@ -780,7 +774,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, EMIT ? 2
         s_hi[i] = pl.hi[first + i];
         s_lo[i] = pl.lo[first + i];
     }
-    for (int i = threadIdx.x; i < 64 * K + 3; i += 256) s_brk[i] = pl.brk[first + i];
     __syncthreads();
 
     const int nmb = bm_hi - bm_lo + 1;
@@ -792,29 +785,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, EMIT ? 2
     const int lb = lane * K;
     const bool own_lane = lane >= hl && lane < 64 - hl;
     uint32_t H[K + 2], Lo[K + 2];
-    uint32_t EVAL[K + 2];   // words k = -1 .. K: window starting here holds no break
-    {
-        uint32_t B[K + 3];
 #pragma unroll
-        for (int j = 0; j < K + 2; j++) { H[j] = s_hi[lb + j]; Lo[j] = s_lo[lb + j]; }
-#pragma unroll
-        for (int j = 0; j < K + 3; j++) B[j] = s_brk[lb + j];
-#pragma unroll
-        for (int j = 0; j < K + 2; j++) B[j] |= funnel(B[j + 1], B[j], 1);
-        B[K + 2] |= B[K + 2] >> 1;
-#pragma unroll
-        for (int j = 0; j < K + 2; j++) B[j] |= funnel(B[j + 1], B[j], 2);
-        B[K + 2] |= B[K + 2] >> 2;
-#pragma unroll
-        for (int j = 0; j < K + 2; j++) EVAL[j] = ~(B[j] | funnel(B[j + 1], B[j], 4));
-    }
-    // END positions of the groups the filter dropped, OR-ed over this wave's motifs (own words only)
-    uint32_t DROP[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) DROP[k] = 0;
+    for (int j = 0; j < K + 2; j++) { H[j] = s_hi[lb + j]; Lo[j] = s_lo[lb + j]; }
 
     const int64_t w_own0 = tile_base + (int64_t)(lane - hl) * K;    // global index of this lane's word k = 0
-    const uint32_t word0 = (uint32_t)w_own0;
     const int64_t length = pl.length;
     // masks are only needed where the lane touches p < 0 or p >= L - (largest shift)
     const int64_t lane_lo = (w_own0 - 1) * 32, lane_hi = (w_own0 + K + 1) * 32;
@@ -834,14 +808,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, EMIT ? 2
     for (int a = 0; a < 5; a++)
 #pragma unroll
         for (int j = 0; j < K + 2; j++) AN[a][j] = 0;
-
-    EventSink sink;
-    sink.events = events;
-    sink.counters = counters;
-    sink.region_cap = pp.ev_cap / EV_SHARDS;
-    sink.shard = (blockIdx.x * 4u + (uint32_t)wave + blockIdx.y) % EV_SHARDS;
-    volatile uint64_t *stage = s_stage[wave];
-    int staged = 0;
 
     const int s_first = max(1, wm_lo - 2);
     const int s_last = wm_hi + 2;
@@ -938,21 +904,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, EMIT ? 2
             if (high_len >= 3 && high_len < two_s) keep |= mask_high;
             AN[R][k + 1] = keep;
         }
-        if constexpr (EMIT) {
-            AN[R][0] = __shfl_up(AN[R][K], 1);          // left neighbour's last own word
-            AN[R][K + 1] = __shfl_down(AN[R][1], 1);    // right neighbour's first own word
-        }
 
         const int m = s - 2;
         if (m < wm_lo) return;
         // ---- composed mismatch of motif m:  ~XA_m = mismatch_m & ~(anchor_{m-2,m-1,m+1,m+2})
-        uint32_t A1[K + 2], B1[K + 2], C1[K + 2];
+        uint32_t A1[K + 2];
         {
             // mismatch words of shift m (words k = -1 .. K): the shifted operands usually sit in the registers loaded for
             // shift s = m + 2; only when m and s straddle a multiple of 32 they are read from LDS
             const int qm = m >> 5;
             const uint32_t rm = (uint32_t)m & 31u;
-            constexpr int J0 = EMIT ? 0 : 1, J1 = EMIT ? K + 2 : K + 1;      // the planes alone need the own words only
+            constexpr int J0 = 1, J1 = K + 1;      // the planes need the own words only
             if (qm == cur_q) {
 #pragma unroll
                 for (int j = J0; j < J1; j++) {
@@ -982,60 +944,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, EMIT ? 2
                     if (w_own0 + k < xa_stride) dst[k] = ~A1[k + 1];
             }
         }
-        if constexpr (!EMIT) return;
-#pragma unroll
-        for (int j = 0; j < K + 2; j++) {          // span 2
-            const uint32_t sa = (j <= K) ? funnel(A1[j + 1 <= K + 1 ? j + 1 : j], A1[j], 1) : (A1[j] >> 1);
-            B1[j] = A1[j] & sa;
-            A1[j] = A1[j] | sa;
-        }
-#pragma unroll
-        for (int j = 0; j < K + 2; j++) {          // span 4
-            const uint32_t sa = (j <= K) ? funnel(A1[j + 1 <= K + 1 ? j + 1 : j], A1[j], 2) : (A1[j] >> 2);
-            const uint32_t sb = (j <= K) ? funnel(B1[j + 1 <= K + 1 ? j + 1 : j], B1[j], 2) : (B1[j] >> 2);
-            C1[j] = (B1[j] & sa) | (A1[j] & sb);
-            B1[j] = B1[j] | sb | (A1[j] & sa);
-            A1[j] = A1[j] | sa;
-        }
-        uint32_t PASS[K + 2];   // words k = -1 .. K (the last one is the right neighbour's first own word)
-#pragma unroll
-        for (int j = 0; j < K + 1; j++) {          // span 8: at least three mismatches fail the window
-            const uint32_t sa = funnel(A1[j + 1], A1[j], 4);
-            const uint32_t sb = funnel(B1[j + 1], B1[j], 4);
-            const uint32_t sc = funnel(C1[j + 1], C1[j], 4);
-            const uint32_t bad = C1[j] | sc | (B1[j] & sa) | (A1[j] & sb);
-            PASS[j] = EVAL[j] & ~bad;
-        }
-        // ---- group filter: SV bit q = the group that position q belongs to may pass the length filter, or is one of the
-        // groups that are kept regardless (words k = -1 .. K-1; only bit 31 of word -1 is used)
-        const int tj = tj_table ? tj_table[m - pp.m_lo] : 0;          // wave-uniform; 0: every group is kept
-        uint32_t SV[K + 1];
-        if (tj > 0) {
-            PASS[K + 1] = (uint32_t)__shfl_down((int)PASS[1], 1);     // exact in bits 0..23, which is as far as the filter looks
-            uint32_t DR[K];
-            group_filter(PASS, EVAL, tj, SV, DR);
-#pragma unroll
-            for (int k = 0; k < K; k++) DROP[k] |= own_lane ? DR[k] : 0u;
-        } else {
-#pragma unroll
-            for (int j = 0; j < K + 1; j++) SV[j] = 0xffffffffu;
-        }
-        uint32_t ST[K], EN[K];
-        uint32_t any = 0;
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            const uint32_t prev = funnel(PASS[k + 1], PASS[k], 31);
-            const uint32_t svprev = funnel(SV[k + 1], SV[k], 31);
-            ST[k] = own_lane ? (PASS[k + 1] & ~prev & SV[k + 1]) : 0u;
-            EN[k] = own_lane ? (~PASS[k + 1] & prev & svprev) : 0u;
-            any |= ST[k] | EN[k];
-        }
-        if (__ballot(any != 0) != 0ull) {
-            stage_events(ST, EN, word0, (uint32_t)m, sink, stage, staged, lane, [&](int k, uint32_t b, uint32_t pos) {
-                if ((EVAL[k + 1] >> b) & 1u) return (uint32_t)EV_END_ZERO;
-                return ((int64_t)pos + 7 >= length) ? (uint32_t)EV_END_EOS : (uint32_t)EV_END_N;
-            });
-        }
     };
     for (int s = s_first; s <= s_last; s += 5) {
         step(std::integral_constant<int, 0>{}, s);
@@ -1044,16 +952,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, EMIT ? 2
         if (s + 3 <= s_last) step(std::integral_constant<int, 3>{}, s + 3);
         if (s + 4 <= s_last) step(std::integral_constant<int, 4>{}, s + 4);
     }
-    sink_flush(sink, stage, staged, lane);
-    if (dropmap != nullptr && own_lane) {
-#pragma unroll
-        for (int k = 0; k < K; k++)
-            if (DROP[k] && w_own0 + k >= 0) atomicOr(&dropmap[w_own0 + k], DROP[k]);
-    }
 }
 
-void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint32_t *xa, int64_t xa_stride,
-                          uint64_t *events, uint32_t *counters, const int32_t *tj_table, uint32_t *dropmap, hipStream_t stream) {
+void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint32_t *xa, int64_t xa_stride, hipStream_t stream) {
     const int nm = pp.m_hi - pp.m_lo + 1;
     const int64_t nwords = pl.length / 32 + 1;
     const int hl = anchored_halo_lanes(pp.m_hi);
@@ -1066,12 +967,7 @@ void launch_scan_anchored(const DevicePlanes &pl, const PerfectLaunch &pp, uint3
     int motifs_per_block = (nm + gy - 1) / gy;
     gy = (nm + motifs_per_block - 1) / motifs_per_block;
     dim3 grid((unsigned)ntiles, (unsigned)gy);
-    if (events != nullptr)
-        hipLaunchKernelGGL(scan_anchored_kernel<true>, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, hl, xa, xa_stride, events,
-                           counters, tj_table, dropmap);
-    else
-        hipLaunchKernelGGL(scan_anchored_kernel<false>, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, hl, xa, xa_stride, events,
-                           counters, tj_table, dropmap);
+    hipLaunchKernelGGL(scan_anchored_kernel, grid, dim3(256), 0, stream, pl, pp, motifs_per_block, hl, xa, xa_stride);
 }
 
 // ------------------------------------------------------------- window scan of composed planes

@@ -365,29 +365,6 @@ int main(int argc, char **argv) {
         handles.push_back(extra);
         handle_dev.push_back(dev);
     }
-    // Short records side by side on one GPU can share alignment batches (the reference aligns seed by seed, parse_seed.cpp:404 /
-    // parse_smallmotif_seed.cpp:270; a read has too few alignments to pay for batches of its own): one batcher per GPU slot,
-    // fed by all of that slot's handles.  OFF unless asked for, by measurement:
-    //   RIBBIT_SHARED_SSW=1   the reads' short first-level alignments: 400 reads of 50 kb at -M 100 with 8 and 16 in flight
-    //                         (tools/cli_reads_sweep.sh) take 1.84-2.2 s against 1.34-1.41 s with every record aligning them on
-    //                         its own two host threads;
-    //   RIBBIT_DEFER_READS=1  the EXPENSIVE nodes of the reads' long-motif seeds (processSeed's recursion put off level by
-    //                         level, include/ribbit_hip.h: ribbit_debug_level_counters): 100 Mbp of reads at -M 500 take 53-104 s
-    //                         against 22.8 s on the host threads (tools/m500_probe.py; a batch lasts as long as its longest
-    //                         alignment and a read's tree needs 3-7 of them one after the other).
-    std::vector<RibbitAlignBatcher *> batchers((size_t)ndev, nullptr);
-    const char *shared_env = std::getenv("RIBBIT_SHARED_SSW");
-    const char *defer_env = std::getenv("RIBBIT_DEFER_READS");
-    if (jobs > 1 && !failed && ((shared_env && std::atoi(shared_env) != 0) || (defer_env && std::atoi(defer_env) != 0)))
-        for (int d = 0; d < ndev; ++d) {
-            if (ribbit_hip_batcher_open(&scan, devices[(size_t)d], jobs, &batchers[(size_t)d]) != RIBBIT_OK) {
-                std::cerr << "ribbit-hip: no shared alignment batches on GPU " << devices[(size_t)d] << " (" << ribbit_hip_last_error() << ")\n";
-                batchers[(size_t)d] = nullptr;
-                continue;
-            }
-            for (size_t j = 0; j < handles.size(); ++j)
-                if (handle_dev[j] == d) ribbit_hip_set_batcher(handles[j], batchers[(size_t)d]);
-        }
     std::vector<std::thread> pool;
     for (size_t j = 0; j < handles.size(); ++j) pool.emplace_back(worker, handles[j], handle_dev[j], j < (size_t)ndev);      // handles 0 .. ndev-1: one per GPU
 
@@ -431,17 +408,6 @@ int main(int argc, char **argv) {
         } catch (const PathError &e) { failed = true; failure = e.what; }
     }
     if (failed) { std::cerr << "ribbit-hip: " << failure << "\n"; status = 1; }
-    for (size_t j = 0; j < handles.size(); ++j) ribbit_hip_set_batcher(handles[j], nullptr);
-    for (int d = 0; d < ndev; ++d) {
-        if (!batchers[(size_t)d]) continue;
-        if (std::getenv("RIBBIT_PROFILE")) {
-            int64_t st[4] = {0, 0, 0, 0};
-            ribbit_hip_batcher_stats(batchers[(size_t)d], st);
-            std::cerr << "[shared alignment batches] slot " << d << ": " << st[0] << " batches for " << st[1] << " records, " << st[2] << " alignment jobs, "
-                      << st[3] << " of them on the GPU\n";
-        }
-        ribbit_hip_batcher_close(batchers[(size_t)d]);
-    }
     for (size_t j = 1; j < handles.size(); ++j) ribbit_hip_close(handles[j]);
     ribbit_hip_close(h);
     if (reader) ribbit_fasta_close(reader);

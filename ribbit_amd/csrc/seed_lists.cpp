@@ -88,7 +88,8 @@ inline void retire(RibbitSeed &s) { s.type = RIBBIT_RANK_N; }
 
 // a seed of a list that parallel workers share: retirement and the "is it retired" test (see ListRefs)
 inline void retire_shared(ListRefs &sl, RibbitSeed &s) {
-    if (sl.undo && s.type != RIBBIT_RANK_N) sl.undo->push_back({&s, s.type});
+    const int32_t was = __atomic_load_n(&s.type, __ATOMIC_RELAXED);
+    if (sl.undo && was != RIBBIT_RANK_N) sl.undo->push_back({&s, was});
     __atomic_store_n(&s.type, (int32_t)RIBBIT_RANK_N, __ATOMIC_RELAXED);
 }
 inline bool live_shared(const ListRefs &sl, const RibbitSeed &s) {
@@ -163,7 +164,9 @@ int subst_add(ListRefs &sl, int seed_start, int seed_end, int mlen, int from_ind
 
         for (const Cand &c : cands) {
             RibbitSeed &old = c.from_perfect ? P[c.idx] : S[c.idx];
-            const int o_start = old.start, o_end = old.end, o_mlen = old.mlen, o_type = old.type;
+            // (the type through an atomic load: another range may be retiring this seed right now -- what this range then
+            // did with a stale value is found by the validation pass, parallel_merge.cpp -- ThreadSanitizer, round 4)
+            const int o_start = old.start, o_end = old.end, o_mlen = old.mlen, o_type = __atomic_load_n(&old.type, __ATOMIC_RELAXED);
             const int o_rend = o_end + o_mlen, o_len = o_end - o_start, o_rlen = o_rend - o_start;
 
             if (o_end < seed_start) break;                     // :150
@@ -379,7 +382,7 @@ Cursor2 anchored_add(ListRefs &sl, int seed_start, int seed_end, int mlen, const
 
         for (const Cand3 &c : cands) {
             const RibbitSeed &old = seed_of(sl, c.src, c.idx);
-            o_start = old.start; o_mlen = old.mlen; o_end = old.end; o_rend = o_end + o_mlen; o_type = old.type;
+            o_start = old.start; o_mlen = old.mlen; o_end = old.end; o_rend = o_end + o_mlen; o_type = __atomic_load_n(&old.type, __ATOMIC_RELAXED);
 
             if (o_end < seed_start) break;                                                   // :203
             if (o_type == RIBBIT_RANK_N) continue;                                           // :205

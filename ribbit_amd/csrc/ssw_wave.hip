@@ -4,8 +4,8 @@
 // tests/test_ssw_gpu.py.
 //
 // (Queries of 129..4096 bases, in three classes by LDS need.  Since the end of round 3 the product uses this kernel for the
-// first class only, 129..512 bases; longer queries run a workgroup per alignment, ssw_group.hip, and RIBBIT_SSW_GROUP=0 brings
-// the two long classes back here for comparison.)
+// first class only, 129..512 bases; longer queries run a workgroup per alignment, ssw_group.hip -- and this kernel only if the
+// device will not give a workgroup the LDS it asks for.)
 // ssw_kernels.hip gives an alignment one DPP row of 16 lanes (= one SSE2 register) and walks the stripes j = 0..segLen-1
 // one after the other: right for queries of a few dozen bases, but a 1000-base query has 125 stripes per column and
 // every step waits for LDS.  Here the 64 lanes are W register lanes x G = 64/W consecutive stripes (lane = l*G + jj), and

@@ -53,7 +53,7 @@ def test_cli_records_dealt_over_several_devices(tmp_path):
     records.insert(3, ("long one", sims[1][1][:150_000]))
     fa, bed, bed2 = tmp_path / "in.fa", tmp_path / "out.bed", tmp_path / "out2.bed"
     write_fasta(str(fa), records)
-    env = dict(os.environ, RIBBIT_PROFILE="1", RIBBIT_SHARED_SSW="1")
+    env = dict(os.environ, RIBBIT_PROFILE="1")
     r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "30", "--devices", "0,0", "--jobs", "2"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -61,13 +61,10 @@ def test_cli_records_dealt_over_several_devices(tmp_path):
     assert bed.read_text() == want
     dealt = [l for l in r.stderr.split("\n") if l.startswith("[devices] slot")]
     assert len(dealt) == 2 and all(" 0 records" not in l for l in dealt), r.stderr[-1500:]
-    # RIBBIT_SHARED_SSW=1: the short records of a slot share their alignment batches (one batcher per GPU slot)
-    shared = [l for l in r.stderr.split("\n") if l.startswith("[shared alignment batches]")]
-    assert len(shared) == 2 and sum(int(l.split(" alignment jobs, ")[1].split(" ")[0]) for l in shared) > 100, r.stderr[-1500:]
-    # ... and without them (the default: every record aligns on its own host threads) the BED is the same
+    # ... and on one slot with three records in flight the BED is the same
     r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed2), "-m", "2", "-M", "30", "--jobs", "3"], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, RIBBIT_PROFILE="1"))
-    assert r.returncode == 0 and bed2.read_text() == want and "[shared alignment batches]" not in r.stderr
+    assert r.returncode == 0 and bed2.read_text() == want
     # the same list through the environment; an unusable list is refused
     r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed2), "-m", "2", "-M", "30"], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, RIBBIT_DEVICES="0,0,0"))
@@ -96,12 +93,11 @@ def test_cli_with_every_alignment_forced_onto_the_gpu(tmp_path, label, m_lo, m_h
     assert "alignment jobs (" in r.stderr, "no record took the GPU alignment path"
 
 
-def test_the_comparison_switches_of_the_alignment_pipeline_give_the_same_bed(tmp_path):
-    """The pipeline keeps two switches for measuring it against its older forms: RIBBIT_SSW_FEEDERS=1 (one feeder thread instead
-    of two on alternating slices) and RIBBIT_SSW_GROUP=0 (the long classes on one wavefront per alignment instead of a workgroup;
-    queries beyond 4096 bases then stay on the host).  They are read once per process, so this goes through the command line: one
-    record with long repeats (alignments of every size class, several slices), alignments forced onto the GPU, BED identical under
-    every setting and equal to the oracle's."""
+def test_the_alignment_pipeline_on_every_size_class_and_any_number_of_slices(tmp_path):
+    """One record with long repeats -- alignments of every size class incl. the three workgroup classes -- with the alignments
+    forced onto the GPU pipeline, through the command line, cut into 2, 5 and 9 slices of the seed list (two feeders on
+    alternating slices): the BED is the oracle's every time.  (Until round 4 this test also ran the pipeline's older forms
+    behind RIBBIT_SSW_FEEDERS / RIBBIT_SSW_GROUP; they lost their measurements in round 3 and are gone from the product.)"""
     import numpy as np
     from ribbit_amd.simulate import simulate_sequence
     seq, _ = simulate_sequence(1_500_000, 23, 2, 60)
@@ -117,14 +113,13 @@ def test_the_comparison_switches_of_the_alignment_pipeline_give_the_same_bed(tmp
     fa = tmp_path / "in.fa"
     write_fasta(str(fa), records)
     beds = {}
-    for label, env in (("default", {}), ("one_feeder", {"RIBBIT_SSW_FEEDERS": "1"}), ("wavefront_kernels", {"RIBBIT_SSW_GROUP": "0"}),
-                       ("both", {"RIBBIT_SSW_FEEDERS": "1", "RIBBIT_SSW_GROUP": "0"})):
-        bed = tmp_path / f"{label}.bed"
+    for slices in ("2", "5", "9"):
+        bed = tmp_path / f"slices{slices}.bed"
         r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "60"], capture_output=True, text=True, timeout=900,
-                           env=dict(os.environ, RIBBIT_GPU_SSW="1", RIBBIT_SSW_SLICES="5", RIBBIT_PROFILE="1", **env))
+                           env=dict(os.environ, RIBBIT_GPU_SSW="1", RIBBIT_SSW_SLICES=slices, RIBBIT_PROFILE="1"))
         assert r.returncode == 0, r.stderr[-2000:]
-        assert "alignment jobs (" in r.stderr and "5 slices" in r.stderr, r.stderr[-1500:]
-        beds[label] = bed.read_text()
+        assert "alignment jobs (" in r.stderr and f"{slices} slices" in r.stderr, r.stderr[-1500:]
+        beds["default" if slices == "5" else slices] = bed.read_text()
     assert beds["default"] == _oracle_bed(records, 2, 60)
     assert all(b == beds["default"] for b in beds.values()), [k for k, b in beds.items() if b != beds["default"]]
 

@@ -1,5 +1,5 @@
 """processSeed's recursion on the flanks (parse_seed.cpp:443-463), level by level on the GPU (refine.h: DeferredNode;
-api.cpp: refine_levels): nodes of long-motif seeds' recursion trees from RIBBIT_DEFER_MIN bases on are not refined where
+api_refine_bed.cpp: refine_levels): nodes of long-motif seeds' recursion trees from RIBBIT_DEFER_MIN bases on are not refined where
 they are met but put off, batched -- consensus rows, striped passes, path search -- and their rows sorted into place.
 The BED text must stay the oracle pipeline's byte for byte whatever the threshold, in both forms of refinement (a short
 record's host threads, a long record's GPU alignment pipeline), and the counters must show that nodes WERE put off over
@@ -16,7 +16,6 @@ pytestmark = pytest.mark.gpu
 
 
 def _bed_both(seq, m_lo, m_hi, env):
-    env = dict(env, RIBBIT_DEFER_READS="1")      # (a short record's host-thread form puts nodes off only on request)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -86,11 +85,11 @@ def test_fuzzed_records_with_every_node_put_off(block):
             assert got == want, (seed, gpu_ssw, len(seq), m_lo, m_hi)
 
 
-def test_reads_in_flight_share_their_level_batches(tmp_path):
-    """ribbit-hip on many short records at -M 500: the nodes each read puts off go into the GPU's shared batches (one batcher
-    per GPU slot), level by level, together with the other reads' -- same BED as the oracle's, and the batcher's statistics
-    show that batches held several records' alignments."""
-    import re
+
+def test_reads_in_flight_put_nodes_off_and_finish_them_on_their_own_threads(tmp_path):
+    """ribbit-hip on many short records at -M 500: a read puts its expensive nodes off like any record, finds them too few
+    for a GPU batch (5-30 a level) and finishes them on its host threads right after -- same BED as the oracle's, with the
+    threshold low (most long-motif nodes take the detour) and at its default."""
     import subprocess
     from ribbit_amd.simulate import write_fasta
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -104,14 +103,13 @@ def test_reads_in_flight_share_their_level_batches(tmp_path):
             o.run_all()
             want.append(o.refine_bed(name))
     want = "".join(want)
-    for defer_min, deferred in (("200", "1"), ("700", "1"), ("200", "0")):
-        env = dict(os.environ, RIBBIT_PROFILE="1", RIBBIT_DEFER_MIN=defer_min, RIBBIT_DEFER_READS=deferred)
+    for defer_min, level_min in (("200", ""), ("", ""), ("200", "4"), ("0", "")):
+        env = dict(os.environ, RIBBIT_PROFILE="1")
+        if defer_min:
+            env["RIBBIT_DEFER_MIN"] = defer_min
+        if level_min:
+            env["RIBBIT_LEVEL_MIN"] = level_min          # (levels of four nodes and more get GPU batches of their own)
         r = subprocess.run([os.path.join(root, "ribbit_amd", "ribbit-hip"), "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "500", "--jobs", "6"],
                            capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
-        assert bed.read_text() == want, (defer_min, deferred)
-        m = re.search(r"\[shared alignment batches\] slot 0: (\d+) batches for (\d+) records, (\d+) alignment jobs", r.stderr)
-        if deferred == "0":
-            assert m is None          # the default: no batcher, every node on the read's own host threads
-        else:
-            assert m and int(m.group(3)) > 0 and int(m.group(2)) > int(m.group(1)), r.stderr[-1500:]      # batches held more than one record's nodes
+        assert bed.read_text() == want, (defer_min, level_min)

@@ -118,7 +118,6 @@ def test_bed_is_identical_with_the_striped_passes_on_the_gpu(tmp_path):
         if flag:
             env["RIBBIT_GPU_SSW"] = flag
         env["RIBBIT_PROFILE"] = "1"
-        env["RIBBIT_SHARED_SSW"] = "0"            # this test is about a record's OWN batches (short records in flight share theirs otherwise)
         bed = tmp_path / f"out_{flag}.bed"
         r = subprocess.run([os.path.join(root, "ribbit_amd", "ribbit-hip"), "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "100"],
                            capture_output=True, text=True, timeout=900, env=env)
