@@ -378,6 +378,7 @@ def sharded_full_path(ribbit_amd, dist, torch, sc, seq: bytes, bases: int, rank:
 
 
 def main():
+    global M_HI
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -407,7 +408,6 @@ def main():
                     help="after the timed region, run the substitution and anchored scan kernels once on the workload record "
                          "(so that a profiler pass over this command sees all three scan kernels at the same size)")
     args = ap.parse_args()
-    global M_HI
     if args.max_motif != M_HI:
         M_HI = args.max_motif
         args.chr1_bases = 0          # the chromosome leg and its digest are for -M 100

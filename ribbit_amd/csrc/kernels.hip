@@ -201,6 +201,96 @@ __device__ __forceinline__ void stage_events(const uint32_t (&S)[WORDS_PER_LANE]
 
 constexpr int K = WORDS_PER_LANE;
 
+// The same compaction when events are SPARSE (the perfect scan: where a (tile, motif) pair or a flush of the candidate queue
+// has events at all, a dozen lanes hold one or two each).  stage_events walks the set bits of a lane's words IN that lane --
+// eight serialised loops with two or three lanes alive in each: a quarter of the perfect kernel's instructions and 29 % of its
+// time (rounds 2-3).  Here the lanes that hold events park their words in LDS, COOP_SRC lanes a round, and all 64
+// lanes expand them: lane (r, j) takes words 2j and 2j + 1 of parked lane r, so the two short loops below run with most lanes
+// that have anything to do doing it at once.  Where an event goes is settled before any is written -- one scan over the
+// lanes' event counts, as in stage_events -- so a pair's events stay in one piece whatever the number of rounds.
+// word0 / mlen / brk_at may differ from lane to lane (candidates of several motifs, see scan_perfect_kernel): first own word,
+// motif, and the LDS index in s_brk of the lane's word k = 0 (what closed a run: an N, the end of the record, a mismatch).
+// above RB_COOP_MAX_LANES lanes with events the lanes expand their own words (stage_events): nothing is gained by parking most
+// of a wave; at or below COOP_SRC one round does it and the parked words need not stay in registers
+#ifndef RB_COOP_MAX_LANES
+#define RB_COOP_MAX_LANES 16
+#endif
+constexpr int COOP_SRC = 16;
+struct CoopScratch { uint32_t w[COOP_SRC][20]; };      // per parked lane: S[0..7], E[0..7], word0, mlen, brk_at, first event's place
+
+__device__ __forceinline__ void stage_events_coop(const uint32_t (&S)[WORDS_PER_LANE], const uint32_t (&E)[WORDS_PER_LANE], uint32_t word0, uint32_t mlen,
+                                                  uint32_t brk_at, const uint32_t *s_brk, uint32_t length, CoopScratch &sc, const EventSink &sink,
+                                                  volatile uint64_t *stage, int &staged, int lane) {
+    uint32_t Sv[WORDS_PER_LANE], Ev[WORDS_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < WORDS_PER_LANE; k++) {
+        Sv[k] = S[k]; Ev[k] = E[k];
+        asm volatile("" : "+v"(Sv[k]), "+v"(Ev[k]));      // (keeps this block out of the caller's hot loop, as in stage_events)
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < WORDS_PER_LANE; k++) cnt += __popc(Sv[k] | Ev[k]);      // a position is a START or an END, never both
+    const int incl = wave_inclusive_scan(cnt);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (staged + total > EV_STAGE) sink_flush(sink, stage, staged, lane);
+    const bool direct = total > EV_STAGE;
+    uint32_t first = (uint32_t)(incl - cnt);
+    uint64_t *gdst = nullptr;
+    if (direct) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&sink.counters[sink.shard * EV_COUNTER_STRIDE], (uint32_t)total);
+        first += (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        gdst = sink.events + (size_t)sink.shard * sink.region_cap;
+    } else {
+        first += (uint32_t)staged;
+    }
+    unsigned long long todo = __ballot(cnt != 0);
+    const int r = lane >> 2, j = lane & 3;
+    do {                                                    // rounds of COOP_SRC parked lanes (wave-uniform; one round if the caller's limit is COOP_SRC)
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
+        const bool mine = ((todo >> lane) & 1ull) != 0ull && rank < COOP_SRC;
+        if (mine) {
+            uint32_t *row = sc.w[rank];
+#pragma unroll
+            for (int k = 0; k < WORDS_PER_LANE; k++) { row[k] = Sv[k]; row[WORDS_PER_LANE + k] = Ev[k]; }
+            row[16] = word0; row[17] = mlen; row[18] = brk_at; row[19] = first;
+        }
+        const unsigned long long handled = __ballot(mine);
+        const int nsrc = __popcll(handled);
+        todo &= ~handled;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t s0 = 0, s1 = 0, e0 = 0, e1 = 0;
+        if (r < nsrc) { s0 = sc.w[r][2 * j]; s1 = sc.w[r][2 * j + 1]; e0 = sc.w[r][WORDS_PER_LANE + 2 * j]; e1 = sc.w[r][WORDS_PER_LANE + 2 * j + 1]; }
+        const int c = __popc(s0 | e0) + __popc(s1 | e1);
+        // events of the parked lane's earlier words: the counts of the quad's lower lanes
+        const int q0 = __builtin_amdgcn_update_dpp(0, c, 0x00, 0xf, 0xf, true);      // quad_perm:[0,0,0,0]
+        const int q1 = __builtin_amdgcn_update_dpp(0, c, 0x55, 0xf, 0xf, true);      // quad_perm:[1,1,1,1]
+        const int q2 = __builtin_amdgcn_update_dpp(0, c, 0xaa, 0xf, 0xf, true);      // quad_perm:[2,2,2,2]
+        if (c != 0) {
+            const uint32_t w0 = sc.w[r][16], ml = sc.w[r][17], bb = sc.w[r][18];
+            uint32_t idx = sc.w[r][19] + (uint32_t)((j > 0 ? q0 : 0) + (j > 1 ? q1 : 0) + (j > 2 ? q2 : 0));
+            auto expand = [&](uint32_t sw, uint32_t ew, uint32_t k) {
+                uint32_t both = sw | ew;
+                while (both) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(both);
+                    both &= both - 1u;
+                    const uint32_t pos = ((w0 + k) << 5) + b;
+                    uint32_t kind = (uint32_t)EV_START;
+                    if (!((sw >> b) & 1u))
+                        kind = pos >= length ? (uint32_t)EV_END_EOS : (((s_brk[bb + k] >> b) & 1u) ? (uint32_t)EV_END_N : (uint32_t)EV_END_ZERO);
+                    const uint64_t e = ev_pack(pos, ml, kind);
+                    if (direct) { if (idx < sink.region_cap) gdst[idx] = e; }
+                    else stage[idx] = e;
+                    idx++;
+                }
+            };
+            expand(s0, e0, 2u * (uint32_t)j);
+            expand(s1, e1, 2u * (uint32_t)j + 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+    } while (RB_COOP_MAX_LANES > COOP_SRC && todo != 0ull);
+    if (!direct) staged += total;
+}
 // ------------------------------------------------------------------------- group filter
 // See scan_anchored_kernel.  PASS / EVAL: words k = -1 .. K of the pass bits and of the evaluated-window mask (word K of PASS
 // need only be exact in bits 0..23).  tj (1 < tj <= GROUP_FILTER_MAX, wave-uniform): positions a group must span.
@@ -376,6 +466,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_PERFECT_
     __shared__ uint32_t s_brk[TILE_WORDS + 8];
     __shared__ uint64_t s_stage[4][EV_STAGE];
     __shared__ CandQueue s_cand[4];
+    __shared__ CoopScratch s_coop[4];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform on purpose: keeps the motif loop scalar
@@ -448,15 +539,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_PERFECT_
             for (int k = 0; k < K; k++) { SQ[k] = 0; EQ[k] = 0; }
         }
 #ifdef RB_ABLATE_STAGING        // tools/build_variant.sh: timing without the event staging
-        if (__ballot(any == 0xdeadbeefu) != 0ull) {
+        const unsigned long long with_events = __ballot(any == 0xdeadbeefu);
 #else
-        if (__ballot(any != 0) != 0ull) {
+        const unsigned long long with_events = __ballot(any != 0);
 #endif
+        if (with_events != 0ull) {
             const uint32_t src_word0 = (uint32_t)tile_base + src * (uint32_t)K;
-            stage_events(SQ, EQ, src_word0, qm, sink, stage, staged, lane, [&](int k, uint32_t b, uint32_t pos) {
-                if (pos >= length) return (uint32_t)EV_END_EOS;
-                return ((s_brk[src * (uint32_t)K + (uint32_t)k + 1u] >> b) & 1u) ? (uint32_t)EV_END_N : (uint32_t)EV_END_ZERO;
-            });
+            if (__popcll(with_events) <= RB_COOP_MAX_LANES)
+                stage_events_coop(SQ, EQ, src_word0, qm, src * (uint32_t)K + 1u, s_brk, length, s_coop[wave], sink, stage, staged, lane);
+            else
+                stage_events(SQ, EQ, src_word0, qm, sink, stage, staged, lane, [&](int k, uint32_t b, uint32_t pos) {
+                    if (pos >= length) return (uint32_t)EV_END_EOS;
+                    return ((s_brk[src * (uint32_t)K + (uint32_t)k + 1u] >> b) & 1u) ? (uint32_t)EV_END_N : (uint32_t)EV_END_ZERO;
+                });
         }
         queued = 0;
         __builtin_amdgcn_wave_barrier();
@@ -535,14 +630,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_PERFECT_
         uint32_t SQ[K], EQ[K];
         const uint32_t any = perfect_edges<true>(Z, t3, t4, t5, 32u - (uint32_t)sp, SQ, EQ);
 #ifdef RB_ABLATE_STAGING
-        if (__ballot(any == 0xdeadbeefu) != 0ull) {
+        const unsigned long long with_events = __ballot(any == 0xdeadbeefu);
 #else
-        if (__ballot(any != 0) != 0ull) {
+        const unsigned long long with_events = __ballot(any != 0);
 #endif
-            stage_events(SQ, EQ, word0, (uint32_t)m, sink, stage, staged, lane, [&](int k, uint32_t b, uint32_t pos) {
-                if (pos >= length) return (uint32_t)EV_END_EOS;
-                return ((Bk[k + 1] >> b) & 1u) ? (uint32_t)EV_END_N : (uint32_t)EV_END_ZERO;
-            });
+        if (with_events != 0ull) {
+            if (__popcll(with_events) <= RB_COOP_MAX_LANES)
+                stage_events_coop(SQ, EQ, word0, (uint32_t)m, (uint32_t)lb + 1u, s_brk, length, s_coop[wave], sink, stage, staged, lane);
+            else
+                stage_events(SQ, EQ, word0, (uint32_t)m, sink, stage, staged, lane, [&](int k, uint32_t b, uint32_t pos) {
+                    if (pos >= length) return (uint32_t)EV_END_EOS;
+                    return ((Bk[k + 1] >> b) & 1u) ? (uint32_t)EV_END_N : (uint32_t)EV_END_ZERO;
+                });
         }
     }
     flush_candidates();
