@@ -108,6 +108,34 @@ _lib = None
 loaded_before_torch = False      # libribbit_hip.so entered the process before torch did: torch.cuda will not work in it
 
 
+def _share_torchs_hip_runtime() -> bool:
+    """One HIP runtime per process, whichever of torch and this library comes first (round 4; until then the multi-GPU bench
+    leg depended on `import torch` coming first).  The torch wheel bundles its own runtime (torch/lib/libamdhip64.so, SONAME
+    libamdhip64.so.7) and asks for it by FILE name; libribbit_hip.so needs "libamdhip64.so.7" and would otherwise pull in
+    /opt/rocm's copy -- two runtimes, and the second one (torch's) finds the device taken.  If a torch is installed and not yet
+    imported, its bundled runtime is loaded HERE first (by path, globally): the library's NEEDED entry is then satisfied by it
+    (same SONAME), and a later `import torch` finds the very file it asks for already in the process.  Without torch installed
+    nothing happens and the library runs on /opt/rocm's runtime, as the command-line front end does.  torch itself is not
+    imported.  -> True if torch's runtime is now the process's (or already was)."""
+    if "torch" in sys.modules:
+        return True
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return False
+    if spec is None or not spec.submodule_search_locations:
+        return False
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return False
+    try:
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return False
+    return True
+
+
 def load_library():
     """Load libribbit_hip.so; raises (never falls back) if it has not been built."""
     global _lib
@@ -118,7 +146,7 @@ def load_library():
         raise RibbitHipError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(make -C ribbit_amd/csrc). ribbit_amd has no CPU fallback.")
     global loaded_before_torch
-    loaded_before_torch = "torch" not in sys.modules      # see ribbit_amd.distributed.device_bytes
+    loaded_before_torch = "torch" not in sys.modules and not _share_torchs_hip_runtime()      # see ribbit_amd.distributed.device_bytes
     L = C.CDLL(path)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.ribbit_scan_params_default.restype = None

@@ -10,6 +10,8 @@ import pytest
 # process whose first one holds the device: torch then reports "No HIP GPUs are available" (readelf -d on the three files;
 # tools/torch_order_probe.py shows both orders).  It made test_sharded_gpu.py fail as a file while each of its tests passed
 # alone.  bench.py imports torch at its top for the same reason; with torch first the library runs on torch's bundled runtime.
+# Since round 4 the order no longer matters -- ribbit_amd.load_library() loads torch's bundled runtime itself when a torch is
+# installed (tests/test_torch_order_gpu.py) -- and the import below only saves the suite a second of start-up later.
 try:
     import torch  # noqa: F401
 except ImportError:            # the CPU-only parts of the suite do not need it

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Two HIP runtimes in one process: torch imported before / after libribbit_hip.so is loaded (tests/conftest.py has the
-mechanism).  Runs both orders in child processes on the GPU box and prints what torch sees.  Expected: first order fine,
-second order "No HIP GPUs are available" with the explanatory error of ribbit_amd.distributed.device_bytes."""
+"""torch imported before / after libribbit_hip.so is loaded: both orders in child processes on the GPU box, and what torch
+sees in each.  Until round 4 the second order put two HIP runtimes into the process (tests/conftest.py has the mechanism)
+and torch reported "No HIP GPUs are available"; ribbit_amd.load_library() now loads torch's bundled runtime first when a
+torch is installed, so both orders must print "torch sees the GPU" (tests/test_torch_order_gpu.py runs this)."""
 import os
 import subprocess
 import sys
