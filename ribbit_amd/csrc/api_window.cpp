@@ -34,15 +34,20 @@ int scan_and_pair_streaks(RibbitHandle *h, int which, uint32_t *n_streaks, int (
     if ((rc = h->d_run_base.ensure(entries))) return rc;
     if ((rc = h->d_pair_partial.ensure(entries / 1024 + 2))) return rc;
     if ((rc = h->d_halves.ensure(2 * (size_t)pr.nm))) return rc;
-    // typical event densities on repeat-rich sequence: 0.25 per base (1-mismatch windows), 3.7 (anchored windows at 99
-    // motif sizes); a too small first guess costs a second launch
-    const size_t per_base_x4 = which == 1 ? 2 : (size_t)std::max(16, (h->params.max_motif - h->params.min_motif + 1) / 6);
+    const bool filter = which == 2 && filter_min_span != nullptr && std::getenv("RIBBIT_NO_GROUP_FILTER") == nullptr;
+    // typical event densities on repeat-rich sequence: 0.25 per base (1-mismatch windows); anchored windows 3.7 at 99 motif
+    // sizes without the group filter (growing with the motif sizes), and 1.3 (99 sizes) .. 1.6 (499) with it: the filter drops
+    // nearly everything the large motifs add.  A too small first guess costs a second launch of the window scan; a too large
+    // one costs memory -- until round 4 the filtered scan was sized like the unfiltered one, which at -M 500 meant 2 x 34 GB for
+    // 3.3 GB of events, and on a box whose memory had just been used two seconds of the driver clearing it.
+    // (1-mismatch windows at 499 motif sizes: 0.49 per base, and the profile of round 4 showed the scan launched twice)
+    const size_t nm_all = (size_t)(h->params.max_motif - h->params.min_motif + 1);
+    const size_t per_base_x4 = which == 1 ? std::max<size_t>(2, nm_all / 100) : filter ? 10 : std::max<size_t>(16, nm_all / 6);
     size_t cap = std::max<size_t>((size_t)1 << 20, (size_t)h->length * per_base_x4 / 4);
     cap = std::max(cap, h->d_events.cap);
     if (h->debug_first_cap) cap = h->debug_first_cap;
     const rb::DevicePlanes pl = h->planes();
     uint64_t produced = 0;
-    const bool filter = which == 2 && filter_min_span != nullptr && std::getenv("RIBBIT_NO_GROUP_FILTER") == nullptr;
     bool first_attempt_fit = false;
     const size_t drop_words = (size_t)(h->length / 32 + 1) + 1024;
     h->dropmap_valid = false;

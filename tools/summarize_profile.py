@@ -59,7 +59,7 @@ for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "VALUBus
 # the window-stage scan kernels (launched once per pass by --stage-kernels, on the same 100-Mbp record): per base, so
 # that bench.py can scale them to the chromosome-sized record of its configs[2] leg
 bases = bench["config"]["bases_per_gpu"]
-# (the anchored stage runs as two kernels since round 3: the planes kernel scan_anchored_kernel<false> and the window scan of the
+# (the anchored stage runs as two kernels since round 3: the planes kernel scan_anchored_kernel and the window scan of the
 # planes scan_xa_window_kernel; "scan_anchored_kernel" below is whichever instantiation ran)
 for key, needle in (("scan_window_kernel", "scan_window_kernel<1>"), ("scan_anchored_kernel", "scan_anchored_kernel"), ("scan_xa_window_kernel", "scan_xa_window_kernel")):
     k = [name for name in pmc if needle in name]
@@ -79,7 +79,7 @@ if "scan_xa_window_kernel_hbm_bytes_per_base" in out and "scan_anchored_kernel_h
     for q in ("hbm_read_bytes_per_base", "hbm_write_bytes_per_base", "hbm_bytes_per_base", "SQ_INSTS_VALU_per_base", "SQ_INSTS_SALU_per_base"):
         if ("scan_anchored_kernel_" + q) in out and ("scan_xa_window_kernel_" + q) in out:
             out["anchored_stage_scan_" + q] = out["scan_anchored_kernel_" + q] + out["scan_xa_window_kernel_" + q]
-    out["anchored_stage_scan_kernels"] = ["scan_anchored_kernel<false> (planes)", "scan_xa_window_kernel"]
+    out["anchored_stage_scan_kernels"] = ["scan_anchored_kernel (planes)", "scan_xa_window_kernel"]
 with open(os.path.join(dst, "traffic.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out, indent=1))
