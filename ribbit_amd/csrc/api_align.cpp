@@ -331,20 +331,16 @@ int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const s
     std::vector<uint64_t> cell_off, ops_off;
     std::vector<Open> next;
     constexpr uint64_t ARENA = (uint64_t)6 << 30;            // cell bytes per launch
-    // A round's items in four groups by band (kernels.h: launch_ssw_paths), each in seed order: narrow ones four to a wavefront
-    // (nineteen in twenty), one wavefront each, a workgroup of 4 or of 16 wavefronts each (the wide twentieth, round 4).
-    auto group_of = [](int band) {
-        return band <= rb::SSW_PATH_NARROW_BAND ? 0 : band <= rb::SSW_PATH_WAVE_BAND ? 1 : band <= rb::SSW_PATH_GROUP4_BAND ? 2 : band <= rb::SSW_PATH_GROUP16_BAND ? 3 : 1;
-    };
+    // Alignments with a narrow band (nineteen in twenty) run four to a wavefront (ssw_path4_kernel): they come first among a
+    // round's items, in seed order, the others behind them, in seed order too.
     while (!open.empty()) {
         // one launch per arena-full of items
-        size_t group_end[4] = {0, 0, 0, 0};          // where each group ends in the ordered list
+        size_t n_narrow_all = 0;
         {
             next.clear();
-            for (int g = 0; g < 4; ++g) {
-                for (const Open &o : open) if (group_of(o.band) == g) next.push_back(o);
-                group_end[g] = next.size();
-            }
+            for (const Open &o : open) if (o.band <= rb::SSW_PATH_NARROW_BAND) next.push_back(o);
+            n_narrow_all = next.size();
+            for (const Open &o : open) if (o.band > rb::SSW_PATH_NARROW_BAND) next.push_back(o);
             open.swap(next);
         }
         size_t at = 0;
@@ -362,12 +358,10 @@ int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const s
                 items.push_back(open[at].job); items.push_back(open[at].band); items.push_back(0); items.push_back(0);
                 cell_off.push_back(cells); ops_off.push_back(ops);
                 cells += need; ops += (uint64_t)(rl + ql + 2);
-                if (at >= group_end[0] && at < group_end[1]) max_band = std::max(max_band, open[at].band);        // (the LDS of the one-per-wavefront launch)
+                if (at >= n_narrow_all) max_band = std::max(max_band, open[at].band);        // (the LDS of the one-per-wavefront launch)
             }
             const size_t ni = at - first;
-            // how many of this launch's items [first, at) fall into each group
-            auto in_group = [&](size_t lo, size_t hi) { const size_t a = std::max(first, lo), b = std::min(at, hi); return b > a ? b - a : (size_t)0; };
-            const size_t n_narrow = in_group(0, group_end[0]), n_group4 = in_group(group_end[1], group_end[2]), n_group16 = in_group(group_end[2], group_end[3]);
+            const size_t n_narrow = first < n_narrow_all ? std::min(ni, n_narrow_all - first) : 0;
             if ((rc = h->d_path_items.ensure(items.size())) || (rc = h->d_path_cell_off.ensure(ni)) || (rc = h->d_path_ops_off.ensure(ni)) ||
                 (rc = h->d_path_cells.ensure((size_t)std::max<uint64_t>(cells, 16))) || (rc = h->d_path_scratch.ensure((size_t)ops)))
                 return rc;
@@ -376,7 +370,7 @@ int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const s
             HIP_TRY(hipMemcpyAsync(h->d_path_ops_off.p, ops_off.data(), ni * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
             rb::launch_ssw_paths(h->dev_ascii_src, h->length, h->d_ssw_pool.p, h->d_ssw_jobs.p, h->d_ssw_out.p, h->d_path_items.p, h->d_path_cell_off.p,
                                  h->d_path_ops_off.p, (int)ni, max_band, h->d_path_cells.p, h->d_path_scratch.p, h->d_path_ops.p, (uint32_t)path_cap,
-                                 h->d_path_count.p, h->d_path_result.p, h->stream, (int)n_narrow, (int)n_group4, (int)n_group16);
+                                 h->d_path_count.p, h->d_path_result.p, h->stream, (int)n_narrow);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(h->stream));       // the item arrays above are reused by the next launch
         }

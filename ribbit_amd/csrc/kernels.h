@@ -182,20 +182,15 @@ void launch_ssw_passes(const uint8_t *ascii, int64_t length, const uint8_t *moti
 // ((2*band+1) * read_len) and scratch operations (ref_len + read_len + 2 entries) go; finished paths are appended to
 // path_ops (path_cap entries, *path_count their number so far); result[4*job..] = {state, band, first operation in
 // path_ops, operations}: state 0 path found, 1 walk failed, 2 band too narrow (run again with twice the band).
-// The items come in four groups, in this order (n_items = their sum): n_narrow with a band of at most SSW_PATH_NARROW_BAND, four to a
-// wavefront (ssw_path4_kernel); then those on one wavefront each (ssw_path_kernel: a row of at most 64 cells -- band <=
-// SSW_PATH_WAVE_BAND -- or a band beyond the workgroup kernel's reach; max_band: the largest band among THESE, sizes their LDS); then
-// n_group4 and n_group16 on a workgroup of 4 / 16 wavefronts each (ssw_pathg_kernel, a wavefront per 64-cell chunk of a row: bands
-// up to SSW_PATH_GROUP4_BAND / SSW_PATH_GROUP16_BAND).
+// max_band: the largest band among the items (sizes the LDS).
 constexpr int SSW_PATH_MAX_BAND = 2048;
-constexpr int SSW_PATH_NARROW_BAND = 7;
-constexpr int SSW_PATH_WAVE_BAND = 31;         // 2 * 31 + 1 = 63 cells: one chunk
-constexpr int SSW_PATH_GROUP4_BAND = 127;      // 255 cells: four chunks
-constexpr int SSW_PATH_GROUP16_BAND = 511;     // 1023 cells: sixteen chunks
 void launch_ssw_paths(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs, const int32_t *ends,
                       const int32_t *items, const uint64_t *cell_off, const uint64_t *ops_off, int n_items, int max_band,
                       uint8_t *cells, uint32_t *ops, uint32_t *path_ops, uint32_t path_cap, uint32_t *path_count, int32_t *result,
-                      hipStream_t stream, int n_narrow = 0, int n_group4 = 0, int n_group16 = 0);
+                      hipStream_t stream, int n_narrow = 0);
+// n_narrow: the first n_narrow items have a band of at most SSW_PATH_NARROW_BAND and run four to a wavefront (ssw_path4_kernel);
+// max_band then is the largest band among the OTHERS.
+constexpr int SSW_PATH_NARROW_BAND = 7;
 
 // profiling aid: reads nwords dwords of src with one coalesced dword per lane (known byte count)
 void launch_calib_stream_read(const uint32_t *src, int64_t nwords, uint32_t *sink, hipStream_t stream);

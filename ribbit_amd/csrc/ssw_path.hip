@@ -320,148 +320,20 @@ __global__ __launch_bounds__(64) void ssw_path4_kernel(const uint8_t *__restrict
     walk_back(cell, row_cells, band, ref_len, read_len, ops + ops_off[t], path_ops, path_cap, path_count, res);
 }
 
-// The same search for alignments with a WIDE band, a workgroup per alignment (round 4).  On one wavefront a row of the band is walked
-// in chunks of 64 cells, one after the other, and the twentieth of a record's alignments whose band exceeds 31 cells -- the long
-// batch's above all: thousands of rows, hundreds of cells each -- was three quarters of the path search's time.  But a
-// row has no order inside it: E and the diagonal come from the row above, and F is a PREFIX MAXIMUM along the row of values that
-// come from the row above too -- f[k] = max(F0, max_{s<k} (g[s] - open + (s + 1) extend)) - k extend with F0 = -extend (the cell
-// left of the row is out of band), which is the recurrence f[k+1] = max(g[k] - open, f[k] - extend) unrolled; the single-wavefront
-// kernel's chunk carry is the same number.  So every wavefront of the workgroup takes ONE chunk of the row: (a) g of its cells and
-// the prefix maximum inside the chunk, the chunk's maximum to LDS; (b) barrier; (c) the maxima of the chunks before it are its
-// carry; h, f, the direction byte, the row state for the next row; (d) barrier.  Two barriers a row instead of up to sixteen
-// dependent chunk iterations.  The row state is written in place (after (b) nobody reads the row above any more); the slot the
-// next row treats as cleared (the library's `edge`, cleared by the single-wavefront kernel at the start of the row) is written as
-// zero right away.  Same cells, same bytes, same walk back (one thread) as the kernels above.
-// blockDim = 64 T, T = 4 or 16 wavefronts; the band satisfies 2 band + 1 <= 64 T.
-__global__ __launch_bounds__(1024) void ssw_pathg_kernel(const uint8_t *__restrict__ ascii, int64_t length, const uint8_t *__restrict__ motif_pool,
-                                                         const int32_t *__restrict__ jobs /* 9 ints each */, const int32_t *__restrict__ ends /* 8 ints each */,
-                                                         const int32_t *__restrict__ items, const uint64_t *__restrict__ cell_off,
-                                                         const uint64_t *__restrict__ ops_off, int n_items, uint8_t *__restrict__ cells,
-                                                         uint32_t *__restrict__ ops, uint32_t *__restrict__ path_ops, uint32_t path_cap,
-                                                         uint32_t *__restrict__ path_count, int32_t *__restrict__ result) {
-    extern __shared__ int32_t lds[];          // h_above[slots + 1], e_above[slots + 1], per wavefront {chunk maximum, the same without its last cell, g of its last cell}, best
-    const int t = (int)blockIdx.x;
-    if (t >= n_items) return;
-    const int tid = (int)threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), T = (int)blockDim.x >> 6;
-    const int job = items[4 * t], band = items[4 * t + 1];
-    const int32_t *jb = jobs + 9 * (int64_t)job;
-    const int32_t *en = ends + 8 * (int64_t)job;
-    const int atom = jb[3];
-    int qstart = jb[4];
-    if (qstart < 0) qstart = 0;
-    const uint8_t *motif = motif_pool + jb[8];
-    const int score = en[0], ref_end = en[1], query_end = en[2], ref_begin = en[5], query_begin = en[6];
-    const int ref_len = ref_end - ref_begin + 1, read_len = query_end - query_begin + 1;
-    const int row_cells = 2 * band + 1, slots = row_cells + 2;
-    int32_t *h_above = lds, *e_above = lds + (slots + 1), *summ = lds + 2 * (slots + 1), *bestw = summ + 3 * T;
-    for (int i = tid; i < 2 * (slots + 1); i += (int)blockDim.x) lds[i] = 0;
-    uint8_t *cell = cells + cell_off[t];
-    const uint8_t *q_at = ascii + qstart + query_begin;
-    const int k = (w << 6) + lane;              // this thread's cell of every row (chunk = wavefront)
-    int cell_mod = (ref_begin + k) % atom;      // (ref_begin + first + k) % atom, carried from row to row
-    constexpr int NEG = INT32_MIN / 2;
-    const int f_zero = max(0 - GAP_O, 0 - GAP_E);       // f of a row's first cell: the cell to its left is out of band (h = f = 0)
-    int best = 0;
-    for (int i = 0; i < read_len; ++i) {
-        const int first = max(0, i - band), last = min(ref_len - 1, i + band);
-        const int first_above = max(0, i - 1 - band);
-        const int n_in_row = last - first + 1;
-        if (i > band) { if (++cell_mod == atom) cell_mod = 0; }
-        __syncthreads();                        // the row above is complete (and, before row 0, the cleared state)
-        const bool live = k < n_in_row;
-        const int j = first + k, u = k + 1;
-        const int above = j - first_above + 1;
-        int e = 0, g = 0, diag = 0;
-        uint8_t code = 0;
-        if (live) {
-            const int qc = path_code(q_at[i]);
-            const int e_open = i == 0 ? -GAP_O : h_above[above] - GAP_O;
-            const int e_ext = i == 0 ? -GAP_E : e_above[above] - GAP_E;
-            e = max(e_open, e_ext);
-            if (e_open > e_ext) code |= E_OPENS;
-            const int rc = path_code(motif[cell_mod]);
-            diag = h_above[above - 1] + ((rc == qc && rc < 4) ? 2 : -2);
-            g = max(max(e, 0), diag);
-        }
-        const int inject = live ? g - GAP_O + (k + 1) * GAP_E : NEG;
-        const int before_local = wave_exclusive_max(inject, NEG, lane);
-        {
-            const int m_but_last = __builtin_amdgcn_readlane(before_local, 63);
-            const int m_all = max(m_but_last, __builtin_amdgcn_readlane(inject, 63));
-            const int g_last = __builtin_amdgcn_readlane(g, 63);
-            if (lane == 0) { summ[3 * w] = m_all; summ[3 * w + 1] = m_but_last; summ[3 * w + 2] = g_last; }
-        }
-        __syncthreads();                        // every chunk's summary is there; nobody reads the row above any more
-        int carry = NEG, carry_but_one = NEG;   // maximum over the chunks before this one / before the one before
-        for (int c = 0; c < w; ++c) { carry_but_one = carry; carry = max(carry, summ[3 * c]); }
-        const int f = max(f_zero, max(carry, before_local)) - k * GAP_E;
-        const int h = max(g, f);
-        // h and f of the cell to the left: the lane below, or -- first lane of a chunk -- the last cell of the chunk before
-        int h_first = 0, f_first = 0;
-        if (w > 0) {
-            f_first = max(f_zero, max(carry_but_one, summ[3 * (w - 1) + 1])) - (k - 1) * GAP_E;
-            h_first = max(summ[3 * (w - 1) + 2], f_first);
-        }
-        const int h_prev = from_lane_below(h, h_first, lane), f_prev = from_lane_below(f, f_first, lane);
-        // the slot the next row treats as cleared
-        const int next_edge = min(min(ref_len - 1, i + 1 + band) + 1, slots - 1);
-        if (live) {
-            if (h_prev - GAP_O > f_prev - GAP_E) code |= F_OPENS;
-            const int e0 = max(e, 0), f0 = max(f, 0);
-            const int gap = max(e0, f0);
-            code |= gap <= diag ? FROM_DIAG : (e0 > f0 ? FROM_E : FROM_F);
-            cell[(size_t)row_cells * i + k] = code;
-            e_above[u] = u == next_edge ? 0 : e;
-            h_above[u] = u == next_edge ? 0 : h;
-            best = max(best, h);
-        } else if (k < row_cells) {
-            cell[(size_t)row_cells * i + k] = NO_CELL;      // columns past the reference
-        }
-        if (tid == 0 && next_edge > n_in_row) { h_above[next_edge] = 0; e_above[next_edge] = 0; }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) best = max(best, __shfl_xor(best, d));
-    if (lane == 0) bestw[w] = best;
-    __threadfence_block();                      // the cells this workgroup wrote, visible to the thread that walks back
-    __syncthreads();
-    if (tid != 0) return;
-    for (int c = 1; c < T; ++c) best = max(best, bestw[c]);
-    const int longest = max(ref_len, read_len);
-    int32_t *res = result + 4 * (int64_t)job;
-    if (best < score && band * 2 <= longest) { res[0] = 2; res[1] = band; res[2] = 0; res[3] = 0; return; }
-    walk_back(cell, row_cells, band, ref_len, read_len, ops + ops_off[t], path_ops, path_cap, path_count, res);
-}
-
-// The items of a launch come in four groups, in this order: n_narrow with a band of at most SSW_PATH_NARROW_BAND (four to a
-// wavefront), n_wave on one wavefront each (a row of at most 64 cells, or a band beyond the workgroup kernel's reach; max_band: the
-// widest of them, for the LDS), n_group4 and n_group16 on a workgroup of 4 / 16 wavefronts each (bands up to SSW_PATH_GROUP4_BAND /
-// SSW_PATH_GROUP16_BAND).
+// n_narrow: the first n_narrow items have a band of at most SSW_PATH_NARROW_BAND (four to a wavefront); max_band: of the others
 void launch_ssw_paths(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs, const int32_t *ends,
                       const int32_t *items, const uint64_t *cell_off, const uint64_t *ops_off, int n_items, int max_band,
                       uint8_t *cells, uint32_t *ops, uint32_t *path_ops, uint32_t path_cap, uint32_t *path_count, int32_t *result,
-                      hipStream_t stream, int n_narrow, int n_group4, int n_group16) {
+                      hipStream_t stream, int n_narrow) {
     if (n_items <= 0) return;
     n_narrow = max(0, min(n_narrow, n_items));
-    n_group16 = max(0, min(n_group16, n_items - n_narrow));
-    n_group4 = max(0, min(n_group4, n_items - n_narrow - n_group16));
-    const int n_wave = n_items - n_narrow - n_group4 - n_group16;
     if (n_narrow > 0)
         hipLaunchKernelGGL(ssw_path4_kernel, dim3((unsigned)((n_narrow + 3) / 4)), dim3(64), 0, stream, ascii, length, motif_pool, jobs, ends, items, cell_off,
                            ops_off, n_narrow, cells, ops, path_ops, path_cap, path_count, result);
-    // the widest first: a launch lasts as long as its longest alignment, and these are the long ones
-    auto group = [&](int at, int n, int waves, int band_limit) {
-        if (n <= 0) return;
-        const size_t lds = (2 * (size_t)(2 * band_limit + 1 + 2 + 1) + 4 * (size_t)waves) * sizeof(int32_t);
-        hipLaunchKernelGGL(ssw_pathg_kernel, dim3((unsigned)n), dim3(64u * (unsigned)waves), lds, stream, ascii, length, motif_pool, jobs, ends,
-                           items + 4 * (size_t)at, cell_off + at, ops_off + at, n, cells, ops, path_ops, path_cap, path_count, result);
-    };
-    group(n_narrow + n_wave + n_group4, n_group16, 16, SSW_PATH_GROUP16_BAND);
-    group(n_narrow + n_wave, n_group4, 4, SSW_PATH_GROUP4_BAND);
-    if (n_wave > 0) {
+    if (n_items > n_narrow) {
         const size_t lds = 3 * (size_t)(2 * max_band + 1 + 2 + 1) * sizeof(int32_t);
-        hipLaunchKernelGGL(ssw_path_kernel, dim3((unsigned)n_wave), dim3(64), lds, stream, ascii, length, motif_pool, jobs, ends,
-                           items + 4 * (size_t)n_narrow, cell_off + n_narrow, ops_off + n_narrow, n_wave, cells, ops, path_ops, path_cap, path_count, result);
+        hipLaunchKernelGGL(ssw_path_kernel, dim3((unsigned)(n_items - n_narrow)), dim3(64), lds, stream, ascii, length, motif_pool, jobs, ends,
+                           items + 4 * (size_t)n_narrow, cell_off + n_narrow, ops_off + n_narrow, n_items - n_narrow, cells, ops, path_ops, path_cap, path_count, result);
     }
 }
 
