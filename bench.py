@@ -354,19 +354,53 @@ def sharded_full_path(ribbit_amd, dist, torch, sc, seq: bytes, bases: int, rank:
     sent = sharded.part_bytes(part)
     all_sent = [None] * world
     dist.all_gather_object(all_sent, dict(sent, halo_grown=part["halo_grown"], left_halo=part["left_halo"]))
+    lists, t_merge = None, 0.0
+    if rank == 0:
+        t2 = time.perf_counter()
+        lists = sharded.merge_parts(M_LO, M_HI, L, gathered)
+        t_merge = time.perf_counter() - t2
+    # Refinement over the ranks (round 4; ribbit_hip_adopt_dispatch): the dispatched seeds are independent, so rank r takes the r-th
+    # slice of the dispatch list -- 16 bytes a seed from rank 0 -- with the record loaded on its own GPU (the composed planes made
+    # there by the planes kernel alone), refines it on its GPU and its share of the host threads, and the BED text of the slices goes
+    # back to rank 0 in order.  (An alignment with an empty query at the head of a slice would need the record refined in one
+    # piece, as ribbit-hip does: reported here, and the texts' identity with the one-GPU run is checked either way.)
+    sync()
+    t3 = time.perf_counter()
+    box = [lists["dispatch"] if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    dispatch_all = box[0]
+    nd = len(dispatch_all)
+    lo, hi = nd * rank // world, nd * (rank + 1) // world
+    sc.load_record(record)
+    sc.adopt_dispatch(dispatch_all[lo:hi])
+    my_bed = sc.refine_bed("rec")
+    met_empty = sc.refine_met_empty_query()
+    torch.cuda.synchronize()
+    t_refine_own = time.perf_counter() - t3
+    beds = [None] * world
+    dist.all_gather_object(beds, (my_bed, bool(met_empty), t_refine_own))
+    sync()
+    t_refine = time.perf_counter() - t3
     if rank != 0:
         return None
-    t2 = time.perf_counter()
-    lists = sharded.merge_parts(M_LO, M_HI, L, gathered)
-    t_merge = time.perf_counter() - t2
     sc.load_record(record)
     perfect, subst, anchored = sc.processShiftXORsAnchored()
     dispatch = sc.dispatch_seeds()
     same = all(np.array_equal(lists[k].view("<i4"), w.view("<i4")) for k, w in
                (("perfect", perfect), ("subst", subst), ("anchored", anchored), ("dispatch", dispatch)))
-    total = float(t.item()) + t_exchange + t_merge
+    t4 = time.perf_counter()
+    bed_one = sc.refine_bed("rec")
+    t_refine_one_gpu = time.perf_counter() - t4
+    bed_sharded = "".join(b[0] for b in beds)
+    any_empty = any(b[1] for b in beds[1:])
+    total = float(t.item()) + t_exchange + t_merge + t_refine
     return {"bases": L, "bases_per_gpu": bases, "seconds": total, "value": L / total / 1e9, "unit": "Gbases/s",
             "scan_seconds_max_over_ranks": float(t.item()), "exchange_seconds": t_exchange, "merge_seconds_rank0": t_merge,
+            "refinement": {"seconds": t_refine, "seconds_per_rank": [b[2] for b in beds], "seconds_on_one_gpu": t_refine_one_gpu,
+                           "bed_rows": bed_sharded.count("\n"), "identical_to_single_gpu_bed": bool(bed_sharded == bed_one),
+                           "empty_query_at_a_slice_head": bool(any_empty),
+                           "what": "the dispatch list from rank 0 (16 B a seed), a slice per rank refined on that rank's GPU and host threads "
+                                   "(ribbit_hip_adopt_dispatch), the slices' BED text gathered on rank 0; `seconds` from the broadcast to the last text"},
             "exchange": {"headline": headline_transport, "headline_rule": "the faster of the transports timed in this run",
                          "seconds": by_transport, "shm_identical_to_collective": shm_identical},
             "identical_to_single_gpu_scan": bool(same),
@@ -374,7 +408,7 @@ def sharded_full_path(ribbit_amd, dist, torch, sc, seq: bytes, bases: int, rank:
             "dispatched": int(len(lists["dispatch"])), "sent_per_rank": all_sent,
             "what": "one record chunk-sharded over the ranks, perfect + substitution + anchored stages: per-rank device stages (scan, pairing, "
                     "window state machines, filters), gather-v of 16-byte run records and kept calls + the ranks' plane words to rank 0, "
-                    "merges and dispatch order on rank 0; refinement not included"}
+                    "merges and dispatch order on rank 0, refinement sharded by dispatched seed over the ranks"}
 
 
 def main():

@@ -165,6 +165,21 @@ int ribbit_hip_seeds_anchored(RibbitHandle *h, const RibbitSeed **perfect, size_
 int ribbit_hip_dispatch_seeds(RibbitHandle *h, const RibbitSeed **out, size_t *n);
 
 /*
+ * Refinement of ONE record on several GPUs (fasta_utils.cpp:211-242 handles the dispatched seeds one after the other, and each
+ * independently of the others): a handle on another GPU that has the same record loaded takes over a SLICE of the dispatch list --
+ * `seeds` = n consecutive entries of the list ribbit_hip_dispatch_seeds returned on the handle that ran the stages (they are
+ * copied; they may also be a slice of this handle's own list) -- makes the composed planes on its own device (the planes kernel
+ * alone: no scan, no merge) and is then ready for ribbit_hip_refine_bed, whose text is the BED rows of exactly those seeds.  The
+ * slices' texts, in order, are the record's BED -- with ONE exception the caller must check: an alignment with an empty query sees
+ * the previous seed's CIGAR (the reference's shared Alignment object); inside a slice that is resolved exactly, across a slice's
+ * first seed it cannot be, so if ribbit_hip_refine_met_empty_query is 1 for any slice the record is refined again in one piece.
+ * After this call the handle's seed lists are not available (ribbit_hip_seeds_* run the stages again from the next load on).
+ */
+int ribbit_hip_adopt_dispatch(RibbitHandle *h, const RibbitSeed *seeds, size_t n);
+/* 1 if the last ribbit_hip_refine_bed on this handle met an alignment with an empty query */
+int ribbit_hip_refine_met_empty_query(const RibbitHandle *h);
+
+/*
  * Thresholds the refinement scans read from the reference's globals: MINIMUM_LENGTH / PERFECT_UNITS
  * (global_variables.h:36-38, filled at ribbit.cpp:143-174,219-235; index = motif size, 0 = the value
  * operator[] default-inserts for a missing key), PURITY_THRESHOLD (always 0.85, -p is ignored) and

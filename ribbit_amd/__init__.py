@@ -42,6 +42,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_subst_calls", "ribbit_hip_seeds_substitutions",
     "ribbit_host_replay_calls", "ribbit_seed_lists_free", "ribbit_host_longest_runs", "ribbit_debug_set_merge_min_range", "ribbit_debug_last_merge",
     "ribbit_hip_small_motifs", "ribbit_debug_small_motif_counters", "ribbit_debug_last_dispatch_ranges", "ribbit_debug_alignment_counters", "ribbit_debug_level_counters",
+    "ribbit_hip_adopt_dispatch", "ribbit_hip_refine_met_empty_query",
     "ribbit_hip_anchored_calls", "ribbit_hip_seeds_anchored", "ribbit_hip_dispatch_seeds", "ribbit_hip_guard_hits",
     "ribbit_hip_debug_stream_read",
     "ribbit_refine_params_default", "ribbit_hip_seed_longest_runs", "ribbit_hip_refine_jobs",
@@ -185,6 +186,8 @@ def load_library():
     L.ribbit_debug_last_dispatch_ranges.argtypes = []
     L.ribbit_debug_alignment_counters.restype = None
     L.ribbit_debug_alignment_counters.argtypes = [C.POINTER(C.c_int64 * 3)]
+    L.ribbit_hip_adopt_dispatch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.ribbit_hip_refine_met_empty_query.argtypes = [C.c_void_p]
     L.ribbit_debug_level_counters.restype = None
     L.ribbit_debug_level_counters.argtypes = [C.POINTER(C.c_int64 * 3)]
     L.ribbit_debug_small_motif_counters.restype = None
@@ -767,6 +770,14 @@ class Scanner:
         if not n.value:
             return np.zeros(0, dtype=np.uint8)
         return np.ctypeslib.as_array(C.cast(text.value, C.POINTER(C.c_uint8)), shape=(n.value,))
+
+    def adopt_dispatch(self, seeds) -> None:
+        """ribbit_hip_adopt_dispatch: this handle (same record loaded) refines a slice of another handle's dispatch list"""
+        d = np.ascontiguousarray(seeds, dtype=SEED_DT)
+        self._check(self._L.ribbit_hip_adopt_dispatch(self._h, d.ctypes.data, len(d)))
+
+    def refine_met_empty_query(self) -> bool:
+        return bool(self._L.ribbit_hip_refine_met_empty_query(self._h))
 
     def guard_hits(self) -> int:
         return int(self._L.ribbit_hip_guard_hits(self._h))

@@ -213,6 +213,7 @@ struct RibbitHandle {
     std::string bed;
     int stage_done = STAGE_NONE;          // how far the seed lists have been advanced
     rb::SeedLists lists;
+    bool refine_met_empty_query = false;  // the last ribbit_hip_refine_bed on this handle met an alignment with an empty query (ribbit_hip_refine_met_empty_query)
     RibbitHandle *aux = nullptr;          // helper handle of ribbit_hip_refine_bed: streams and buffers of the long alignment batch
     RibbitHandle *aux2 = nullptr;         // ... and of its second feeder (every other slice of the short alignments)
 

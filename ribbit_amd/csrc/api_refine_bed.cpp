@@ -9,7 +9,11 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
 int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const char *sequence_id,
                           const char **text, size_t *len) {
     try {
-        return refine_bed_impl(h, prm, sequence_id, text, len);
+        // (the helper threads' calls report an empty query through their order_dependent flags, which end in a call on THIS thread)
+        rb::refine_met_empty_query(true);
+        const int rc = refine_bed_impl(h, prm, sequence_id, text, len);
+        if (h) h->refine_met_empty_query = rb::refine_met_empty_query(true);
+        return rc;
     } catch (const std::bad_alloc &) {           // nothing may unwind through the C boundary
         return fail(RIBBIT_E_NOMEM, "out of host memory in refinement");
     }
@@ -629,5 +633,41 @@ void ribbit_text_free(char *text) { std::free(text); }
 void ribbit_debug_level_counters(int64_t out[3]) {
     for (int k = 0; k < 3; ++k) out[k] = g_level_counts[k].load();
 }
+
+int ribbit_hip_adopt_dispatch(RibbitHandle *h, const RibbitSeed *seeds, size_t n) {
+    if (!h || (n && !seeds)) return fail(RIBBIT_E_ARG, "null argument");
+    if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
+    if (h->pair_pending || h->copy_pending) return fail(RIBBIT_E_STATE, "a perfect scan is in flight on this handle");
+    int rc;
+    if ((rc = bind_device(h))) return rc;
+    if ((rc = ensure_host_planes(h))) return rc;
+    // the composed planes on THIS device (the scans of the seeds read them there): the planes kernel alone, no window scan
+    if (!h->xa_on_device) {
+        if ((rc = prepare_anchored(h))) return rc;
+        rb::PerfectLaunch pp;
+        pp.m_lo = h->params.min_motif;
+        pp.m_hi = h->params.max_motif;
+        pp.ev_cap = 0;
+        rb::launch_scan_anchored(h->planes(), pp, h->d_xa.p, h->xa_stride, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->xa_on_device = true;
+    }
+    // No host copy of the composed planes is made: refinement reads them on the host only for the flank nodes' longest runs, and
+    // HostPlanes recomputes the slice a query covers from the packed planes when it has no copy (0.6 us a query).
+    if (h->stage_done < STAGE_ANCHORED) {
+        if (h->xa_copy_pending) { HIP_TRY(hipEventSynchronize(h->ev_xa)); h->xa_copy_pending = false; }
+        h->host.xa.clear(); h->host.xa_view = nullptr; h->host.xa_stride = 0;
+        h->host.xa_m_lo = h->params.min_motif; h->host.xa_m_hi = h->params.max_motif;      // plane m IS the composed plane (fasta_utils.cpp:159), recomputed on request
+    }
+    // `seeds` may point into this handle's own dispatch list (a slice of it)
+    rb::SeedVec taken(seeds, seeds + n);
+    h->dispatch.swap(taken);
+    h->longest_valid = false; h->best_rows_valid = false; h->small_valid = false;
+    h->stage_done = STAGE_ANCHORED;
+    return RIBBIT_OK;
+}
+
+int ribbit_hip_refine_met_empty_query(const RibbitHandle *h) { return h && h->refine_met_empty_query ? 1 : 0; }
 
 }  // extern "C"

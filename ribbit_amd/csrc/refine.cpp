@@ -850,6 +850,9 @@ struct Writer {
 
 }  // namespace
 
+namespace { thread_local bool tl_met_empty_query = false; }
+bool refine_met_empty_query(bool reset) { const bool v = tl_met_empty_query; if (reset) tl_met_empty_query = false; return v; }
+
 void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefineParams &prm,
                    const SeedVec &dispatch, const int32_t *longest_runs, const int32_t *best_rows,
                    const std::string &sequence_id, std::string &bed, unsigned host_threads,
@@ -957,6 +960,7 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
         for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
         work();
         for (std::thread &th : pool) th.join();
+        if (empty_seen) tl_met_empty_query = true;
         if (empty_seen && order_dependent) *order_dependent = true;
         return;
     }
@@ -984,6 +988,7 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
                 flush_counters();
             });
         for (std::thread &th : pool) th.join();
+        if (empty_seen) tl_met_empty_query = true;
         if (empty_seen && order_dependent) { *order_dependent = true; return; }
         if (empty_seen) sequential = true;
         else if (pieces) { for (auto &pp : part_pieces) for (BedPiece &pc : pp) pieces->push_back(std::move(pc)); }
@@ -993,6 +998,7 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
         Writer w(b, hp, sequence, prm, sequence_id);
         std::vector<BedPiece> segs;
         run_range(seed_lo, seed_hi, w, pieces ? &segs : nullptr);
+        if (w.saw_empty_query) tl_met_empty_query = true;
         if (pieces) for (BedPiece &pc : segs) pieces->push_back(std::move(pc));
         else bed += w.os.str();
         flush_counters();

@@ -104,6 +104,12 @@ void refine_to_bed(const HostPlanes &hp, const char *sequence, const RibbitRefin
 // tree (optional, needs pieces): nodes of long-motif seeds' recursion trees that are worth a GPU batch are not done here but
 // appended to tree->out, and the rows around them are cut into pieces that sort into place; with tree->nodes the call refines
 // such nodes (one per entry of `dispatch`, with `only`).
+// Whether a refine_to_bed call made by the CALLING THREAD since the last reset met an alignment with an empty query (the one order
+// dependence between seeds: such an alignment sees the previous seed's CIGAR).  Inside a call that is resolved exactly; a caller that
+// refines a record's seeds in SLICES of its own (several GPUs, include/ribbit_hip.h: ribbit_hip_adopt_dispatch) cannot resolve it
+// across a slice's first seed and redoes the record in one piece when a slice reports it.
+bool refine_met_empty_query(bool reset);
+
 // job_first (optional, with jobs): job_first[i - job_first_base] = first job (index into jobs) of dispatch seed i, for every seed
 // the call refines and the one after it (else it is worked out from the jobs' seed indices on every call).  With a base, `jobs`
 // may hold the jobs of a slice of the seed list only.

@@ -202,8 +202,56 @@ struct StageClock {
 };
 
 // processSequence (fasta_utils.cpp:59-250) through the C ABI, with the reference's progress lines
+// Refinement of ONE record over several GPUs (ribbit_hip_adopt_dispatch): the dispatched seeds in as many slices as there are
+// handles, equal numbers of seeds each (a seed's cost varies by orders of magnitude, but over millions of seeds the slices even
+// out); every helper loads the record on its own GPU, makes the composed planes there and refines its slice on its GPU's share of
+// the host threads; the texts in order are the record's BED.  An alignment with an empty query in any slice (it would see the
+// previous seed's CIGAR, which may be another slice's) makes the record be refined again in one piece, on `h`.
+struct Helper { RibbitHandle *h; int host_threads; };
+bool refine_over_devices(RibbitHandle *h, const std::vector<Helper> &helpers, const RibbitRefineParams &prm, const std::string &name, const char *bases,
+                         int64_t length, const RibbitSeed *d, size_t nd, std::ostream &out, std::ostream &log) {
+    const size_t parts = helpers.size() + 1;
+    const std::vector<RibbitSeed> all(d, d + nd);          // (`d` is `h`'s own list, which adopting a slice replaces)
+    std::vector<std::string> text(parts), error(parts);
+    std::vector<int> empty_query(parts, 0);
+    auto slice = [&](size_t k, RibbitHandle *hk, bool load) {
+        const size_t lo = nd * k / parts, hi = nd * (k + 1) / parts;
+        if (load && ribbit_hip_load_record_pinned(hk, bases, length) != RIBBIT_OK) { error[k] = ribbit_hip_last_error(); return; }
+        const char *t = nullptr;
+        size_t len = 0;
+        if (ribbit_hip_adopt_dispatch(hk, all.data() + lo, hi - lo) != RIBBIT_OK || ribbit_hip_refine_bed(hk, &prm, name.c_str(), &t, &len) != RIBBIT_OK) {
+            error[k] = ribbit_hip_last_error();
+            return;
+        }
+        text[k].assign(t, len);
+        empty_query[k] = ribbit_hip_refine_met_empty_query(hk);
+    };
+    std::vector<std::thread> pool;
+    for (size_t k = 1; k < parts; ++k) {
+        check(ribbit_hip_set_host_threads(helpers[k - 1].h, helpers[k - 1].host_threads));
+        pool.emplace_back(slice, k, helpers[k - 1].h, true);
+    }
+    slice(0, h, false);
+    for (std::thread &t : pool) t.join();
+    for (size_t k = 0; k < parts; ++k)
+        if (!error[k].empty()) throw PathError{"GPU path failed: " + error[k]};
+    bool redo = false;
+    for (size_t k = 1; k < parts; ++k) redo = redo || empty_query[k] != 0;
+    if (redo) {
+        const char *t = nullptr;
+        size_t len = 0;
+        check(ribbit_hip_adopt_dispatch(h, all.data(), nd));
+        check(ribbit_hip_refine_bed(h, &prm, name.c_str(), &t, &len));
+        out.write(t, (std::streamsize)len);
+        log << "[devices] an alignment with an empty query at the head of a slice: the record was refined again in one piece\n";
+        return false;
+    }
+    for (size_t k = 0; k < parts; ++k) out.write(text[k].data(), (std::streamsize)text[k].size());
+    return true;
+}
+
 void process_sequence(RibbitHandle *h, const RibbitRefineParams &prm, const std::string &name, const char *bases, int64_t length,
-                      std::ostream &out, std::ostream &log) {
+                      std::ostream &out, std::ostream &log, const std::vector<Helper> *helpers = nullptr) {
     const time_t t0 = time(0);
     auto secs = [&]() { return difftime(time(0), t0); };
     { StageClock c(0); check(ribbit_hip_load_record_pinned(h, bases, length)); }
@@ -222,10 +270,19 @@ void process_sequence(RibbitHandle *h, const RibbitRefineParams &prm, const std:
     const RibbitSeed *d;
     size_t nd;
     { StageClock c(4); check(ribbit_hip_dispatch_seeds(h, &d, &nd)); }
-    const char *text;
-    size_t len;
-    { StageClock c(5); check(ribbit_hip_refine_bed(h, &prm, name.c_str(), &text, &len)); }
-    out.write(text, (std::streamsize)len);
+    // one record over several GPUs: only worth it from a few hundred thousand seeds on (RIBBIT_SHARD_MIN_SEEDS: a test hook)
+    static const size_t shard_min = std::getenv("RIBBIT_SHARD_MIN_SEEDS") ? (size_t)std::atoll(std::getenv("RIBBIT_SHARD_MIN_SEEDS")) : 400000;
+    if (helpers && !helpers->empty() && nd >= shard_min && nd >= 2 * (helpers->size() + 1)) {
+        StageClock c(5);
+        const bool sharded = refine_over_devices(h, *helpers, prm, name, bases, length, d, nd, out, log);
+        if (std::getenv("RIBBIT_PROFILE"))
+            log << "[devices] refinement of " << name << ": " << nd << " dispatched seeds " << (sharded ? "in " : "NOT in ") << helpers->size() + 1 << " slices over as many handles\n";
+    } else {
+        const char *text;
+        size_t len;
+        { StageClock c(5); check(ribbit_hip_refine_bed(h, &prm, name.c_str(), &text, &len)); }
+        out.write(text, (std::streamsize)len);
+    }
     log << "Total number of seeds that are processed for alignment: " << nd << "\t Time elapsed: " << secs() << "secs\n";
 }
 
@@ -402,9 +459,15 @@ int main(int argc, char **argv) {
     }
     if (!failed) {
         try {
-            check(ribbit_hip_set_host_threads(h, 0));
+            // The last record runs here, after the workers have gone: every other GPU of --devices is idle by now, so a long last
+            // record -- a FASTA with ONE chromosome, above all -- has its refinement dealt over all of them, a slice of the
+            // dispatched seeds per GPU with that GPU's share of the host threads (refine_over_devices; scans and merges stay on
+            // the first GPU: 0.55 of a chromosome's 2 s).
+            std::vector<Helper> helpers;
+            for (int d = 1; d < ndev && (size_t)d < handles.size(); ++d) helpers.push_back(Helper{handles[(size_t)d], (int)dev_cores});
+            check(ribbit_hip_set_host_threads(h, helpers.empty() ? 0 : (int)dev_cores));
             static const char kNoBases[1] = {0};
-            process_sequence(h, prm, last_name, last_bases ? last_bases : kNoBases, last_length, out, std::cerr);
+            process_sequence(h, prm, last_name, last_bases ? last_bases : kNoBases, last_length, out, std::cerr, &helpers);
         } catch (const PathError &e) { failed = true; failure = e.what; }
     }
     if (failed) { std::cerr << "ribbit-hip: " << failure << "\n"; status = 1; }

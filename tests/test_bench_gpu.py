@@ -98,3 +98,7 @@ def test_two_ranks_on_one_gpu_reproduce_the_unsharded_runs(exchange):
         assert fx["shm_identical_to_collective"] is True
     for sent in fp["sent_per_rank"]:
         assert sent["window_call_bytes"] == 16 * sent["kept_window_calls"] and sent["planes"] > 0
+    # refinement sharded by dispatched seed over the ranks (ribbit_hip_adopt_dispatch): the slices' BED back to back is the
+    # one-GPU run's
+    rf = fp["refinement"]
+    assert rf["identical_to_single_gpu_bed"] is True and rf["bed_rows"] > 1000 and len(rf["seconds_per_rank"]) == 2

@@ -272,3 +272,29 @@ def test_whole_path_on_a_two_megabase_record_matches_oracle():
         got = sc.refine_bed("chrTest")
         want = o.refine_bed("chrTest")
     assert got == want and want.count("\n") > 15_000
+
+
+def test_cli_one_record_refined_over_several_devices(tmp_path):
+    """`--devices` with ONE long record: scans and merges on the first GPU, the dispatched seeds refined in slices over all the
+    listed GPUs (here GPU 0 three times: three handles, three slices; RIBBIT_SHARD_MIN_SEEDS lowers the size from which that is
+    done), BED identical to the oracle's and to the one-device run."""
+    seq = simulated_cases()[1][1]
+    records = [("chrLong some description", seq[:110_000])]
+    fa, bed, bed1 = tmp_path / "in.fa", tmp_path / "out.bed", tmp_path / "one.bed"
+    write_fasta(str(fa), records)
+    want = _oracle_bed(records, 2, 100)
+    r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "100", "--devices", "0,0,0"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, RIBBIT_PROFILE="1", RIBBIT_SHARD_MIN_SEEDS="500"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert bed.read_text() == want
+    assert "in 3 slices over as many handles" in r.stderr, r.stderr[-1500:]
+    r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed1), "-m", "2", "-M", "100"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and bed1.read_text() == want
+    # several records: only the last one (processed when the others are done and the GPUs idle) is dealt that way
+    records = [("first", seq[:40_000]), ("second", seq[40_000:90_000]), ("third and last", seq[90_000:200_000])]
+    write_fasta(str(fa), records)
+    r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed), "-m", "2", "-M", "100", "--devices", "0,0"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, RIBBIT_PROFILE="1", RIBBIT_SHARD_MIN_SEEDS="500"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert bed.read_text() == _oracle_bed(records, 2, 100)
+    assert r.stderr.count("slices over as many handles") == 1 and "refinement of third" in r.stderr, r.stderr[-1500:]

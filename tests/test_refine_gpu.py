@@ -109,3 +109,28 @@ def test_bed_view_is_the_same_text_without_the_copy():
     with ribbit_amd.Scanner(2, 6) as sc:
         sc.load_record(b"ACGTTGCA" * 3)
         assert len(sc.refine_bed_view("none")) == len(sc.refine_bed("none"))
+
+
+def test_a_second_handle_refines_a_slice_of_the_dispatch_list():
+    """ribbit_hip_adopt_dispatch: refinement of one record over several GPUs.  A second handle with the same record loaded takes
+    slices of the dispatch list the first handle made, builds the composed planes on its own device (no scan, no merge) and
+    refines them; the slices' texts back to back are the record's BED -- the oracle's -- however the list is cut, also when the
+    first handle refines a slice of its own list."""
+    from ribbit_amd.simulate import simulate_sequence
+    seq, _ = simulate_sequence(400_000, 71, 2, 120, n_block_rate=0.2, lower_rate=0.1)
+    with Oracle(seq, 2, 120) as o:
+        o.run_all()
+        want = o.refine_bed("rec")
+    with ribbit_amd.Scanner(2, 120) as a, ribbit_amd.Scanner(2, 120) as b:
+        a.load_record(seq)
+        d = a.dispatch_seeds().copy()
+        assert len(d) > 5000
+        b.load_record(seq)
+        for cuts in ([0, len(d)], [0, len(d) // 3, len(d)], [0, 1, 17, len(d) // 2, len(d) - 1, len(d)]):
+            parts = []
+            for k, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+                h = a if k % 2 == 0 and len(cuts) > 2 else b          # the first handle takes slices of its own list too
+                h.adopt_dispatch(d[lo:hi])
+                parts.append(h.refine_bed("rec"))
+                assert not h.refine_met_empty_query()
+            assert "".join(parts) == want, cuts
