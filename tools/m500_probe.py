@@ -62,25 +62,41 @@ def make_reads(args):
 
 
 class VramPeak:
+    """per card: used memory before the run and its peak during it (the box may show other tenants' cards: the card that GREW
+    the most is taken to be ours)"""
     def __init__(self):
         self.files = glob.glob("/sys/class/drm/card*/device/mem_info_vram_used")
-        self.peak, self.base, self.stop = 0, 0, False
-        self.base = self.read()
+        self.stop = False
+        self.before = {f: self.read(f) for f in self.files}
+        self.top = dict(self.before)
         self.t = threading.Thread(target=self.loop, daemon=True)
 
-    def read(self):
-        best = 0
-        for f in self.files:
-            try:
-                best = max(best, int(open(f).read()))
-            except (OSError, ValueError):
-                pass
-        return best
+    @staticmethod
+    def read(f):
+        try:
+            return int(open(f).read())
+        except (OSError, ValueError):
+            return 0
 
     def loop(self):
         while not self.stop:
-            self.peak = max(self.peak, self.read())
+            for f in self.files:
+                self.top[f] = max(self.top[f], self.read(f))
             time.sleep(0.05)
+
+    @property
+    def grown(self):
+        return max((self.top[f] - self.before[f] for f in self.files), default=0)
+
+    @property
+    def peak(self):
+        f = max(self.files, key=lambda f: self.top[f] - self.before[f], default=None)
+        return self.top[f] if f else 0
+
+    @property
+    def base(self):
+        f = max(self.files, key=lambda f: self.top[f] - self.before[f], default=None)
+        return self.before[f] if f else 0
 
 
 def main():
@@ -140,7 +156,7 @@ def main():
     tail = [l for l in err.splitlines() if l.startswith("[stages") or l.startswith("[devices]") or l.startswith("[refine_bed] cumulative")]
     print(json.dumps({"workload": f"{a.mode}: {records} record(s), -m 2 -M {a.M}", "bases": total, "records": records, "wall_s": round(wall, 3),
                       "mbases_per_s": round(total / wall / 1e6, 3), "records_per_s": round(records / wall, 2), "bed_rows": rows,
-                      "peak_vram_gb": round(vram.peak / 1e9, 2), "vram_before_gb": round(vram.base / 1e9, 2), "peak_host_rss_gb": round(rss_kb / 1e6, 2),
+                      "peak_vram_gb": round(vram.peak / 1e9, 2), "vram_before_gb": round(vram.base / 1e9, 2), "vram_grown_gb": round(vram.grown / 1e9, 2), "peak_host_rss_gb": round(rss_kb / 1e6, 2),
                       "generate_s": round(t_gen, 1), "jobs": a.jobs or "auto", "profile": tail[-3:]}), flush=True)
     if not a.keep:
         os.remove(fasta); os.remove(bed)
