@@ -168,7 +168,8 @@ int ribbit_hip_open(const RibbitScanParams *params, int device, RibbitHandle **o
 int ribbit_hip_close(RibbitHandle *h) {
     if (!h) return RIBBIT_OK;
     if (h->aux) { (void)ribbit_hip_close(h->aux); h->aux = nullptr; }
-    if (h->aux2) { (void)ribbit_hip_close(h->aux2); h->aux2 = nullptr; }
+    for (RibbitHandle *fa : h->feed_aux) (void)ribbit_hip_close(fa);
+    h->feed_aux.clear();
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);

@@ -215,7 +215,7 @@ struct RibbitHandle {
     rb::SeedLists lists;
     bool refine_met_empty_query = false;  // the last ribbit_hip_refine_bed on this handle met an alignment with an empty query (ribbit_hip_refine_met_empty_query)
     RibbitHandle *aux = nullptr;          // helper handle of ribbit_hip_refine_bed: streams and buffers of the long alignment batch
-    RibbitHandle *aux2 = nullptr;         // ... and of its second feeder (every other slice of the short alignments)
+    std::vector<RibbitHandle *> feed_aux; // ... and of its further feeders (each takes every n-th slice of the short alignments)
 
     rb::DevicePlanes planes() const {
         rb::DevicePlanes pl;

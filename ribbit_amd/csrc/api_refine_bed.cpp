@@ -414,11 +414,19 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         // Two feeders on alternating slices, the second on a helper handle of its own (streams, buffers): a launch of the path
         // search lasts as long as its longest alignment, and with one feeder the GPU idles through every such tail before the
         // next slice's passes start.
-        size_t n_feeders = 2;
-        if (n_slices < 2) n_feeders = 1;
-        if (n_feeders == 2) {
-            if (!h->aux2 && ribbit_hip_open(&h->params, h->device, &h->aux2) != RIBBIT_OK) n_feeders = 1;      // (no memory for it: one feeder)
-            else { h->aux2->dev_ascii_src = h->dev_ascii_src; h->aux2->length = h->length; h->aux2->loaded = true; }
+        // (Two, by measurement: with three and four of them a chromosome's refinement took 1092-1103 ms against 1105-1127 ms with
+        // two, inside the run-to-run spread -- the GPU side is bound by the throughput of the passes and path searches, not by
+        // gaps between one feeder's launches; round 4, tools/refine_timing.py.)
+        constexpr size_t FEEDERS = 2;
+        size_t n_feeders = std::min(FEEDERS, n_slices);
+        for (size_t k = 1; k < n_feeders; ++k) {
+            if (h->feed_aux.size() < k) {
+                RibbitHandle *fa = nullptr;
+                if (ribbit_hip_open(&h->params, h->device, &fa) != RIBBIT_OK) { n_feeders = k; break; }      // (no memory for it: fewer feeders)
+                h->feed_aux.push_back(fa);
+            }
+            RibbitHandle *fa = h->feed_aux[k - 1];
+            fa->dev_ascii_src = h->dev_ascii_src; fa->length = h->length; fa->loaded = true;
         }
         auto feeder_loop = [&](size_t k, RibbitHandle *fh) {
             for (size_t c = k; c < n_slices && !stop; c += n_feeders) {
@@ -429,13 +437,16 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                 if (slices[c].rc) break;
             }
         };
-        std::thread feeder, feeder2;
+        std::vector<std::thread> feeders;
         struct FeederGuard {
-            std::atomic<bool> &stop; std::condition_variable &cv; std::thread &a, &b;
-            ~FeederGuard() { stop = true; cv.notify_all(); if (a.joinable()) a.join(); if (b.joinable()) b.join(); }
-        } feeder_guard{stop, cv, feeder, feeder2};
-        feeder = std::thread([&]() { feeder_loop(0, h); });
-        if (n_feeders == 2) feeder2 = std::thread([&]() { feeder_loop(1, h->aux2); });
+            std::atomic<bool> &stop; std::condition_variable &cv; std::vector<std::thread> &all;
+            ~FeederGuard() { stop = true; cv.notify_all(); for (std::thread &t : all) if (t.joinable()) t.join(); }
+        } feeder_guard{stop, cv, feeders};
+        feeders.reserve(n_feeders);
+        for (size_t k = 0; k < n_feeders; ++k) {
+            RibbitHandle *fh = k == 0 ? h : h->feed_aux[k - 1];
+            feeders.emplace_back([&feeder_loop, k, fh]() { feeder_loop(k, fh); });
+        }
         {
             // all slices in one parallel region (refine.cpp): a slice is handed over by the thread that finished its last chunk
             std::vector<std::pair<size_t, size_t>> bounds(n_slices);
@@ -468,8 +479,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         }
         stop = true;
         cv.notify_all();
-        feeder.join();
-        if (feeder2.joinable()) feeder2.join();
+        for (std::thread &t : feeders) t.join();
         const double tw = now_ms();
         if (long_thread.joinable()) long_thread.join();
         if (later_thread.joinable()) later_thread.join();
