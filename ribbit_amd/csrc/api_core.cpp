@@ -2,6 +2,8 @@
 // There is no CPU fallback for any scan anywhere in this library.
 #include "api_internal.h"
 
+#include <sys/mman.h>
+
 namespace rbapi {
 
 thread_local std::string g_last_error;
@@ -14,6 +16,60 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     g_last_error = buf;
     return code;
+}
+
+
+// ---- page-locked host memory (api_internal.h)
+namespace {
+constexpr size_t PINNED_HUGE_FROM = (size_t)64 << 20;
+std::mutex g_mapped_mu;
+std::vector<std::pair<void *, size_t>> g_mapped;      // regions made by mmap + hipHostRegister (a handful per process)
+}  // namespace
+
+int pinned_alloc(size_t bytes, void **out) {
+    *out = nullptr;
+    if (bytes >= PINNED_HUGE_FROM) {
+        const size_t len = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p != MAP_FAILED) {
+            (void)madvise(p, len, MADV_HUGEPAGE);
+            // fault the pages in on several threads (one touch per 4 KB covers both page sizes): registration alone would do it on one
+            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(std::thread::hardware_concurrency(), 16u), len >> 26));
+            auto touch = [p, len, nt](unsigned t) {
+                volatile char *c = static_cast<volatile char *>(p);
+                for (size_t i = len / nt * t, e = t + 1 == nt ? len : len / nt * (t + 1); i < e; i += 4096) c[i] = 0;
+            };
+            std::vector<std::thread> pool;
+            unsigned started = 1;          // part 0 is this thread's
+            try { for (; started < nt; ++started) pool.emplace_back(touch, started); } catch (...) {}
+            touch(0);
+            for (unsigned t = started; t < nt; ++t) touch(t);      // (parts whose thread could not start)
+            for (std::thread &th : pool) th.join();
+            if (hipHostRegister(p, len, hipHostRegisterDefault) == hipSuccess) {
+                std::lock_guard<std::mutex> lk(g_mapped_mu);
+                g_mapped.emplace_back(p, len);
+                *out = p;
+                return RIBBIT_OK;
+            }
+            (void)hipGetLastError();
+            munmap(p, len);
+        }
+    }
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { *out = nullptr; return fail(RIBBIT_E_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
+    return RIBBIT_OK;
+}
+
+void pinned_free(void *p) {
+    if (!p) return;
+    size_t len = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_mapped_mu);
+        for (size_t i = 0; i < g_mapped.size(); ++i)
+            if (g_mapped[i].first == p) { len = g_mapped[i].second; g_mapped.erase(g_mapped.begin() + (std::ptrdiff_t)i); break; }
+    }
+    if (len) { (void)hipHostUnregister(p); munmap(p, len); }
+    else (void)hipHostFree(p);
 }
 
 }  // namespace rbapi
@@ -256,15 +312,11 @@ int ribbit_hip_load_record_device(RibbitHandle *h, const void *dev_ascii, int64_
 
 int ribbit_hip_host_alloc(size_t bytes, void **out) {
     if (!out || !bytes) return fail(RIBBIT_E_ARG, "bad argument");
-    *out = nullptr;
-    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
-    if (e != hipSuccess) { *out = nullptr; return fail(RIBBIT_E_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
-    return RIBBIT_OK;
+    return pinned_alloc(bytes, out);
 }
 
 int ribbit_hip_host_free(void *p) {
-    if (!p) return RIBBIT_OK;
-    HIP_TRY(hipHostFree(p));
+    pinned_free(p);
     return RIBBIT_OK;
 }
 

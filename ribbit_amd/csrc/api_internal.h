@@ -63,19 +63,28 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Page-locked host memory (api_core.cpp).  From PINNED_HUGE_FROM bytes on: anonymous memory advised into 2-MB pages, touched on
+// several threads, then registered with the runtime -- measured on the GPU box (tools/probes/pin_probe.hip, 8 GB): 0.05 s against
+// 1.27 s for hipHostMalloc, the copies into it at the same 53 GB/s.  The composed planes' host copy is 3 GB for a chromosome at
+// -M 100 and 15.5 GB at -M 500 (2.5 s of a 15-s run before).  Falls back to hipHostMalloc wherever a step fails.
+int pinned_alloc(size_t bytes, void **out);      // RIBBIT_OK / RIBBIT_E_NOMEM (fail() has the message)
+void pinned_free(void *p);
+
 template <typename T>
 struct PinnedBuf {
     T *p = nullptr;
     size_t cap = 0;
     int ensure(size_t n) {
         if (n <= cap) return RIBBIT_OK;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-        hipError_t e = hipHostMalloc((void **)&p, n * sizeof(T), hipHostMallocDefault);
-        if (e != hipSuccess) { p = nullptr; return fail(RIBBIT_E_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e)); }
+        if (p) { pinned_free(p); p = nullptr; cap = 0; }
+        void *q = nullptr;
+        const int rc = pinned_alloc(n * sizeof(T), &q);
+        if (rc) return rc;
+        p = static_cast<T *>(q);
         cap = n;
         return RIBBIT_OK;
     }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) pinned_free(p); p = nullptr; cap = 0; }
 };
 
 inline double now_ms() {

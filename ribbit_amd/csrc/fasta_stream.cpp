@@ -50,7 +50,7 @@ struct RibbitFastaReader {
         b.cap = cap;
         if (pinned) {
             void *p = nullptr;
-            if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { error = "hipHostMalloc failed"; return RIBBIT_E_NOMEM; }
+            if (ribbit_hip_host_alloc(cap, &p) != RIBBIT_OK) { error = "page-locked allocation failed"; return RIBBIT_E_NOMEM; }      // (huge pages + registration from 64 MB on, api_core.cpp)
             b.p = (char *)p;
         } else {
             b.p = (char *)std::malloc(cap);
@@ -60,7 +60,7 @@ struct RibbitFastaReader {
     }
     void dealloc(Buffer &b) {
         if (!b.p) return;
-        if (pinned) (void)hipHostFree(b.p); else std::free(b.p);
+        if (pinned) (void)ribbit_hip_host_free(b.p); else std::free(b.p);
         b = Buffer{};
     }
     // a buffer of at least `cap` bytes: the smallest spare one that fits, else a new one
