@@ -630,7 +630,48 @@ int ribbit_host_refine_bed(const RibbitScanParams *params, const RibbitRefinePar
     std::vector<int32_t> longest(n_dispatch);
     for (size_t i = 0; i < n_dispatch; ++i) longest[i] = rb::longest_run_host(hp, seeds[i].mlen, seeds[i].start, seeds[i].end);
     std::string bed;
-    rb::refine_to_bed(hp, sequence, *prm, seeds, longest.data(), nullptr, sequence_id, bed);
+    bool in_pieces = false;
+    if (std::getenv("RIBBIT_HOST_DEFER") != nullptr && defer_min_length() > 0 && n_dispatch) {
+        // Test hook (no GPU needed): the recursion of the long-motif seeds cut into nodes, pieces and levels exactly as the GPU
+        // path cuts it (refine.h: DeferredNode) -- nodes from RIBBIT_DEFER_MIN bases on are put off, every level is refined by
+        // this function's own host code (which may put off the next one), and the pieces are sorted into place.  The BED must
+        // not depend on any of it (tests/test_refine.py).
+        std::vector<rb::DeferredNode> nodes, next;
+        std::mutex lock;
+        std::vector<rb::BedPiece> pieces;
+        bool order_dependent = false;
+        rb::Deferral tree = make_deferral(&nodes, &lock);
+        tree.max_query = INT32_MAX; tree.max_ref = INT32_MAX;        // (no kernel to fit here)
+        rb::refine_to_bed(hp, sequence, *prm, seeds, longest.data(), nullptr, sequence_id, bed, 0, nullptr, nullptr, nullptr, 0, (size_t)-1, &order_dependent,
+                          nullptr, nullptr, nullptr, &pieces, nullptr, 0, &tree);
+        int64_t levels = 0, put_off = 0;
+        while (!order_dependent && !nodes.empty()) {
+            const size_t n = nodes.size();
+            rb::SeedVec ns(n);
+            std::vector<int32_t> nl(n), nb(n);
+            std::vector<uint32_t> all(n);
+            for (size_t i = 0; i < n; ++i) { ns[i] = RibbitSeed{nodes[i].start, nodes[i].end, nodes[i].mlen, nodes[i].type}; nl[i] = nodes[i].longest; nb[i] = nodes[i].known_row; all[i] = (uint32_t)i; }
+            next.clear();
+            rb::Deferral d = make_deferral(&next, &lock);
+            d.max_query = INT32_MAX; d.max_ref = INT32_MAX;
+            d.nodes = nodes.data();
+            // (no jobs: a level's nodes are aligned here; a node may put its own flanks off again -- not itself: it is this call's)
+            d.min_length = levels % 3 == 2 ? INT32_MAX : d.min_length;      // every third level finishes its subtrees by recursion, as the GPU path's last level does
+            std::string unused;
+            rb::refine_to_bed(hp, sequence, *prm, ns, nl.data(), nb.data(), sequence_id, unused, 0, nullptr, nullptr, nullptr, 0, n, &order_dependent,
+                              nullptr, nullptr, nullptr, &pieces, &all, 0, &d);
+            ++levels; put_off += (int64_t)n;
+            nodes.swap(next);
+        }
+        if (!order_dependent) {
+            std::sort(pieces.begin(), pieces.end(), [](const rb::BedPiece &x, const rb::BedPiece &y) {
+                return x.first_seed != y.first_seed ? x.first_seed < y.first_seed : x.path < y.path; });
+            for (const rb::BedPiece &pc : pieces) bed += pc.text;
+            in_pieces = true;
+            g_level_counts[0] += levels; g_level_counts[1] += put_off;
+        } else bed.clear();
+    }
+    if (!in_pieces) rb::refine_to_bed(hp, sequence, *prm, seeds, longest.data(), nullptr, sequence_id, bed);
     *len = bed.size();
     *text = (char *)std::malloc(bed.size() + 1);
     if (!*text) return fail(RIBBIT_E_NOMEM, "out of host memory");

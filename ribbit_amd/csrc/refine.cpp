@@ -808,7 +808,8 @@ struct Writer {
         if (longest < prm.continuous_ones_threshold) return;
         const int seq_len = usable_length(b, start, end, m);
         const int ppr_len = padded_length(seq_len, m, seq_len, prm.purity_threshold);
-        if (tree && tree->out && sink && seq_len >= tree->min_length && !(root_call && jobs) &&
+        // (not the node the caller asked for when it is a node put off earlier, or has its alignment among the GPU's jobs: it is due now)
+        if (tree && tree->out && sink && seq_len >= tree->min_length && !(root_call && (jobs || tree->nodes)) &&
             std::min(seq_len, b.L - start) <= tree->max_query && ppr_len <= tree->max_ref && start >= 0) {
             // worth a GPU batch: not done here.  What has been printed so far is a piece of its own; the node's rows will sort
             // behind it, and whatever this seed prints afterwards behind them

@@ -82,6 +82,11 @@ for min_range in (1, 16):
                 ribbit_amd.host_refine_jobs(m_lo, m_hi, seq, xa, stride, o.dispatch())
                 del os.environ["RIBBIT_DEBUG_JOB_SLICES"]
                 assert ribbit_amd.host_refine_bed(m_lo, m_hi, seq, xa, stride, o.dispatch(), "fz") == o.refine_bed("fz")
+                # the recursion cut into nodes, pieces and levels (refine.h: DeferredNode): writers on several threads hand their
+                # nodes to one list and their pieces to another
+                os.environ["RIBBIT_HOST_DEFER"] = "1"; os.environ["RIBBIT_DEFER_MIN"] = "30"
+                assert ribbit_amd.host_refine_bed(m_lo, m_hi, seq, xa, stride, o.dispatch(), "fz") == o.refine_bed("fz")
+                del os.environ["RIBBIT_HOST_DEFER"], os.environ["RIBBIT_DEFER_MIN"]
 print("host-tsan-run-ok")
 """
 

@@ -117,3 +117,38 @@ def test_consensus_rows_with_every_simd_form_give_the_same_bed():
         assert same == "True" and int(rows) > 500, r.stdout
         seen.add(digest)
     assert len(seen) == 1
+
+
+def test_the_recursion_cut_into_nodes_pieces_and_levels_gives_the_same_bed():
+    """processSeed's recursion on the flanks (parse_seed.cpp:443-463) as the GPU path cuts it -- nodes put off from a threshold
+    on, a level at a time, their rows in pieces labelled with their place in the seed's recursion tree and sorted into
+    pre-order at the end (refine.h: DeferredNode) -- run here by the host-only entry point (RIBBIT_HOST_DEFER: every level is
+    refined by host code; every third level finishes its subtrees by recursion, like the GPU path's last level): the BED is
+    the oracle's whatever the threshold, and the counters show that nodes were put off over several levels."""
+    import os
+    from fuzz import fuzz_case
+    from ribbit_amd.simulate import simulate_sequence
+    cases = [(simulate_sequence(250_000, 91, 2, 300, n_block_rate=0.2)[0], 2, 300), (simulate_sequence(150_000, 7, 2, 500, lower_rate=0.2)[0], 2, 500)]
+    cases += [fuzz_case(s) for s in (9001, 9007, 9013, 82531)] + [c[1:] for c in ALL[:6]]
+    os.environ["RIBBIT_HOST_DEFER"] = "1"
+    try:
+        deep = 0
+        for seq, m_lo, m_hi in cases:
+            with Oracle(seq, m_lo, m_hi) as o:
+                o.run_all()
+                d = o.dispatch()
+                xa, stride = ribbit_amd.pack_bit_planes([o.plane(m) for m in range(m_lo, m_hi + 1)], len(seq))
+                want = o.refine_bed("x")
+            for threshold in ("1", "60", "700"):
+                os.environ["RIBBIT_DEFER_MIN"] = threshold
+                before = ribbit_amd.level_counters()
+                got = ribbit_amd.host_refine_bed(m_lo, m_hi, seq, xa, stride, d, "x")
+                levels, nodes, _ = (b - a for a, b in zip(before, ribbit_amd.level_counters()))
+                assert got == want, (len(seq), m_lo, m_hi, threshold)
+                deep = max(deep, levels)
+                if threshold == "1" and len(seq) >= 150_000:
+                    assert nodes > 100 and levels >= 2, (levels, nodes)
+        assert deep >= 3
+    finally:
+        os.environ.pop("RIBBIT_HOST_DEFER", None)
+        os.environ.pop("RIBBIT_DEFER_MIN", None)
