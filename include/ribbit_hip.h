@@ -77,6 +77,9 @@ int ribbit_hip_abi_version(void);
 
 /* Number of usable gfx950 devices (0 if none; never initialises a device context). */
 int ribbit_hip_device_count(void);
+/* The PCI bus id of a device ("0000:c1:00.0"), e.g. to find its counters under /sys/class/drm on a host whose other GPUs belong to
+ * other jobs (tools/m500_probe.py). */
+int ribbit_hip_device_pci_bus_id(int device, char *out, size_t cap);
 
 /* Open a handle on `device`.  Replaces the globals set up in main() (ribbit.cpp:237-243). */
 int ribbit_hip_open(const RibbitScanParams *params, int device, RibbitHandle **out);

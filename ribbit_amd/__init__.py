@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_subst_calls", "ribbit_hip_seeds_substitutions",
     "ribbit_host_replay_calls", "ribbit_seed_lists_free", "ribbit_host_longest_runs", "ribbit_debug_set_merge_min_range", "ribbit_debug_last_merge",
     "ribbit_hip_small_motifs", "ribbit_debug_small_motif_counters", "ribbit_debug_last_dispatch_ranges", "ribbit_debug_alignment_counters", "ribbit_debug_level_counters",
-    "ribbit_hip_adopt_dispatch", "ribbit_hip_refine_met_empty_query",
+    "ribbit_hip_adopt_dispatch", "ribbit_hip_refine_met_empty_query", "ribbit_hip_device_pci_bus_id",
     "ribbit_hip_anchored_calls", "ribbit_hip_seeds_anchored", "ribbit_hip_dispatch_seeds", "ribbit_hip_guard_hits",
     "ribbit_hip_debug_stream_read",
     "ribbit_refine_params_default", "ribbit_hip_seed_longest_runs", "ribbit_hip_refine_jobs",
@@ -186,6 +186,7 @@ def load_library():
     L.ribbit_debug_last_dispatch_ranges.argtypes = []
     L.ribbit_debug_alignment_counters.restype = None
     L.ribbit_debug_alignment_counters.argtypes = [C.POINTER(C.c_int64 * 3)]
+    L.ribbit_hip_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     L.ribbit_hip_adopt_dispatch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.ribbit_hip_refine_met_empty_query.argtypes = [C.c_void_p]
     L.ribbit_debug_level_counters.restype = None

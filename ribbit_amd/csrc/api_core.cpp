@@ -176,6 +176,12 @@ int ribbit_hip_device_count(void) {
     return ok;
 }
 
+int ribbit_hip_device_pci_bus_id(int device, char *out, size_t cap) {
+    if (!out || cap < 16) return fail(RIBBIT_E_ARG, "bad argument");
+    HIP_TRY(hipDeviceGetPCIBusId(out, (int)cap, device));
+    return RIBBIT_OK;
+}
+
 int ribbit_hip_open(const RibbitScanParams *params, int device, RibbitHandle **out) {
     if (!params || !out) return fail(RIBBIT_E_ARG, "null argument");
     *out = nullptr;

@@ -55,6 +55,10 @@ struct DevBuf {
     int ensure(size_t n) {
         if (n <= cap) return RIBBIT_OK;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        // RIBBIT_PROFILE_MEMORY=<MB>: one line per device allocation of at least that size (which buffers are large, and when)
+        static const size_t trace_from = std::getenv("RIBBIT_PROFILE_MEMORY") ? (size_t)std::max(1, std::atoi(std::getenv("RIBBIT_PROFILE_MEMORY"))) << 20 : 0;
+        if (trace_from && n * sizeof(T) >= trace_from)
+            std::fprintf(stderr, "[device memory] %.2f GB (%zu elements of %zu bytes), called from %p\n", (double)(n * sizeof(T)) * 1e-9, n, sizeof(T), __builtin_return_address(0));
         hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
         if (e != hipSuccess) { p = nullptr; return fail(RIBBIT_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e)); }
         cap = n;

@@ -474,6 +474,12 @@ int main(int argc, char **argv) {
     for (size_t j = 1; j < handles.size(); ++j) ribbit_hip_close(handles[j]);
     ribbit_hip_close(h);
     if (reader) ribbit_fasta_close(reader);
+    if (std::getenv("RIBBIT_PROFILE")) {
+        char bus[64] = {0};
+        for (int d = 0; d < ndev; ++d)
+            if (ribbit_hip_device_pci_bus_id(devices[(size_t)d], bus, sizeof bus) == RIBBIT_OK)
+                std::cerr << "[devices] slot " << d << " is GPU " << devices[(size_t)d] << " at PCI " << bus << "\n";
+    }
     if (std::getenv("RIBBIT_PROFILE") && ndev > 1)
         for (int d = 0; d < ndev; ++d)
             std::cerr << "[devices] slot " << d << " (GPU " << devices[(size_t)d] << "): " << dev_records[(size_t)d] << " records, " << dev_bases[(size_t)d] << " bases\n";

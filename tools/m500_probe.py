@@ -62,8 +62,8 @@ def make_reads(args):
 
 
 class VramPeak:
-    """per card: used memory before the run and its peak during it (the box may show other tenants' cards: the card that GREW
-    the most is taken to be ours)"""
+    """per card of the host: used memory before the run and its peak during it.  The other cards belong to other jobs, so the figures
+    reported are those of the card ribbit-hip says it ran on (its "[devices] slot 0 is GPU n at PCI ..." line under RIBBIT_PROFILE)."""
     def __init__(self):
         self.files = glob.glob("/sys/class/drm/card*/device/mem_info_vram_used")
         self.stop = False
@@ -84,19 +84,23 @@ class VramPeak:
                 self.top[f] = max(self.top[f], self.read(f))
             time.sleep(0.05)
 
-    @property
-    def grown(self):
-        return max((self.top[f] - self.before[f] for f in self.files), default=0)
+    def card_of(self, pci: str):
+        for f in self.files:
+            try:
+                if os.path.basename(os.path.realpath(os.path.dirname(f))).lower() == pci.lower():
+                    return f
+            except OSError:
+                pass
+        return None
 
-    @property
-    def peak(self):
-        f = max(self.files, key=lambda f: self.top[f] - self.before[f], default=None)
-        return self.top[f] if f else 0
-
-    @property
-    def base(self):
-        f = max(self.files, key=lambda f: self.top[f] - self.before[f], default=None)
-        return self.before[f] if f else 0
+    def report(self, stderr_text: str) -> dict:
+        import re
+        m = re.search(r"\[devices\] slot 0 is GPU \d+ at PCI (\S+)", stderr_text)
+        f = self.card_of(m.group(1)) if m else None
+        if f is None:
+            return {"peak_vram_gb": None, "vram_note": "the run's card was not identified among the host's cards"}
+        return {"peak_vram_gb": round(self.top[f] / 1e9, 2), "vram_before_gb": round(self.before[f] / 1e9, 2),
+                "vram_grown_gb": round((self.top[f] - self.before[f]) / 1e9, 2), "card": m.group(1)}
 
 
 def main():
@@ -156,7 +160,7 @@ def main():
     tail = [l for l in err.splitlines() if l.startswith("[stages") or l.startswith("[devices]") or l.startswith("[refine_bed] cumulative")]
     print(json.dumps({"workload": f"{a.mode}: {records} record(s), -m 2 -M {a.M}", "bases": total, "records": records, "wall_s": round(wall, 3),
                       "mbases_per_s": round(total / wall / 1e6, 3), "records_per_s": round(records / wall, 2), "bed_rows": rows,
-                      "peak_vram_gb": round(vram.peak / 1e9, 2), "vram_before_gb": round(vram.base / 1e9, 2), "vram_grown_gb": round(vram.grown / 1e9, 2), "peak_host_rss_gb": round(rss_kb / 1e6, 2),
+                      **vram.report(err), "peak_host_rss_gb": round(rss_kb / 1e6, 2),
                       "generate_s": round(t_gen, 1), "jobs": a.jobs or "auto", "profile": tail[-3:]}), flush=True)
     if not a.keep:
         os.remove(fasta); os.remove(bed)
