@@ -145,11 +145,12 @@ int ribbit_hip_seeds_substitutions(RibbitHandle *h, const RibbitSeed **perfect, 
 
 /*
  * The addSeedToSeedPositionsAnchored calls processShiftXORsAnchored would make
- * (parse_anchored_shiftxor.cpp:580-723), in its call order.  Runs the fused anchored kernel:
- * generateAnchoredShiftXORs (parse_anchored_shiftxor.h:10, called at fasta_utils.cpp:144), the plane
- * composition of fasta_utils.cpp:146-160 and the 6-of-8 window scan.  After this call "plane m"
- * means the composed plane for every motif length m (as in the reference, fasta_utils.cpp:159).
- * Motif sizes up to 990 (the anchored kernel widens its per-wave halo with max_motif).
+ * (parse_anchored_shiftxor.cpp:580-723), in its call order.  Runs the anchored stage's two kernels: the planes
+ * kernel -- generateAnchoredShiftXORs (parse_anchored_shiftxor.h:10, called at fasta_utils.cpp:144) and the plane
+ * composition of fasta_utils.cpp:146-160, written to device memory -- and the 6-of-8 window scan of those planes,
+ * then the window state machine on the device.  After this call "plane m" means the composed plane for every motif
+ * length m (as in the reference, fasta_utils.cpp:159).  Motif sizes up to 990 (the planes kernel widens its per-wave
+ * halo with max_motif).
  */
 int ribbit_hip_anchored_calls(RibbitHandle *h, const RibbitCall **out, size_t *n);
 
@@ -330,8 +331,8 @@ const char *ribbit_fasta_last_error(void);
 int64_t ribbit_hip_guard_hits(const RibbitHandle *h);
 
 /*
- * Bits [start, end) of shift plane `shift` (X_shift, or the anchored plane once
- * ribbit_hip_anchor_planes has run), one byte per base.  Replaces reads of
+ * Bits [start, end) of shift plane `shift` (X_shift; for a motif length, the composed plane XA_shift once the anchored
+ * stage has run on this record -- ribbit_hip_anchored_calls / ribbit_hip_seeds_anchored), one byte per base.  Replaces reads of
  * lshift_xor_bsets[shift-MINIMUM_SHIFT][L-1-p] (fasta_utils.cpp:220-222, parse_seed.cpp:366).
  */
 int ribbit_hip_plane_bits(RibbitHandle *h, int32_t shift, int64_t start, int64_t end, uint8_t *out);
