@@ -46,6 +46,7 @@ struct Options {
     int device = 0;
     std::vector<int> devices;                     // --devices / RIBBIT_DEVICES: GPUs the records are dealt over (empty: `device` alone)
     int jobs = 0;                                 // records in flight PER DEVICE; 0 = automatic
+    std::string timing;                           // --timing FILE: a JSON record of the run (the reference has cerr progress lines only)
 };
 
 const char *kHelp =
@@ -65,7 +66,9 @@ const char *kHelp =
     "  --device arg                  (ribbit-hip) GPU ordinal. Default: 0\n"
     "  --devices arg                 (ribbit-hip) GPU ordinals, comma separated (or RIBBIT_DEVICES): the records of the\n"
     "                                FASTA are dealt over these GPUs, the longest of the look-ahead first; BED rows\n"
-    "                                keep the input order\n";
+    "                                keep the input order\n"
+    "  --timing arg                  (ribbit-hip) write a JSON record of the run to this file: records, bases, wall time and\n"
+    "                                the wall time per stage summed over the records\n";
 
 [[noreturn]] void die(const std::string &msg) {        // argument errors: main thread, before any worker exists
     std::cerr << "ribbit-hip: " << msg << "\n";
@@ -93,7 +96,7 @@ bool parse_device_list(const std::string &value, std::vector<int> &out) {
 int parse_arguments(int argc, char **argv, Options &o) {
     static const std::map<std::string, std::string> longs = {
         {"help", "h"}, {"input-file", "i"}, {"output-file", "o"}, {"min-motif-length", "m"}, {"max-motif-length", "M"},
-        {"purity", "p"}, {"min-length", "l"}, {"min-units", "U"}, {"perfect-units", "P"}, {"device", "D"}, {"jobs", "J"}, {"devices", "G"}};
+        {"purity", "p"}, {"min-length", "l"}, {"min-units", "U"}, {"perfect-units", "P"}, {"device", "D"}, {"jobs", "J"}, {"devices", "G"}, {"timing", "T"}};
     bool help = false;
     for (int a = 1; a < argc; ++a) {
         std::string arg = argv[a], key, value;
@@ -127,6 +130,7 @@ int parse_arguments(int argc, char **argv, Options &o) {
         else if (key == "P") { o.has_perfect_units = true; o.perfect_units = value; }
         else if (key == "D") o.device = std::atoi(value.c_str());
         else if (key == "J") o.jobs = std::atoi(value.c_str());
+        else if (key == "T") o.timing = value;
         else if (key == "G") { if (!parse_device_list(value, o.devices)) die("--devices wants a comma separated list of GPU ordinals, got '" + value + "'"); }
     }
     if (help) { std::cerr << kHelp << "\n"; return 0; }                       // ribbit.cpp:114-117
@@ -296,6 +300,7 @@ int main(int argc, char **argv) {
     if (!opt.out.empty()) file.open(opt.out);
     std::ostream &out = opt.out.empty() ? std::cerr : file;                   // ribbit.cpp:199-205
 
+    const auto t_run0 = std::chrono::steady_clock::now();
     RibbitRefineParams prm;
     build_refine_params(opt, prm);
     std::cerr << "Minimum motif:\t" << opt.min_motif << "\n";
@@ -483,6 +488,17 @@ int main(int argc, char **argv) {
     if (std::getenv("RIBBIT_PROFILE") && ndev > 1)
         for (int d = 0; d < ndev; ++d)
             std::cerr << "[devices] slot " << d << " (GPU " << devices[(size_t)d] << "): " << dev_records[(size_t)d] << " records, " << dev_bases[(size_t)d] << " bases\n";
+    if (!opt.timing.empty()) {
+        // (stage times are wall clock per record, summed: with several records in flight their sum exceeds the run's wall time)
+        std::ofstream tf(opt.timing);
+        const double wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run0).count();
+        int64_t total_bases = last_length;
+        for (int d = 0; d < ndev; ++d) total_bases += dev_bases[(size_t)d];
+        tf << "{\"records\": " << n_records + 1 << ", \"bases\": " << total_bases << ", \"wall_s\": " << wall_s << ", \"status\": " << status
+           << ", \"min_motif\": " << opt.min_motif << ", \"max_motif\": " << opt.max_motif << ", \"devices\": " << ndev << ", \"jobs_per_device\": " << jobs
+           << ", \"stage_ms_summed_over_records\": {\"load\": " << g_stage_ms[0] << ", \"perfect\": " << g_stage_ms[1] << ", \"substitutions\": " << g_stage_ms[2]
+           << ", \"anchored\": " << g_stage_ms[3] << ", \"dispatch\": " << g_stage_ms[4] << ", \"refine_and_bed\": " << g_stage_ms[5] << "}}\n";
+    }
     if (std::getenv("RIBBIT_PROFILE"))
         std::cerr << "[stages, ms over all records] load " << g_stage_ms[0] << "  perfect " << g_stage_ms[1] << "  substitutions "
                   << g_stage_ms[2] << "  anchored " << g_stage_ms[3] << "  dispatch " << g_stage_ms[4] << "  refine+BED " << g_stage_ms[5] << "\n";

@@ -288,8 +288,15 @@ def test_cli_one_record_refined_over_several_devices(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert bed.read_text() == want
     assert "in 3 slices over as many handles" in r.stderr, r.stderr[-1500:]
-    r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed1), "-m", "2", "-M", "100"], capture_output=True, text=True, timeout=900)
+    timing = tmp_path / "timing.json"
+    r = subprocess.run([BIN, "-i", str(fa), "-o", str(bed1), "-m", "2", "-M", "100", "--timing", str(timing)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and bed1.read_text() == want
+    # --timing: a JSON record of the run (the reference has progress lines on stderr only)
+    import json
+    t = json.loads(timing.read_text())
+    assert t["records"] == 1 and t["bases"] == 110_000 and t["status"] == 0 and t["wall_s"] > 0
+    assert set(t["stage_ms_summed_over_records"]) == {"load", "perfect", "substitutions", "anchored", "dispatch", "refine_and_bed"}
+    assert t["stage_ms_summed_over_records"]["refine_and_bed"] > 0
     # several records: only the last one (processed when the others are done and the GPUs idle) is dealt that way
     records = [("first", seq[:40_000]), ("second", seq[40_000:90_000]), ("third and last", seq[90_000:200_000])]
     write_fasta(str(fa), records)
