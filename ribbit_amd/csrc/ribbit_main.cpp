@@ -483,7 +483,7 @@ int main(int argc, char **argv) {
         char bus[64] = {0};
         for (int d = 0; d < ndev; ++d)
             if (ribbit_hip_device_pci_bus_id(devices[(size_t)d], bus, sizeof bus) == RIBBIT_OK)
-                std::cerr << "[devices] slot " << d << " is GPU " << devices[(size_t)d] << " at PCI " << bus << "\n";
+                std::cerr << "[device] slot " << d << " is GPU " << devices[(size_t)d] << " at PCI " << bus << "\n";
     }
     if (std::getenv("RIBBIT_PROFILE") && ndev > 1)
         for (int d = 0; d < ndev; ++d)

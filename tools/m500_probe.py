@@ -63,7 +63,7 @@ def make_reads(args):
 
 class VramPeak:
     """per card of the host: used memory before the run and its peak during it.  The other cards belong to other jobs, so the figures
-    reported are those of the card ribbit-hip says it ran on (its "[devices] slot 0 is GPU n at PCI ..." line under RIBBIT_PROFILE)."""
+    reported are those of the card ribbit-hip says it ran on (its "[device] slot 0 is GPU n at PCI ..." line under RIBBIT_PROFILE)."""
     def __init__(self):
         self.files = glob.glob("/sys/class/drm/card*/device/mem_info_vram_used")
         self.stop = False
