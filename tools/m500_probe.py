@@ -95,7 +95,7 @@ class VramPeak:
 
     def report(self, stderr_text: str) -> dict:
         import re
-        m = re.search(r"\[devices\] slot 0 is GPU \d+ at PCI (\S+)", stderr_text)
+        m = re.search(r"\[device\] slot 0 is GPU \d+ at PCI (\S+)", stderr_text)
         f = self.card_of(m.group(1)) if m else None
         if f is None:
             return {"peak_vram_gb": None, "vram_note": "the run's card was not identified among the host's cards"}
