@@ -12,6 +12,8 @@ Next to that line's headline (configs[1]) rank 0 of an N = 1 run also reports, i
                     uploads double-buffered against the previous batch's kernels): SURVEY.md 8(d)'s clock
   pack_hbm          pack_kernel over a rotating working set larger than the 256 MiB Infinity Cache
   full_path_sample  10 Mbp of the workload through the whole path, beside the CPU oracle on 1 Mbp
+  m500_full_path    BASELINE.json configs[4]'s motif range (-m 2 -M 500) on a 16-Mbp record, FASTA record -> BED text, checked against
+                    the oracle pipeline's committed digest
   chr1_full_path    BASELINE.json configs[2]'s largest record: one chromosome-1-sized record (248,956,422 bp, generator
                     seed 4, N blocks) through perfect + substitution + anchored scans, merges, dispatch, refinement
                     and BED text, with per-kernel times and a roofline block for each scan kernel
@@ -191,6 +193,45 @@ def verify_chr1_digest(bases: int, bed_rows: int, bed_sha: str) -> dict:
                                              "what": "SHA-256 and row count of the whole BED text == the CPU oracle pipeline's for the same 248,956,422-base record "
                                                      "(tests/golden/grch38_shape_digests.json, made by tests/golden/make_full_size_digests.py; the oracle is a "
                                                      "restatement of the reference: parity unpinned, DESIGN.md 2)"}}
+
+
+def m500_full_path(ribbit_amd, bases: int, device: int):
+    """BASELINE.json configs[4]'s motif range as stated (-m 2 -M 500: 499 composed planes, motifs beyond 128 bases) on a bounded record,
+    through the whole path to the BED text, checked against the oracle pipeline's committed digest (tests/golden/
+    grch38_shape_digests.json, entry "m500": 16 Mbp, 6.5 minutes of one core in the build container).  One pass, outside the headline."""
+    import hashlib
+    import numpy as np
+    from ribbit_amd.simulate import m500_record
+    seq = m500_record(bases)
+    with ribbit_amd.Scanner(2, 500, device=device) as sc:
+        t0 = time.perf_counter()
+        sc.load_record(seq)
+        sc.processShiftXORsAnchored(copy=False)
+        dispatch = sc.dispatch_seeds(copy=False)
+        t1 = time.perf_counter()
+        bed = sc.refine_bed_view("m500")
+        t2 = time.perf_counter()
+        rows = int(np.count_nonzero(bed == ord("\n")))
+        sha = hashlib.sha256(np.ascontiguousarray(bed)).hexdigest()
+        n_dispatch = int(len(dispatch))
+        del bed
+    out = {"bases": bases, "min_motif": 2, "max_motif": 500, "seconds": t2 - t0, "value": bases / (t2 - t0) / 1e9, "unit": "Gbases/s",
+           "scans_and_merges_s": t1 - t0, "refinement_and_bed_s": t2 - t1, "dispatched": n_dispatch, "bed_rows": rows, "bed_sha256": sha,
+           "what": "one record at BASELINE.json configs[4]'s motif range, FASTA record -> BED text, first use of the handle (allocations included)"}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "grch38_shape_digests.json")
+    try:
+        want = json.load(open(path))["m500"]
+    except (OSError, KeyError, ValueError) as e:
+        out.update({"verified": None, "verification": {"what": f"no digest available ({type(e).__name__})"}})
+        return out
+    if want["bases"] != bases:
+        out.update({"verified": None, "verification": {"what": f"the committed digest is for {want['bases']} bases; this run: {bases}"}})
+        return out
+    out.update({"verified": bool(want["sha256"] == sha and want["bed_rows"] == rows),
+                "verification": {"bed_sha256_oracle": want["sha256"], "bed_rows_oracle": want["bed_rows"], "oracle_seconds_one_core": want["oracle_seconds"],
+                                 "what": "SHA-256 and row count of the BED text == the CPU oracle pipeline's for the same record at -m 2 -M 500 "
+                                         "(tests/golden/grch38_shape_digests.json: m500; parity unpinned, DESIGN.md 2)"}})
+    return out
 
 
 def chr1_full_path(ribbit_amd, bases: int, device: int, traffic: dict):
@@ -435,6 +476,8 @@ def main():
                     help="after the timed region, launch the known-byte-count stream-read kernel (for PMC passes)")
     ap.add_argument("--chr1-bases", type=int, default=CHR1_BASES,
                     help="size of the BASELINE configs[2] record of the chr1_full_path leg (0 = skip the leg)")
+    ap.add_argument("--m500-bases", type=int, default=16_000_000,
+                    help="size of the -M 500 record of the m500_full_path leg (BASELINE configs[4]'s motif range; 0 = skip the leg)")
     ap.add_argument("--max-motif", type=int, default=M_HI,
                     help="-M of the run (default: BASELINE configs[1]'s 100).  Anything else is a profiling run -- tools/profile_bench.sh "
                          "with 500 for configs[4]'s motif range -- and its line says so in config.workload; the headline is quoted at the default")
@@ -810,6 +853,10 @@ def main():
                 for h in scs[1:]:
                     h.close()                     # their buffers are not needed any more; the chr1 record wants the room
                 out["chr1_full_path"] = chr1_full_path(ribbit_amd, args.chr1_bases, local_rank, prof)
+            if args.m500_bases > 0 and M_HI == 100:
+                for h in scs[1:]:
+                    h.close()
+                out["m500_full_path"] = m500_full_path(ribbit_amd, args.m500_bases, local_rank)
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
 

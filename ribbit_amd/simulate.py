@@ -202,3 +202,10 @@ def grch38_shaped_record(k: int, bases: int | None = None, m_lo: int = 2, m_hi: 
     cen = min(3_000_000, bases // 50)
     b[bases // 2:bases // 2 + cen] = ord("N")
     return b.tobytes()
+
+
+def m500_record(bases: int) -> bytes:
+    """BASELINE.json configs[4]'s motif range on one record: generator motifs 2..500, blocks of N and lower-case loci (seed 77).  One
+    definition for tests/test_m500_gpu.py, bench.py's `m500_full_path` leg and the digest under tests/golden/."""
+    seq, _ = simulate_sequence(bases, 77, 2, 500, n_block_rate=0.1, lower_rate=0.1)
+    return seq

@@ -38,8 +38,27 @@ def one_record(k: int, scale: float):
             "bed_rows": bed.count(b"\n"), "bed_bytes": len(bed), "sha256": hashlib.sha256(bed).hexdigest(), "oracle_seconds": round(time.time() - t0, 1)}
 
 
+def m500_digest(bases: int, out: str):
+    """the oracle pipeline on ribbit_amd.simulate.m500_record(bases) at -m 2 -M 500 (~25 s per Mbp on one core here) -> entry
+    "m500" of the digest file: what bench.py's `m500_full_path` leg checks its BED against"""
+    from oracle_lib import Oracle
+    from ribbit_amd.simulate import m500_record
+    seq = m500_record(bases)
+    t0 = time.time()
+    with Oracle(seq, 2, 500) as o:
+        o.run_all()
+        bed = o.refine_bed_bytes("m500")
+    have = json.load(open(out)) if os.path.exists(out) else {}
+    have["m500"] = {"bases": bases, "generator_seed": 77, "m_lo": 2, "m_hi": 500, "bed_rows": bed.count(b"\n"), "bed_bytes": len(bed),
+                    "sha256": hashlib.sha256(bed).hexdigest(), "oracle_seconds": round(time.time() - t0, 1), "sequence_id": "m500"}
+    json.dump(have, open(out + ".tmp", "w"), indent=1, sort_keys=True)
+    os.replace(out + ".tmp", out)
+    print(have["m500"], flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--m500", type=int, default=0, help="instead of the set: the -M 500 record of this many bases (bench.py uses 16000000)")
     ap.add_argument("--records", default="all")
     ap.add_argument("--budget-gb", type=float, default=40.0)
     ap.add_argument("--max-workers", type=int, default=max(1, (os.cpu_count() or 2) - 2))
@@ -47,6 +66,9 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "grch38_shape_digests.json"))
     ap.add_argument("--one", type=int, default=-1, help=argparse.SUPPRESS)       # worker mode: one record, JSON on stdout
     a = ap.parse_args()
+    if a.m500:
+        m500_digest(a.m500, a.out)
+        return
     if a.one >= 0:
         print(json.dumps(one_record(a.one, a.scale)), flush=True)
         return

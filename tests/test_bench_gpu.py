@@ -19,8 +19,8 @@ def _line(out):
 
 
 def test_single_gpu_line_has_the_contracted_fields():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--bases", "3000000", "--chr1-bases", "4000000"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--bases", "3000000", "--chr1-bases", "4000000",
+                        "--m500-bases", "1000000"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -45,7 +45,11 @@ def test_single_gpu_line_has_the_contracted_fields():
     assert pi["unit"] == "Gbases/s" and 0 < pi["value"] < 60 and pi["h2d_bytes_per_step"] == 3_000_000     # 1 B/base over PCIe bounds it
     ph = d["pack_hbm"]
     assert ph["kernel"] == "pack_kernel" and 0 < ph["frac"] < 1 and ph["working_set_bytes"] == 8 * 3_000_000
+    # BASELINE.json configs[4]'s motif range on a bounded record (no digest for this size: `verified` is null, the leg itself must run)
+    m5 = d["m500_full_path"]
+    assert m5["bases"] == 1_000_000 and m5["max_motif"] == 500 and m5["bed_rows"] > 1000 and m5["verified"] is None and len(m5["bed_sha256"]) == 64
     c1 = d["chr1_full_path"]
+    assert c1["verified"] is None          # (4 Mbp: the committed digest is for the full 248,956,422 bases)
     assert c1["bases"] == 4_000_000 and c1["bed_rows"] > 1000 and c1["seeds"]["anchored"] > 0 and len(c1["passes"]) == 2
     for k in ("scan_window_kernel<1>", "scan_anchored_kernel", "scan_perfect_kernel"):
         rf2 = c1["roofline"][k]

@@ -21,9 +21,8 @@ M_LO, M_HI = 2, 500
 
 
 def m500_record(bases: int) -> bytes:
-    from ribbit_amd.simulate import simulate_sequence
-    seq, _ = simulate_sequence(bases, 77, M_LO, M_HI, n_block_rate=0.1, lower_rate=0.1)
-    return seq
+    from ribbit_amd.simulate import m500_record as record
+    return record(bases)
 
 
 def _digest(a) -> str:
