@@ -230,10 +230,13 @@ bool refine_over_devices(RibbitHandle *h, const std::vector<Helper> &helpers, co
         text[k].assign(t, len);
         empty_query[k] = ribbit_hip_refine_met_empty_query(hk);
     };
+    for (const Helper &hp : helpers) check(ribbit_hip_set_host_threads(hp.h, hp.host_threads));      // (anything that can throw: before the first thread exists)
     std::vector<std::thread> pool;
-    for (size_t k = 1; k < parts; ++k) {
-        check(ribbit_hip_set_host_threads(helpers[k - 1].h, helpers[k - 1].host_threads));
-        pool.emplace_back(slice, k, helpers[k - 1].h, true);
+    pool.reserve(parts);
+    try {
+        for (size_t k = 1; k < parts; ++k) pool.emplace_back(slice, k, helpers[k - 1].h, true);
+    } catch (...) {            // a thread that could not start: its slice and the ones after it run here, one after the other
+        for (size_t k = pool.size() + 1; k < parts; ++k) slice(k, helpers[k - 1].h, true);
     }
     slice(0, h, false);
     for (std::thread &t : pool) t.join();
