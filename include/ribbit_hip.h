@@ -516,6 +516,13 @@ void ribbit_debug_set_merge_min_range(size_t calls);
  * | range runs of the anchored stage's parallel passes, all passes together << 1,
  * list-head writes that changed an entry, first range empty (0/1) | parallel passes of the stage << 8}. */
 void ribbit_debug_last_merge(int stage, int32_t out[5]);
+/* Test hook: the anchored stage's merge runs its first parallel pass on the GPU for stages of 2^20 kept calls and more
+ * (anchored_merge.hip: one lane per range of some 64 calls, the host threads taking the ranges of more than 192 calls meanwhile;
+ * environment RIBBIT_DEVICE_MERGE_MIN / RIBBIT_DEVICE_MERGE_RANGE / RIBBIT_DEVICE_MERGE_MAX_CALLS change the three numbers).
+ * out = {ranges the device merged, ranges it was given but left to the host threads (candidate lists beyond its LDS, budget of
+ * passes), ranges the host threads merged meanwhile, ranges of the stage, ranges merged again by the validation walk} of the
+ * calling thread's last anchored merge; the first three are zero when the device pass did not run. */
+void ribbit_debug_last_device_merge(int32_t out[5]);
 /* Test hook: in how many independent ranges the calling thread's last dispatch merge (fasta_utils.cpp:187-224) ran; 1 = the
  * sequential merge (no cuts, or a list did not split cleanly at them). */
 int32_t ribbit_debug_last_dispatch_ranges(void);

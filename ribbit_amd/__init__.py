@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "ribbit_hip_last_timing_ms", "ribbit_hip_last_event_count",
     "ribbit_hip_subst_calls", "ribbit_hip_seeds_substitutions",
     "ribbit_host_replay_calls", "ribbit_seed_lists_free", "ribbit_host_longest_runs", "ribbit_debug_set_merge_min_range", "ribbit_debug_last_merge",
-    "ribbit_hip_small_motifs", "ribbit_debug_small_motif_counters", "ribbit_debug_last_dispatch_ranges", "ribbit_debug_alignment_counters", "ribbit_debug_level_counters",
+    "ribbit_hip_small_motifs", "ribbit_debug_small_motif_counters", "ribbit_debug_last_dispatch_ranges", "ribbit_debug_last_device_merge", "ribbit_debug_alignment_counters", "ribbit_debug_level_counters",
     "ribbit_hip_adopt_dispatch", "ribbit_hip_refine_met_empty_query", "ribbit_hip_device_pci_bus_id",
     "ribbit_hip_anchored_calls", "ribbit_hip_seeds_anchored", "ribbit_hip_dispatch_seeds", "ribbit_hip_guard_hits",
     "ribbit_hip_debug_stream_read",
@@ -182,6 +182,8 @@ def load_library():
     L.ribbit_seed_lists_free.argtypes = [C.POINTER(SeedLists)]
     L.ribbit_debug_last_merge.restype = None
     L.ribbit_debug_last_merge.argtypes = [C.c_int, C.POINTER(C.c_int32 * 5)]
+    L.ribbit_debug_last_device_merge.restype = None
+    L.ribbit_debug_last_device_merge.argtypes = [C.POINTER(C.c_int32 * 5)]
     L.ribbit_debug_last_dispatch_ranges.restype = C.c_int32
     L.ribbit_debug_last_dispatch_ranges.argtypes = []
     L.ribbit_debug_alignment_counters.restype = None
@@ -414,6 +416,16 @@ def level_counters():
     out = (C.c_int64 * 3)()
     L.ribbit_debug_level_counters(C.byref(out))
     return int(out[0]), int(out[1]), int(out[2])
+
+
+def last_device_merge():
+    """(ranges the GPU merged, ranges it was given but left to the host threads, ranges the host threads merged while its kernel
+    ran, ranges of the stage, ranges merged again by the validation walk) of the calling thread's last anchored-stage merge; the
+    first three are zero when the merge ran on the host threads alone"""
+    L = load_library()
+    out = (C.c_int32 * 5)()
+    L.ribbit_debug_last_device_merge(C.byref(out))
+    return tuple(int(v) for v in out)
 
 
 def small_motif_counters():

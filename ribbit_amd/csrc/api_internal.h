@@ -174,6 +174,20 @@ struct RibbitHandle {
     PinnedBuf<int32_t> h_pend_[2];
     PinnedBuf<uint32_t> h_ws_[2];
     PinnedBuf<uint32_t> h_xa;          // host copy of the composed planes (rb::HostPlanes::xa_view points here)
+    // the anchored stage's merge as device work (api_merge.cpp, anchored_merge.hip): the lists, the ranges and what they leave
+    struct MergeBufs {
+        DevBuf<RibbitSeed> d_perfect, d_subst, d_own;
+        DevBuf<int32_t> d_type0, d_cuts;                // types before the stage (perfect then substitution list); cut_pos | cur0
+        DevBuf<uint32_t> d_first, d_range_out, d_log, d_head_log, d_counts, d_scratch;
+        PinnedBuf<RibbitSeed> h_own;
+        PinnedBuf<uint32_t> h_range_out, h_log, h_head_log, h_counts, h_sync;      // h_sync: read and written by the lanes while the kernel runs
+        uint32_t *h_sync_dev = nullptr;
+        void release() {
+            d_perfect.release(); d_subst.release(); d_own.release(); d_type0.release(); d_cuts.release(); d_first.release(); d_range_out.release();
+            d_log.release(); d_head_log.release(); d_counts.release(); d_scratch.release();
+            h_own.release(); h_range_out.release(); h_log.release(); h_head_log.release(); h_counts.release(); h_sync.release(); h_sync_dev = nullptr;
+        }
+    } mg;
     hipEvent_t ev_xa = nullptr;        // the copy of the composed planes has landed
     hipEvent_t ev_ssw = nullptr;       // orders the longest alignment class (on the copy stream) against the compute stream
     bool xa_copy_pending = false;
@@ -280,6 +294,9 @@ int window_stage_device(RibbitHandle *h, int which, bool full, int (*min_span)(i
 void full_calls_from_device(const DeviceCalls &dc, rb::CallVec &calls);
 int build_subst_calls(RibbitHandle *h);
 void subst_merge(RibbitHandle *h, const DeviceCalls *dc);
+// api_merge.cpp: the first parallel pass of the anchored stage's merge on the device (d_calls / d_pend: the stage's kept calls as
+// window_stage_device left them in device memory, d_pend null when kc.pend is)
+rb::AnchoredDevicePass anchored_device_pass(RibbitHandle *h, RibbitCall *d_calls, const int32_t *d_pend);
 int advance_to_subst(RibbitHandle *h);
 int prepare_anchored(RibbitHandle *h);
 int xa_copy_begin(RibbitHandle *h);

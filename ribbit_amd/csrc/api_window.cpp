@@ -372,10 +372,10 @@ int build_anchored_calls(RibbitHandle *h) {
 // either host merge starts, so the copies (kept calls, composed planes) travel while the host merges.
 // RIBBIT_PROFILE line of the anchored stage's merge (GPU path and host replay alike)
 void print_anchored_merge_profile(size_t seeds, const rb::MergeStats &st, double dispatch_ms, unsigned dispatch_ranges) {
-    std::fprintf(stderr, "[anchored merge] %zu seeds: %u ranges on %u threads%s, %u passes, %lld changing head writes, %u ranges done again, preparation %.1f ms, merges %.1f ms "
-                 "(parallel passes %.1f ms over %u range runs: the ranges' own times sum to %.1f ms = %.1f ms per thread, longest range %.1f ms; in-order walk %.1f ms; joining the ranges' lists %.1f ms; before the first pass %.1f ms; end-of-sequence calls %.1f ms), dispatch order %.1f ms in %u ranges\n",
+    std::fprintf(stderr, "[anchored merge] %zu seeds: %u ranges on %u threads%s, %u passes, %lld changing head writes, %u ranges done again, preparation %.1f ms (cuts %.1f, cursors %.1f, type snapshots %.1f), merges %.1f ms "
+                 "(parallel passes %.1f ms over %u range runs [device pass %.1f ms for %u ranges, the host threads' share meanwhile: %u ranges in %.1f ms; results into the ranges' states %.1f ms; then %u ranges the device left]: the ranges' own times sum to %.1f ms = %.1f ms per thread, longest range %.1f ms; in-order walk %.1f ms; joining the ranges' lists %.1f ms; before the first pass %.1f ms; end-of-sequence calls %.1f ms), dispatch order %.1f ms in %u ranges\n",
                  seeds, st.ranges, st.threads, st.redone_in_order ? " (REDONE IN ORDER)" : (st.head_writes ? " (list-head writes: ranges done again, see passes)" : ""), st.passes, st.head_writes,
-                 st.ranges_redone, st.prepare_ms, st.merge_ms, st.pass_ms, st.ranges_run, st.range_ms_sum, st.range_ms_sum / std::max(1u, st.threads), st.range_ms_max, st.walk_ms, st.concat_ms, st.before_passes_ms, st.flush_ms, dispatch_ms, dispatch_ranges);
+                 st.ranges_redone, st.prepare_ms, st.prep_parts[0], st.prep_parts[1] - st.prep_parts[0], st.prep_parts[2] - st.prep_parts[1], st.merge_ms, st.pass_ms, st.ranges_run, st.device_ms, st.device_ranges, st.device_host_share, st.device_meanwhile_ms, st.device_apply_ms, st.device_bailed, st.range_ms_sum, st.range_ms_sum / std::max(1u, st.threads), st.range_ms_max, st.walk_ms, st.concat_ms, st.before_passes_ms, st.flush_ms, dispatch_ms, dispatch_ranges);
 }
 
 int advance_to_anchored(RibbitHandle *h) {
@@ -418,7 +418,12 @@ int advance_to_anchored(RibbitHandle *h) {
     const unsigned threads = rb::merge_threads(h->host_threads);
     rb::MergeStats st;
     if (full) rb::merge_anchored_stage_full(h->lists, h->anchored_calls.data(), h->anchored_calls.size(), threads, &st);
-    else rb::merge_anchored_stage(h->lists, dca, threads, &st);
+    else {
+        // the first parallel pass as device work for stages of a million calls and more (api_merge.cpp): the kept calls are still
+        // where window_stage_device put them (d_dense as 16-byte call records, d_pend)
+        const rb::AnchoredDevicePass on_device = anchored_device_pass(h, reinterpret_cast<RibbitCall *>(h->d_dense.p), dca.pend ? h->d_pend.p : nullptr);
+        rb::merge_anchored_stage(h->lists, dca, threads, &st, &on_device);
+    }
     const double t1 = now_ms();
     const unsigned dispatch_ranges = rb::dispatch_order_ranges(h->lists, st.cut_pos, threads, h->dispatch);
     h->merge_ms = now_ms() - t0;
@@ -498,6 +503,11 @@ void ribbit_debug_last_merge(int stage, int32_t out[5]) {
     out[3] = (int32_t)std::min<long long>(st.head_writes, INT32_MAX); out[4] = (st.first_range_empty ? 1 : 0) | (int32_t)(st.passes << 8);
 }
 
+void ribbit_debug_last_device_merge(int32_t out[5]) {
+    const rb::MergeStats st = rb::last_merge_stats(1);
+    out[0] = (int32_t)st.device_ranges; out[1] = (int32_t)st.device_bailed; out[2] = (int32_t)st.device_host_share; out[3] = (int32_t)st.ranges; out[4] = (int32_t)st.ranges_redone;
+}
+
 int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
                              const uint32_t *hi, const uint32_t *lo, const uint32_t *brk, size_t nwords,
                              const uint32_t *xa, size_t xa_stride,
@@ -542,7 +552,22 @@ int ribbit_host_replay_calls(const RibbitScanParams *params, int64_t length,
     rb::SeedVec dispatch;
     if (anchored_stage) {
         rb::MergeStats st;
-        rb::merge_anchored_stage_full(sl, anchored_calls, n_anchored_calls, rb::merge_threads(0), &st);
+        // test hook RIBBIT_MERGE_DEVICE_RANGES=<calls per range>: the stage cut as for the GPU's pass of the anchored merge (hundreds of
+        // thousands of ranges, prepared on the host threads) with a device that cannot run -- the host threads then merge those ranges
+        rb::AnchoredDevicePass no_device;
+        const char *fine = std::getenv("RIBBIT_MERGE_DEVICE_RANGES");
+        if (fine) {
+            no_device.min_calls = 0; no_device.calls_per_range = (size_t)std::max(1, std::atoi(fine));
+            // (the "device" takes the lighter half of the ranges and merges none of them)
+            no_device.run = [](const rb::SeedLists &, const rb::KeptCalls &, const std::vector<size_t> &, const std::vector<int> &, const std::vector<rb::Cursor2> &, const std::vector<uint32_t> &order, size_t,
+                               const std::function<void(uint32_t *, const uint32_t *)> &meanwhile, std::vector<rb::AnchoredDevicePass::RangeResult> &, std::vector<rb::AnchoredDevicePass::LogEntry> &,
+                               std::vector<rb::AnchoredDevicePass::LogEntry> &, std::vector<rb::AnchoredDevicePass::HeadEntry> &) {
+                uint32_t from_back = (uint32_t)order.size(), from_front = (uint32_t)order.size() / 2;
+                meanwhile(&from_back, &from_front);
+                return false;
+            };
+        }
+        rb::merge_anchored_stage_full(sl, anchored_calls, n_anchored_calls, rb::merge_threads(0), &st, fine ? &no_device : nullptr);
         const double td = now_ms();
         const unsigned dispatch_ranges = rb::dispatch_order_ranges(sl, st.cut_pos, rb::merge_threads(0), dispatch);
         if (std::getenv("RIBBIT_PROFILE")) print_anchored_merge_profile(sl.anchored.size(), st, now_ms() - td, dispatch_ranges);

@@ -192,6 +192,51 @@ void launch_ssw_paths(const uint8_t *ascii, int64_t length, const uint8_t *motif
 // max_band then is the largest band among the OTHERS.
 constexpr int SSW_PATH_NARROW_BAND = 7;
 
+// anchored_merge.hip: the anchored stage's seed-list merge (parse_anchored_shiftxor.cpp:113-534, merge_types.cpp:11-189), one lane
+// per independent range of the stage's kept calls (parallel_merge.h).  P / S: the perfect and substitution lists on the device (their
+// `type` fields change: retirements); *_type0: the types before the stage; first[nr + 1], cut_pos[nr], cur0[2 nr]: the ranges' first
+// calls, left cuts and starting cursors; own: n_calls + nr entries, range k's part of the anchored list at first[k] + k (entry 0 of
+// every range but the first is the sentinel); range_out[AM_RANGE_OUT_WORDS k ..]: entries in own, status (AM_* bits: the host merges
+// the range itself), guard count (2 words), final cursors (2), by-counter head reads (2 x 2), calls taken, the lane's time; log: 4 words per entry
+// {kind << 28 | range, list << 31 | index, old type or "was live", 0}; head_log: 8 words per logged list-head write
+// {range, list, index, start, end, mlen, type, 0}.
+constexpr int AM_PS_CAP = 12, AM_CAND_CAP = 40;      // candidate lists of a call: this much of them in LDS (208 bytes per lane, 13 KB per wavefront) ...
+constexpr int AM_CHILD_CAP = 128, AM_COV_CAP = 48, AM_MAX_ROUNDS = 1 << 20;
+constexpr int AM_PS_SPILL = 244, AM_CAND_SPILL = 984;      // ... and what a dense locus has beyond, in global memory (256 / 1024 entries in all)
+constexpr int AM_SCRATCH_WORDS = 2 * AM_CHILD_CAP + 3 * AM_COV_CAP + AM_PS_SPILL + AM_CAND_SPILL;
+constexpr int AM_RANGE_OUT_WORDS = 12;
+constexpr int AM_RESIDENT_WAVES = 12 * 256;      // what the chip holds at once: twelve wavefronts per CU (LDS, and three per SIMD by registers)
+constexpr uint32_t AM_MAX_PASSES = 12000;        // a range that takes its lane more passes than this (80 ms) is given up: AM_TOO_SLOW
+enum : uint32_t { AM_SCRATCH_FULL = 1u, AM_LOG_FULL = 2u, AM_BAD_PLANE = 4u, AM_RUNAWAY = 8u, AM_TOO_SLOW = 16u };
+enum : uint32_t { AM_LOG_UNDO = 1u, AM_LOG_READ = 2u };
+struct AnchoredMergeArgs {
+    RibbitSeed *P, *S;
+    uint32_t nP, nS;
+    const int32_t *P_type0, *S_type0;
+    RibbitCall *calls;                // (their `pos` fields are overwritten with the calls' cursor bounds)
+    const int32_t *pend;              // may be null
+    const uint32_t *first;
+    const int32_t *cut_pos, *cur0;
+    uint32_t nr;
+    const uint32_t *xa;
+    int64_t xa_stride, length;
+    int32_t m_lo, m_hi;
+    RibbitSeed *own;
+    uint32_t *range_out;
+    uint32_t *log, *log_count;
+    uint32_t log_cap;
+    uint32_t *head_log, *head_count;
+    uint32_t head_cap;
+    uint32_t *scratch;                // AM_SCRATCH_WORDS per LANE of the launch (64 AM_RESIDENT_WAVES at most)
+    uint32_t *next_range;             // zero at launch: the lanes take ranges from it, in the order of ...
+    const uint32_t *order;            // ... the ranges to merge (n_order of the nr; the others are not touched)
+    uint32_t n_order;
+    uint32_t *sync;                   // page-locked host memory: [0] entries of `order` left to the lanes (the host threads take from the back), [1] entries the lanes have taken
+    uint32_t max_passes;              // a range that needs more passes of its lane's loop than this is left to the host (AM_TOO_SLOW)
+};
+void launch_anchored_merge(const AnchoredMergeArgs &a, uint32_t n_calls, uint32_t resident_waves /* <= AM_RESIDENT_WAVES */, hipStream_t stream);
+void launch_seed_types(const RibbitSeed *seeds, uint32_t n, int32_t *types, hipStream_t stream);      // types[i] = seeds[i].type
+
 // profiling aid: reads nwords dwords of src with one coalesced dword per lane (known byte count)
 void launch_calib_stream_read(const uint32_t *src, int64_t nwords, uint32_t *sink, hipStream_t stream);
 

@@ -172,11 +172,12 @@ struct CallExtrema {
 // The coverage bitmap is filled and the running extrema are scanned on the host threads; the search itself looks at
 // the candidates in call order (the first valid one at or after every `per`-th call), as a sequential walk would.
 std::vector<size_t> cut_ranges(const KeptCalls &kc, std::initializer_list<const SeedVec *> statics, int64_t length,
-                               size_t want_ranges, std::vector<int> &cut_pos, unsigned threads, CallExtrema &ext) {
+                               size_t want_ranges, std::vector<int> &cut_pos, unsigned threads, CallExtrema &ext, size_t min_range_cap = 0) {
     const size_t n = kc.n;
     std::vector<size_t> first{0};
     cut_pos.assign(1, INT32_MIN);
-    const size_t min_range = std::max<size_t>(g_min_range.load(), 1);
+    // (min_range_cap: the device pass wants ranges far smaller than what is worth a host thread)
+    const size_t min_range = std::max<size_t>(min_range_cap ? std::min(g_min_range.load(), min_range_cap) : g_min_range.load(), 1);
     const size_t per = std::max(min_range, (n + want_ranges - 1) / std::max<size_t>(want_ranges, 1));
     if (n < 2 * per) return first;
     Coverage cov(length);
@@ -186,17 +187,28 @@ std::vector<size_t> cut_ranges(const KeptCalls &kc, std::initializer_list<const 
     }
     parallel_pieces(n, threads, [&](size_t lo, size_t hi, unsigned) { for (size_t i = lo; i < hi; ++i) cov.mark(kc.calls[i].start, kc.calls[i].end); });
     ext.build(kc, threads);
-    for (size_t i = per; i < n && n - i >= min_range;) {
-        const int64_t left = (int64_t)ext.end_before[i] + 1, right = (int64_t)ext.start_from[i] - 1;
-        const int64_t p = left <= right ? cov.first_clear(left, right) : -1;
-        if (p >= 0) {
-            first.push_back(i);
-            cut_pos.push_back((int)p);
-            i += per;
-        } else {
-            ++i;
+    // the first valid cut at or after every `per`-th call, from call `from` up to `to`
+    auto search = [&](size_t from, size_t to, std::vector<size_t> &at, std::vector<int> &pos) {
+        for (size_t i = from; i < to && n - i >= min_range;) {
+            const int64_t left = (int64_t)ext.end_before[i] + 1, right = (int64_t)ext.start_from[i] - 1;
+            const int64_t p = left <= right ? cov.first_clear(left, right) : -1;
+            if (p >= 0) {
+                at.push_back(i);
+                pos.push_back((int)p);
+                i += per;
+            } else {
+                ++i;
+            }
         }
-    }
+    };
+    const unsigned pieces = min_range_cap ? pieces_for(n, threads) : 1u;
+    if (pieces <= 1) { search(per, n, first, cut_pos); return first; }
+    // (the device pass's hundreds of thousands of ranges: the calls in pieces, each searched from `per` calls behind its start --
+    // whether a cut is valid does not depend on the cuts before it, only which of the valid ones are taken does)
+    std::vector<std::vector<size_t>> at(pieces);
+    std::vector<std::vector<int>> pos(pieces);
+    parallel_pieces(n, pieces, [&](size_t lo, size_t hi, unsigned t) { search(lo + per, hi, at[t], pos[t]); });
+    for (unsigned t = 0; t < pieces; ++t) { first.insert(first.end(), at[t].begin(), at[t].end()); cut_pos.insert(cut_pos.end(), pos[t].begin(), pos[t].end()); }
     return first;
 }
 
@@ -220,11 +232,15 @@ void run_ranges(size_t n_ranges, unsigned threads, Work work) {
 template <class States>
 void join_ranges(const States &state, size_t nr, SeedVec &out, unsigned threads) {
     std::vector<size_t> at(nr + 1, 0);
-    for (size_t k = 0; k < nr; ++k) at[k + 1] = at[k] + state[k].own.size() - (k > 0 ? 1 : 0);
+    for (size_t k = 0; k < nr; ++k) at[k + 1] = at[k] + state[k].own_size() - (k > 0 ? 1 : 0);
     out.resize(at[nr]);
-    run_ranges(nr, threads, [&](size_t k) {
-        const size_t n = at[k + 1] - at[k];
-        if (n) std::memcpy(out.data() + at[k], state[k].own.data() + (k > 0 ? 1 : 0), n * sizeof(RibbitSeed));
+    // (pieces of ranges, not single ranges, per turn of a thread: the device pass makes a hundred thousand of them)
+    const size_t grain = std::max<size_t>(1, nr / ((size_t)threads * 8 + 1));
+    run_ranges((nr + grain - 1) / grain, threads, [&](size_t g) {
+        for (size_t k = g * grain; k < std::min(nr, (g + 1) * grain); ++k) {
+            const size_t n = at[k + 1] - at[k];
+            if (n) std::memcpy(out.data() + at[k], state[k].own_data() + (k > 0 ? 1 : 0), n * sizeof(RibbitSeed));
+        }
     });
 }
 
@@ -304,10 +320,10 @@ void merge_subst_stage_full(SeedLists &lists, const RibbitCall *calls, size_t n,
     merge_subst_stage(lists, c.view, threads, stats);
 }
 
-void merge_anchored_stage_full(SeedLists &lists, const RibbitCall *calls, size_t n, unsigned threads, MergeStats *stats) {
+void merge_anchored_stage_full(SeedLists &lists, const RibbitCall *calls, size_t n, unsigned threads, MergeStats *stats, const AnchoredDevicePass *device) {
     Compacted c;
     compact_full(calls, n, lists.length, anchored_seedlen_cutoff, c);
-    merge_anchored_stage(lists, c.view, threads, stats);
+    merge_anchored_stage(lists, c.view, threads, stats, device);
 }
 
 void replay_anchored_calls(SeedLists &lists, const RibbitCall *calls, size_t n, int64_t length) {
@@ -323,6 +339,12 @@ void replay_subst_calls(SeedLists &lists, const RibbitCall *calls, size_t n) {
 // One range's private state: the list it appends to and the logs that let it be validated and redone.
 struct RangeState {
     SeedVec own;                    // the stage's list, this range's part (own[0] = SENTINEL for ranges > 0)
+    // ... or, after the device pass (AnchoredDevicePass), where that left it; reset() returns to `own`
+    const RibbitSeed *ext = nullptr;
+    size_t ext_n = 0;
+    size_t own_size() const { return ext ? ext_n : own.size(); }
+    const RibbitSeed *own_data() const { return ext ? ext : own.data(); }
+    bool own_empty() const { return own_size() == 0; }
     std::vector<ListRefs::TypeWrite> undo;
     std::vector<ListRefs::TypeRead> foreign_reads;
     std::vector<ListRefs::HeadWrite> head_writes;
@@ -333,6 +355,7 @@ struct RangeState {
         for (size_t i = undo.size(); i-- > 0;) undo[i].seed->type = undo[i].old_type;
         undo.clear();
         foreign_reads.clear();
+        ext = nullptr; ext_n = 0;
         own.clear();
         own.reserve(expect + 1);
         if (sentinel) own.push_back(SENTINEL);
@@ -439,7 +462,7 @@ void merge_subst_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, 
     if (stats) *stats = st;
 }
 
-void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, MergeStats *stats) {
+void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, MergeStats *stats, const AnchoredDevicePass *device) {
     MergeStats st;
     threads = resolve_threads(threads);
     st.threads = threads;
@@ -447,9 +470,14 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
     std::vector<size_t> first{0};
     std::vector<int> cut_pos;
     static thread_local CallExtrema ext;      // scratch that lives across the records of the calling thread
-    if (threads > 1) first = cut_ranges(kc, {&lists.perfect, &lists.subst}, lists.length, (size_t)threads * 8, cut_pos, threads, ext);
+    // the device pass: ranges of a few hundred calls, one lane each (parallel_merge.h)
+    if (device && !(device->run && kc.n >= device->min_calls && threads > 1 && !std::getenv("RIBBIT_MERGE_FORCE_REDO"))) device = nullptr;
+    if (device) first = cut_ranges(kc, {&lists.perfect, &lists.subst}, lists.length, std::max<size_t>(kc.n / std::max<size_t>(device->calls_per_range, 1), (size_t)threads * 8),
+                                   cut_pos, threads, ext, std::max<size_t>(device->calls_per_range, 1));
+    else if (threads > 1) first = cut_ranges(kc, {&lists.perfect, &lists.subst}, lists.length, (size_t)threads * 8, cut_pos, threads, ext);
     const size_t nr = first.size();
     st.ranges = (unsigned)nr;
+    st.prep_parts[0] = now_ms() - t0;
     if (nr == 1) {
         anchored_in_order(lists, kc);
         st.merge_ms = now_ms() - t0;
@@ -459,7 +487,7 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
     }
     first.push_back(kc.n);
     std::vector<Cursor2> start_cursor(nr);
-    {
+    if (!device) {
         Cursor2 cur;
         for (size_t k = 0; k < nr; ++k) {
             const int seen = ext.seen_before[first[k]];
@@ -469,8 +497,37 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
             }
             start_cursor[k] = cur;
         }
+    } else {
+        // The same cursors for a hundred thousand ranges, on the host threads.  `seen` only grows from range to range, so the chain
+        // of advances above ends, for every range, at the FIRST entry of the whole list whose start exceeds its `seen` (capped at
+        // the last entry): everything before the previous cursor starts at or below the previous, smaller, `seen`.  The first
+        // entry whose start exceeds a value is the first whose running maximum of starts does: a bisection per range.
+        auto running_max = [&](const SeedVec &l) {
+            std::vector<int32_t> m(l.size());
+            int32_t top = INT32_MIN;
+            for (size_t i = 0; i < l.size(); ++i) { top = std::max(top, l[i].start); m[i] = top; }
+            return m;
+        };
+        std::vector<int32_t> mp, ms;
+        std::thread other([&]() { ms = running_max(lists.subst); });
+        mp = running_max(lists.perfect);
+        other.join();
+        auto first_beyond = [](const std::vector<int32_t> &m, int seen) {
+            if (m.empty()) return 0;
+            const size_t i = (size_t)(std::upper_bound(m.begin(), m.end(), seen) - m.begin());
+            return (int)std::min(i, m.size() - 1);
+        };
+        const int32_t *seen_before = ext.seen_before;         // (ext is the CALLING thread's scratch: a worker must not name it)
+        parallel_pieces(nr, threads, [&, seen_before](size_t lo, size_t hi, unsigned) {
+            for (size_t k = lo; k < hi; ++k) {
+                const int seen = seen_before[first[k]];
+                if (seen >= 0) { start_cursor[k].perfect = first_beyond(mp, seen); start_cursor[k].subst = first_beyond(ms, seen); }
+            }
+        });
     }
+    st.prep_parts[1] = now_ms() - t0;
     const std::vector<int32_t> perfect_types = types_of(lists.perfect), subst_types = types_of(lists.subst);
+    st.prep_parts[2] = now_ms() - t0;
     const int64_t guard_before = lists.guard_hits;
     std::vector<RangeState> state(nr);
     st.prepare_ms = now_ms() - t0;
@@ -551,6 +608,111 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
         todo.clear();
         for (size_t k = from; k < nr; ++k) if (stale[k]) { todo.push_back(k); stale[k] = 0; }
         const double tp = now_ms();
+        if (device && passes == 1) {
+            // The first pass on the device -- and, while its kernel runs, on the host threads too.  A lane takes some 70 us per call, a
+            // host thread 0.1: the GPU wins by numbers alone, and the time of its pass is that of its last ranges.  So the ranges are
+            // put in the order of the work they are expected to be (passes of a lane's loop, from the calls of the range and how deep
+            // they lie on one another: fitted on a 60-Mbp record, within 17 % for nine ranges in ten); the lanes take them from the
+            // light end, the host threads from the heavy end -- the dense loci, where a lane needs thousands of passes and its
+            // candidate lists may not fit -- until the two meet.  Neither side locks anything: each publishes how far it is (a word
+            // in page-locked memory) and reads the other's; a range both took is the host's.  What the device could not merge
+            // (candidate lists beyond its LDS, a budget of passes) follows on the host threads.
+            std::vector<AnchoredDevicePass::RangeResult> res;
+            std::vector<AnchoredDevicePass::LogEntry> undo, reads;
+            std::vector<AnchoredDevicePass::HeadEntry> heads;
+            std::vector<uint32_t> order(nr);                      // counting sort by expected work, 16 passes to a bucket
+            size_t device_limit = 0;
+            {
+                constexpr uint32_t BUCKETS = 2048;
+                std::vector<uint16_t> key(nr);
+                parallel_pieces(nr, threads, [&](size_t lo, size_t hi, unsigned) {
+                    for (size_t k = lo; k < hi; ++k) {
+                        int64_t sum = 0; int32_t left = INT32_MAX, right = -1;
+                        for (size_t i = first[k]; i < first[k + 1]; ++i) { const RibbitCall &c = kc.calls[i]; sum += c.end - c.start; left = std::min(left, c.start); right = std::max(right, c.end); }
+                        const double calls = (double)(first[k + 1] - first[k]), depth = (double)sum / (double)std::max(1, right - left);
+                        const double expected = 11.0 * calls + 0.285 * calls * depth;
+                        key[k] = (uint16_t)std::min<double>(BUCKETS - 1, expected / 16.0);
+                    }
+                });
+                std::vector<uint32_t> at(BUCKETS + 1, 0);
+                for (size_t k = 0; k < nr; ++k) ++at[key[k] + 1u];
+                for (uint32_t q = 1; q <= BUCKETS; ++q) at[q] += at[q - 1];
+                for (size_t k = 0; k < nr; ++k) order[at[key[k]]++] = (uint32_t)k;
+                // (at[b] is now the END of bucket b) the lanes' part of the list: ranges expected to take no more than the most a lane should
+                device_limit = at[std::min<size_t>(BUCKETS - 2, device->max_range_passes / 16)];
+            }
+            std::vector<char> host_done(nr, 0);
+            double meanwhile_ms = 0.0;
+            std::atomic<size_t> host_took{0};
+            const std::function<void(uint32_t *, const uint32_t *)> meanwhile = [&](uint32_t *from_back, const uint32_t *from_front) {
+                const double tm = now_ms();
+                // *from_back: how many entries of `order` the lanes may still take -- never more than device_limit, and nothing the
+                // host threads have taken (they start at the very back); *from_front: how many the lanes have taken (as far as the
+                // host has seen)
+                std::atomic<uint32_t> back{(uint32_t)nr};
+                run_ranges(threads, threads, [&](size_t) {
+                    for (;;) {
+                        uint32_t left = back.load(std::memory_order_relaxed);
+                        do { if (left == 0) return; }                                          // (everything is taken)
+                        while (!back.compare_exchange_weak(left, left - 1u, std::memory_order_relaxed));
+                        const uint32_t q = left - 1u;
+                        for (uint32_t seen = __atomic_load_n(from_back, __ATOMIC_RELAXED); q < seen;)       // (only ever lowered)
+                            if (__atomic_compare_exchange_n(from_back, &seen, q, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+                        if (q < __atomic_load_n(from_front, __ATOMIC_RELAXED)) return;          // the lanes are past this one
+                        const size_t k = order[q];
+                        const double tr = now_ms();
+                        state[k].reset(k > 0, first[k + 1] - first[k]);
+                        body(k, state[k], false, nullptr, nullptr);
+                        range_ms[k] = now_ms() - tr;
+                        host_done[k] = 1;
+                        host_took.fetch_add(1, std::memory_order_relaxed);
+                    }
+                });
+                meanwhile_ms = now_ms() - tm;
+            };
+            const double td = now_ms();
+            const bool ran = device->run(lists, kc, first, cut_pos, start_cursor, order, device_limit, meanwhile, res, undo, reads, heads) && res.size() == nr;
+            st.device_ms = now_ms() - td;
+            st.device_meanwhile_ms = meanwhile_ms;
+            st.device_host_share = (unsigned)host_took.load();
+            std::vector<size_t> host_todo;
+            if (ran) {
+                auto seed_at = [&](uint32_t list, uint32_t index) -> RibbitSeed * { return (list ? lists.subst.data() : lists.perfect.data()) + index; };
+                // the results into the ranges' states, on the host threads: each takes a slice of the ranges and looks through the whole
+                // logs for its own (the entries come in the order the lanes happened to write them)
+                const size_t slices = std::max<size_t>(1, std::min<size_t>(threads, nr / 1024 + 1));
+                run_ranges(slices, threads, [&](size_t t) {
+                    const size_t lo = nr * t / slices, hi = nr * (t + 1) / slices;
+                    for (size_t k = lo; k < hi; ++k) {
+                        if (res[k].status || host_done[k]) continue;
+                        RangeState &me = state[k];
+                        me.reset(false, 0);
+                        me.ext = res[k].own; me.ext_n = res[k].own_n;
+                        me.guard_hits = res[k].guard_hits; me.cursor = res[k].cursor;
+                        me.head_reads[0] = res[k].head_reads[0]; me.head_reads[1] = res[k].head_reads[1];
+                    }
+                    // (a range the host merges makes its retirements itself; the others' are made here, as their workers would have)
+                    for (const AnchoredDevicePass::LogEntry &e : undo) {
+                        if (e.range < lo || e.range >= hi || res[e.range].status || host_done[e.range]) continue;
+                        RibbitSeed *sd = seed_at(e.list, e.index);
+                        state[e.range].undo.push_back({sd, e.value});
+                        sd->type = RIBBIT_RANK_N;
+                    }
+                    for (const AnchoredDevicePass::LogEntry &e : reads)
+                        if (e.range >= lo && e.range < hi && !res[e.range].status && !host_done[e.range]) state[e.range].foreign_reads.push_back({seed_at(e.list, e.index), e.value != 0});
+                    for (const AnchoredDevicePass::HeadEntry &e : heads)
+                        if (e.range >= lo && e.range < hi && !res[e.range].status && !host_done[e.range]) state[e.range].head_writes.push_back({seed_at(e.list, e.index), e.value});
+                });
+                for (size_t k = 0; k < nr; ++k) if (res[k].status && !host_done[k]) host_todo.push_back(k);
+                st.device_ranges = (unsigned)(nr - host_todo.size() - host_took.load());
+                st.device_bailed = (unsigned)host_todo.size();
+                st.device_apply_ms = now_ms() - td - st.device_ms;
+            } else {
+                for (size_t k = 0; k < nr; ++k) if (!host_done[k]) host_todo.push_back(k);
+            }
+            for (size_t k2 = 0; k2 < nr; ++k2) if (host_done[k2]) { st.range_ms_sum += range_ms[k2]; st.range_ms_max = std::max(st.range_ms_max, range_ms[k2]); }
+            todo.swap(host_todo);
+        }
         run_ranges(todo.size(), threads, [&](size_t q) {
             const size_t k = todo[q];
             const double tr = now_ms();
@@ -576,7 +738,7 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
                 body(k, state[k], true, ch, &reach);
                 ++st.ranges_redone;
             }
-            if (k == 0 && state[0].own.empty()) { fallback = true; break; }      // later ranges assumed a non-empty list
+            if (k == 0 && state[0].own_empty()) { fallback = true; break; }      // later ranges assumed a non-empty list
             if (ch[0] | ch[1]) {
                 // A later range comes out differently only if it read a changed entry by loop counter, or if the entry -- where
                 // it was or where the write put it -- can be met by the range's ordinary walks: those stay right of the range's
@@ -602,7 +764,7 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
     }
     st.head_writes = head_writes;
     st.passes = passes;
-    st.first_range_empty = state[0].own.empty();
+    st.first_range_empty = state[0].own_empty();
     if (presize.joinable()) presize.join();
     if (fallback) {
         for (size_t k = nr; k-- > 0;) state[k].reset(false, 0);      // takes back the ranges' retirements
@@ -632,9 +794,18 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
 namespace { thread_local unsigned tl_last_dispatch_ranges = 0; }
 unsigned last_dispatch_ranges() { return tl_last_dispatch_ranges; }
 
-unsigned dispatch_order_ranges(const SeedLists &sl, const std::vector<int> &cut_pos, unsigned threads, SeedVec &out) {
-    const size_t nr = cut_pos.size();
+unsigned dispatch_order_ranges(const SeedLists &sl, const std::vector<int> &all_cuts, unsigned threads, SeedVec &out) {
     threads = resolve_threads(threads);
+    // (the device pass of the anchored merge cuts a chromosome into 10^5 ranges; sixteen per thread are plenty here, and any
+    // subset of valid cuts is a valid set of cuts)
+    std::vector<int> thinned;
+    const size_t most = (size_t)threads * 16;
+    if (all_cuts.size() > 2 * most) {
+        const size_t step = (all_cuts.size() + most - 1) / most;
+        for (size_t k = 0; k < all_cuts.size(); k += step) thinned.push_back(all_cuts[k]);
+    }
+    const std::vector<int> &cut_pos = thinned.empty() ? all_cuts : thinned;
+    const size_t nr = cut_pos.size();
     tl_last_dispatch_ranges = 1;
     if (nr < 2 || threads < 2) { dispatch_order(sl, out); return 1; }
     const SeedVec *lists[3] = {&sl.perfect, &sl.subst, &sl.anchored};

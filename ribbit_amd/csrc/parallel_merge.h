@@ -27,6 +27,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <functional>
 #include <vector>
 
 #include "ribbit_hip.h"
@@ -60,6 +61,11 @@ struct MergeStats {
     // anchored stage, inside merge_ms: wall time of the parallel passes, of the in-order walks behind them (with the ranges
     // they do again), and the ranges' own times in the parallel passes (sum over ranges, longest range)
     double pass_ms = 0.0, walk_ms = 0.0, range_ms_sum = 0.0, range_ms_max = 0.0;
+    double device_ms = 0.0, device_apply_ms = 0.0;      // inside pass_ms: the device pass (AnchoredDevicePass::run) and putting its results into the ranges' states
+    double device_meanwhile_ms = 0.0;                    // ... of which the host threads were merging their share of the ranges for this long
+    unsigned device_host_share = 0;                      // ranges the host threads merged while the kernel ran (from the heavy end)
+    unsigned device_ranges = 0, device_bailed = 0;       // ranges the device pass merged / left to the host (scratch overflow)
+    double prep_parts[3] = {0, 0, 0};                    // inside prepare_ms, cumulative: the cuts; the ranges' cursors; the type snapshots (then: the ranges' states)
     double before_passes_ms = 0.0, flush_ms = 0.0;     // inside merge_ms too: what precedes the first pass; the end-of-sequence calls after the join
     std::vector<int> cut_pos;  // the positions the ranges were cut at (first entry INT32_MIN): uncovered by any call or earlier-stage seed
 };
@@ -73,10 +79,40 @@ struct MergeStats {
 unsigned dispatch_order_ranges(const SeedLists &sl, const std::vector<int> &cut_pos, unsigned threads, SeedVec &out);
 unsigned last_dispatch_ranges();      // of the calling thread's last dispatch_order_ranges (1: the sequential merge ran)
 
+// The first parallel pass of the anchored stage's merge as DEVICE work (anchored_merge.hip: one lane per range; the API layer
+// supplies `run`, this file stays free of HIP).  The stage then cuts the calls into ranges of about `calls_per_range` calls (a
+// few hundred: 10^5 ranges for a chromosome) instead of eight ranges per host thread; what comes back per range is exactly what a
+// host worker leaves in its RangeState (parallel_merge.cpp), so the in-order validation walk, the ranges done again and every later
+// pass are the host code unchanged.  A range with a non-zero status was not merged (its scratch lists overflowed): the host
+// merges it.  run() returns false when the device pass could not be made at all (the host pass runs instead).
+struct AnchoredDevicePass {
+    struct RangeResult {
+        const RibbitSeed *own = nullptr;      // the range's part of the anchored list (entry 0 of every range but the first: the sentinel)
+        uint32_t own_n = 0, status = 0;
+        int64_t guard_hits = 0;
+        Cursor2 cursor;
+        uint64_t head_reads[2] = {0, 0};
+    };
+    struct LogEntry { uint32_t range, list, index; int32_t value; };      // list 0 perfect, 1 substitution; value: old type / was live
+    struct HeadEntry { uint32_t range, list, index; RibbitSeed value; };
+    size_t min_calls = 1u << 20;          // smaller stages stay on the host threads
+    size_t calls_per_range = 64;          // what the stage's calls are cut into (wherever a cut is valid)
+    size_t max_range_passes = 6000;       // a range expected to take a lane more passes of its loop than this is the host threads' from the start
+    // order: all ranges, by the work they are expected to be; the lanes take them from the front, the first device_limit of them
+    // at most.  meanwhile(from_back, from_front):
+    // called once while the kernel runs, if it could be launched -- the host threads take ranges from the back of `order` in it;
+    // *from_back (page-locked, read by the lanes) = entries of `order` still left to the device, *from_front (written by the lanes) =
+    // entries they have taken.  A range both sides took is the host's.  ranges[k].status != 0 for every range the device did not merge.
+    std::function<bool(const SeedLists &lists, const KeptCalls &kc, const std::vector<size_t> &first, const std::vector<int> &cut_pos,
+                       const std::vector<Cursor2> &start_cursor, const std::vector<uint32_t> &order, size_t device_limit,
+                       const std::function<void(uint32_t *from_back, const uint32_t *from_front)> &meanwhile,
+                       std::vector<RangeResult> &ranges, std::vector<LogEntry> &undo, std::vector<LogEntry> &reads, std::vector<HeadEntry> &heads)> run;
+};
+
 // lists.subst is rebuilt from kc (lists.perfect as the perfect stage left it)
 void merge_subst_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, MergeStats *stats = nullptr);
 // lists.anchored is rebuilt from kc (lists.perfect / lists.subst as the substitution stage left them)
-void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, MergeStats *stats = nullptr);
+void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned threads, MergeStats *stats = nullptr, const AnchoredDevicePass *device = nullptr);
 
 // Replay of a full anchored call list (ribbit_hip_anchored_calls order: in-loop calls, then the end-of-sequence flush)
 void replay_anchored_calls(SeedLists &lists, const RibbitCall *calls, size_t n, int64_t length);
@@ -86,7 +122,7 @@ void replay_subst_calls(SeedLists &lists, const RibbitCall *calls, size_t n);
 // The same two stages from a FULL call list in the scanner's call order (in-loop calls, then the end-of-sequence
 // flush with pos == length): filtered and bounded here, then merged as above.
 void merge_subst_stage_full(SeedLists &lists, const RibbitCall *calls, size_t n, unsigned threads, MergeStats *stats = nullptr);
-void merge_anchored_stage_full(SeedLists &lists, const RibbitCall *calls, size_t n, unsigned threads, MergeStats *stats = nullptr);
+void merge_anchored_stage_full(SeedLists &lists, const RibbitCall *calls, size_t n, unsigned threads, MergeStats *stats = nullptr, const AnchoredDevicePass *device = nullptr);
 
 // threads the merges may use: `asked` if non-zero, else environment RIBBIT_THREADS, else min(cores, 16)
 unsigned merge_threads(unsigned asked);

@@ -67,6 +67,38 @@ def test_range_parallel_merges_on_fuzzed_records(tiny_ranges, block):
         _check(seq, m_lo, m_hi, f"seed {seed}: {len(seq)} bases, -m {m_lo} -M {m_hi}")
 
 
+@pytest.mark.parametrize("calls_per_range", [1, 4, 64])
+def test_the_ranges_of_the_device_pass_merged_on_the_host_threads(calls_per_range):
+    """The GPU's pass of the anchored merge (anchored_merge.hip) cuts the stage into ranges of a few dozen calls -- prepared on the
+    host threads: cuts searched in pieces, the ranges' cursors by bisection on the running maximum of the list's starts -- gives
+    the long ones to the host threads while its kernel runs and the ones it cannot merge afterwards.  RIBBIT_MERGE_DEVICE_RANGES
+    runs all of that with a device that fails after the host's share: the same lists as the oracle's."""
+    lib = ribbit_amd.load_library()
+    old = {k: os.environ.get(k) for k in ("RIBBIT_MERGE_DEVICE_RANGES", "RIBBIT_THREADS")}
+    os.environ.update(RIBBIT_MERGE_DEVICE_RANGES=str(calls_per_range), RIBBIT_THREADS="4")
+    lib.ribbit_debug_set_merge_min_range(calls_per_range)
+    try:
+        most = 0
+        for name, seq, m_lo, m_hi in CASES:
+            most = max(most, _check(seq, m_lo, m_hi, name)[0])
+        for seed in range(9000, 9060):
+            seq, m_lo, m_hi = fuzz_case(seed)
+            most = max(most, _check(seq, m_lo, m_hi, f"seed {seed}")[0])
+        for seed in (20037, 20171):          # (a range that reads a type its left neighbour changes afterwards: the validation walk)
+            seq, m_lo, m_hi = fuzz_case(seed)
+            _check(seq, m_lo, m_hi, f"seed {seed}")
+        from ribbit_amd.simulate import simulate_sequence
+        _check(simulate_sequence(300_000, 38, 2, 30)[0], 2, 30, "seed 38 (a list-head write that changes its entry)")
+        assert most > 100, most
+    finally:
+        lib.ribbit_debug_set_merge_min_range(4096)
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_a_two_megabase_record_is_cut_into_many_ranges():
     from ribbit_amd.simulate import simulate_sequence
     seq, _ = simulate_sequence(400_000, 17, 2, 40, n_block_rate=0.3)
