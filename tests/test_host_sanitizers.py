@@ -77,6 +77,12 @@ for min_range in (1, 16):
             r = ribbit_amd.host_replay_calls(m_lo, m_hi, seq, pc, sc, o.calls(LIST_ANCHORED), xa, stride)
             assert np.array_equal(r["anchored"].view("<i4"), o.seeds(LIST_ANCHORED).view("<i4"))
             assert np.array_equal(r["dispatch"].view("<i4"), o.dispatch().view("<i4"))
+            # the ranges of the GPU's pass of the anchored merge with a device that cannot run (parallel_merge.h: AnchoredDevicePass):
+            # cuts searched in pieces, cursors by bisection, host threads taking ranges from the back of a list the "lanes" take from the front
+            os.environ["RIBBIT_MERGE_DEVICE_RANGES"] = "4"
+            r = ribbit_amd.host_replay_calls(m_lo, m_hi, seq, pc, sc, o.calls(LIST_ANCHORED), xa, stride)
+            del os.environ["RIBBIT_MERGE_DEVICE_RANGES"]
+            assert np.array_equal(r["anchored"].view("<i4"), o.seeds(LIST_ANCHORED).view("<i4"))
             if len(seq) and min_range == 16:
                 os.environ["RIBBIT_DEBUG_JOB_SLICES"] = "3"          # the refinement pipeline's slice builder (one parallel region)
                 ribbit_amd.host_refine_jobs(m_lo, m_hi, seq, xa, stride, o.dispatch())
