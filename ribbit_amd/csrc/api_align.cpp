@@ -215,8 +215,12 @@ int ssw_class(const RibbitAlignJob &jb) {
 
 // classes: bit c set = jobs of size class c run here (the others keep flag -1).  pool_resident: the motif pool is on the
 // device already (an earlier call of the same record uploaded it).
+static std::atomic<int64_t> g_tm[16];
+double feeder_phase_ms(int k) { return (double)g_tm[k].load() / 1e3; }
+static inline void tm_add(int k, double t0) { g_tm[k] += (int64_t)((now_ms() - t0) * 1000.0); }
 int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const char *pool, size_t pool_len, int mask_len,
                           std::vector<rb::SswEnds> &ends, unsigned classes, bool pool_resident) {
+    double tq = now_ms();
     static_assert(sizeof(RibbitAlignJob) == 9 * sizeof(int32_t), "job record layout");
     static_assert(sizeof(rb::SswEnds) == 8 * sizeof(int32_t), "ends record layout");
     ends.assign(n, rb::SswEnds{});
@@ -258,6 +262,7 @@ int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const 
         if (cls_of[j] >= 0) order[count[(size_t)(NCLS - 1 - cls_of[j]) * BUCKETS + (size_t)(BUCKETS - 1 - bkt_of[j])]++] = (int32_t)j;
     const size_t n_colossal = class_count[4], n_giant = class_count[3], n_huge = class_count[2], n_big = class_count[1], n_small = class_count[0];
     if (order.empty()) return RIBBIT_OK;
+    tm_add(0, tq); tq = now_ms();
     if ((rc = h->d_ssw_jobs.ensure(n * 9))) return rc;
     if ((rc = h->d_ssw_out.ensure(n * 8))) return rc;
     if ((rc = h->d_ssw_order.ensure(order.size()))) return rc;
@@ -266,6 +271,7 @@ int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const 
     HIP_TRY(hipMemcpyAsync(h->d_ssw_order.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     if (pool_len && !pool_resident) HIP_TRY(hipMemcpyAsync(h->d_ssw_pool.p, pool, pool_len, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_ssw_out.p, 0xff, n * 8 * sizeof(int32_t), h->stream));      // flag -1 unless a kernel writes the record
+    tm_add(1, tq); tq = now_ms();
     // The long classes run a workgroup per alignment (ssw_group.hip: 4 / 8 / 16 wavefronts for the huge / giant / colossal class).
     // (Until round 4 RIBBIT_SSW_GROUP=0 selected the older one-wavefront-per-alignment kernel for them: it lost its measurement
     // in round 3 -- 295 against 110 ms for a 64-Mbp record's long batch -- and is gone from the product)
@@ -293,14 +299,18 @@ int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const 
                           rest + n_huge, (int)n_big, rest, (int)n_huge, mask_len, h->d_ssw_out.p, h->stream, 4);
     HIP_TRY(hipGetLastError());
     if (n_apart) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_ssw, 0));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    tm_add(2, tq); tq = now_ms();
     HIP_TRY(hipMemcpyAsync(ends.data(), h->d_ssw_out.p, n * sizeof(rb::SswEnds), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    tm_add(3, tq);
     return RIBBIT_OK;
 }
 
 // The banded path search of every job whose striped passes the GPU has done (run_ssw_passes left jobs, motif pool and end
 // points on the device): rounds of one launch each, the band doubling for the alignments still open (ssw.c:603-728).
 int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const std::vector<rb::SswEnds> &ends, std::vector<rb::SswPath> &paths) {
+    double tq = now_ms();
     paths.assign(n, rb::SswPath{});
     if (n == 0) return RIBBIT_OK;
     int rc;
@@ -321,19 +331,24 @@ int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const s
         worst_ops += (uint64_t)(rl + ql + 2);
     }
     if (open.empty()) return RIBBIT_OK;
+    tm_add(12, tq); tq = now_ms();
     const uint64_t path_cap = std::min<uint64_t>(worst_ops, 0xfffffff0u);
     if ((rc = h->d_path_ops.ensure((size_t)path_cap))) return rc;
     if ((rc = h->d_path_count.ensure(4))) return rc;
     if ((rc = h->d_path_result.ensure(4 * n))) return rc;
+    tm_add(13, tq); tq = now_ms();
     HIP_TRY(hipMemsetAsync(h->d_path_count.p, 0, 4 * sizeof(uint32_t), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_path_result.p, 0xff, 4 * n * sizeof(int32_t), h->stream));      // state -1: no path searched (the buffer is reused)
+    tm_add(14, tq); tq = now_ms();
     std::vector<int32_t> items, result(4 * n, -1);
     std::vector<uint64_t> cell_off, ops_off;
     std::vector<Open> next;
     constexpr uint64_t ARENA = (uint64_t)6 << 30;            // cell bytes per launch
     // Alignments with a narrow band (nineteen in twenty) run four to a wavefront (ssw_path4_kernel): they come first among a
     // round's items, in seed order, the others behind them, in seed order too.
+    tm_add(4, tq);
     while (!open.empty()) {
+        tq = now_ms();
         // one launch per arena-full of items
         size_t n_narrow_all = 0;
         {
@@ -360,6 +375,7 @@ int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const s
                 cells += need; ops += (uint64_t)(rl + ql + 2);
                 if (at >= n_narrow_all) max_band = std::max(max_band, open[at].band);        // (the LDS of the one-per-wavefront launch)
             }
+            tm_add(5, tq); tq = now_ms();
             const size_t ni = at - first;
             const size_t n_narrow = first < n_narrow_all ? std::min(ni, n_narrow_all - first) : 0;
             if ((rc = h->d_path_items.ensure(items.size())) || (rc = h->d_path_cell_off.ensure(ni)) || (rc = h->d_path_ops_off.ensure(ni)) ||
@@ -372,10 +388,13 @@ int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const s
                                  h->d_path_ops_off.p, (int)ni, max_band, h->d_path_cells.p, h->d_path_scratch.p, h->d_path_ops.p, (uint32_t)path_cap,
                                  h->d_path_count.p, h->d_path_result.p, h->stream, (int)n_narrow);
             HIP_TRY(hipGetLastError());
+            tm_add(6, tq); tq = now_ms();
             HIP_TRY(hipStreamSynchronize(h->stream));       // the item arrays above are reused by the next launch
+            tm_add(7, tq); tq = now_ms();
         }
         HIP_TRY(hipMemcpyAsync(result.data(), h->d_path_result.p, 4 * n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        tm_add(8, tq); tq = now_ms();
         for (const Open &o : open) {
             const int32_t *r = &result[4 * (size_t)o.job];
             if (r[0] == 2) {
@@ -387,7 +406,9 @@ int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const s
             }
         }
         open.swap(next);
+        tm_add(9, tq);
     }
+    tq = now_ms();
     uint32_t used = 0;
     HIP_TRY(hipMemcpyAsync(&used, h->d_path_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -397,8 +418,10 @@ int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const s
         HIP_TRY(hipMemcpyAsync(h->h_path_ops.p, h->d_path_ops.p, (size_t)used * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
+    tm_add(10, tq); tq = now_ms();
     for (size_t j = 0; j < n; ++j)
         if (result[4 * j] == 0 && !paths[j].failed) paths[j].ops = h->h_path_ops.p + (uint32_t)result[4 * j + 2];
+    tm_add(11, tq);
     return RIBBIT_OK;
 }
 

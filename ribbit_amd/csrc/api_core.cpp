@@ -60,6 +60,22 @@ int pinned_alloc(size_t bytes, void **out) {
     return RIBBIT_OK;
 }
 
+namespace {
+std::mutex g_free_mu;
+std::vector<void *> g_free_later, g_unpin_later;
+}
+// A buffer that is being replaced by a larger one is released later (at the end of refinement, at a handle's close, or when an
+// allocation fails): hipFree and the unpinning calls wait for every stream of the device -- 20 ms at a time beside another feeder's
+// kernels, 240 ms of a chromosome's first refinement until round 4.
+void device_free_later(void *p) { std::lock_guard<std::mutex> lk(g_free_mu); g_free_later.push_back(p); }
+void pinned_free_later(void *p) { std::lock_guard<std::mutex> lk(g_free_mu); g_unpin_later.push_back(p); }
+void device_free_pending() {
+    std::vector<void *> mine, pinned;
+    { std::lock_guard<std::mutex> lk(g_free_mu); mine.swap(g_free_later); pinned.swap(g_unpin_later); }
+    for (void *p : mine) (void)hipFree(p);
+    for (void *p : pinned) pinned_free(p);
+}
+
 void pinned_free(void *p) {
     if (!p) return;
     size_t len = 0;
@@ -235,6 +251,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    device_free_pending();
     h->d_ascii.release(); h->d_hi.release(); h->d_lo.release(); h->d_brk.release();
     h->d_events.release(); h->d_dense.release(); h->d_counters.release(); h->d_query.release(); h->d_xa.release(); h->d_seeds.release(); h->d_seeds_small.release(); h->d_longest.release(); h->d_sym.release(); h->d_best.release(); h->d_slices.release();
     h->d_ssw_jobs.release(); h->d_ssw_order.release(); h->d_ssw_out.release(); h->d_ssw_pool.release();

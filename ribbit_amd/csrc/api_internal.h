@@ -48,18 +48,29 @@ int fail(int code, const char *fmt, ...);
             return fail(RIBBIT_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// A device buffer that is being replaced by a larger one is released at the next record load or handle close, not on the spot:
+// hipFree synchronises with every stream of the device (api_core.cpp).
+void device_free_later(void *p);
+void pinned_free_later(void *p);
+void device_free_pending();      // (both kinds)
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;   // elements
     int ensure(size_t n) {
         if (n <= cap) return RIBBIT_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        // (half as much again as the last time at least: a buffer that grows slice by slice -- the alignment batches' -- is then
+        // released and allocated a few times per record instead of at every slice that is a little larger than the one before, and
+        // hipFree waits for every stream of the device: 20 ms each time beside another feeder's kernels, round 4)
+        n = std::max(n + std::min(n / 4, ((size_t)256 << 20) / sizeof(T)), cap + std::min(cap / 2, ((size_t)1 << 30) / sizeof(T)));      // (and some headroom: the next slice is rarely smaller)
+        if (p) { device_free_later(p); p = nullptr; cap = 0; }      // (hipFree waits for the whole device: not while another feeder's kernels run)
         // RIBBIT_PROFILE_MEMORY=<MB>: one line per device allocation of at least that size (which buffers are large, and when)
         static const size_t trace_from = std::getenv("RIBBIT_PROFILE_MEMORY") ? (size_t)std::max(1, std::atoi(std::getenv("RIBBIT_PROFILE_MEMORY"))) << 20 : 0;
         if (trace_from && n * sizeof(T) >= trace_from)
             std::fprintf(stderr, "[device memory] %.2f GB (%zu elements of %zu bytes), called from %p\n", (double)(n * sizeof(T)) * 1e-9, n, sizeof(T), __builtin_return_address(0));
         hipError_t e = hipMalloc((void **)&p, n * sizeof(T));
+        if (e != hipSuccess) { device_free_pending(); e = hipMalloc((void **)&p, n * sizeof(T)); }      // (what was put aside may be the room that is missing)
         if (e != hipSuccess) { p = nullptr; return fail(RIBBIT_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e)); }
         cap = n;
         return RIBBIT_OK;
@@ -80,7 +91,8 @@ struct PinnedBuf {
     size_t cap = 0;
     int ensure(size_t n) {
         if (n <= cap) return RIBBIT_OK;
-        if (p) { pinned_free(p); p = nullptr; cap = 0; }
+        n = std::max(n + std::min(n / 4, ((size_t)256 << 20) / sizeof(T)), cap + std::min(cap / 2, ((size_t)1 << 30) / sizeof(T)));      // (as DevBuf: unpinning waits for the device too)
+        if (p) { pinned_free_later(p); p = nullptr; cap = 0; }
         void *q = nullptr;
         const int rc = pinned_alloc(n * sizeof(T), &q);
         if (rc) return rc;
@@ -294,6 +306,7 @@ int window_stage_device(RibbitHandle *h, int which, bool full, int (*min_span)(i
 void full_calls_from_device(const DeviceCalls &dc, rb::CallVec &calls);
 int build_subst_calls(RibbitHandle *h);
 void subst_merge(RibbitHandle *h, const DeviceCalls *dc);
+double feeder_phase_ms(int k);      // (profiling: host phases of run_ssw_passes / run_ssw_paths, cumulative)
 // api_merge.cpp: the first parallel pass of the anchored stage's merge on the device (d_calls / d_pend: the stage's kept calls as
 // window_stage_device left them in device memory, d_pend null when kc.pend is)
 rb::AnchoredDevicePass anchored_device_pass(RibbitHandle *h, RibbitCall *d_calls, const int32_t *d_pend);

@@ -12,6 +12,7 @@ int ribbit_hip_refine_bed(RibbitHandle *h, const RibbitRefineParams *prm, const 
         // (the helper threads' calls report an empty query through their order_dependent flags, which end in a call on THIS thread)
         rb::refine_met_empty_query(true);
         const int rc = refine_bed_impl(h, prm, sequence_id, text, len);
+        device_free_pending();       // (buffers the alignment batches outgrew: released now that their streams are idle)
         if (h) h->refine_met_empty_query = rb::refine_met_empty_query(true);
         return rc;
     } catch (const std::bad_alloc &) {           // nothing may unwind through the C boundary
@@ -558,6 +559,8 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         if (done) join_pieces(h, pieces, threads);     // the pieces' text into place on the threads (150 MB for a chromosome)
         else h->bed.clear();                           // an empty query somewhere (or no batches): the whole record in one call (below)
         t_join = now_ms() - tj0;
+        if (profile) { std::fprintf(stderr, "[feeders' host phases, ms, cumulative] passes: order %.1f, H2D+memset enqueue %.1f, launches+kernel wait %.1f, ends D2H %.1f | paths: first loop %.1f, ensure %.1f, memsets %.1f, vectors %.1f, items %.1f, H2D+launch %.1f, kernel wait %.1f, result D2H %.1f, round loop %.1f, ops D2H %.1f, final loop %.1f\n",
+            feeder_phase_ms(0), feeder_phase_ms(1), feeder_phase_ms(2), feeder_phase_ms(3), feeder_phase_ms(12), feeder_phase_ms(13), feeder_phase_ms(14), feeder_phase_ms(4), feeder_phase_ms(5), feeder_phase_ms(6), feeder_phase_ms(7), feeder_phase_ms(8), feeder_phase_ms(9), feeder_phase_ms(10), feeder_phase_ms(11)); }
         if (profile) std::fprintf(stderr, "[refine_bed] %zu alignment jobs (%zu long ones in their own batch: %.1f ms, set up first in %.1f ms; %zu seeds set aside), set-up in all %.1f ms; %zu slices: "
                                   "feeder %.1f ms in all (GPU striped passes incl. transfers %.1f ms, GPU path search %.1f ms); workers: %.1f ms in their calls, waited %.1f ms "
                                   "for slices, %.1f ms for the long batch; seeds set aside for it %.1f ms; %zu seeds with jobs beyond the kernels' reach refined on the host beside all that in %.1f ms; "

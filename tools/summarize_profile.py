@@ -25,7 +25,7 @@ pmc = {}
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        agg[(r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in agg.items():
         # FETCH_SIZE / WRITE_SIZE are in KB; everything else is a plain count (or a percentage for VALUBusy)
         key = "mean_kb" if c in ("FETCH_SIZE", "WRITE_SIZE") else "mean"
