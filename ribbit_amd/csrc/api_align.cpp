@@ -11,15 +11,30 @@ int build_longest_runs(RibbitHandle *h) {
     if (rc) return rc;
     if ((rc = bind_device(h))) return rc;
     const size_t n = h->dispatch.size();
-    h->longest_runs.assign(n, 0);
+    h->longest_runs.resize(n);
     if (n) {
         if ((rc = h->d_seeds.ensure(n))) return rc;
         if ((rc = h->d_longest.ensure(n))) return rc;
-        HIP_TRY(hipMemcpyAsync(h->d_seeds.p, h->dispatch.data(), n * sizeof(RibbitSeed), hipMemcpyHostToDevice, h->stream));
+        // Through page-locked memory, copied on the host threads: the list is a quarter of a gigabyte for a chromosome, and a copy
+        // straight from (or to) a vector's pageable storage runs at a tenth of the link's speed on one thread.
+        if ((rc = h->h_seed_stage.ensure(n)) || (rc = h->h_longest_stage.ensure(n))) return rc;
+        unsigned nt = h->host_threads ? h->host_threads : std::min(std::thread::hardware_concurrency(), 16u);
+        if (!h->host_threads)
+            if (const char *env = std::getenv("RIBBIT_THREADS")) nt = (unsigned)std::max(1, std::atoi(env));
+        nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, n / 262144 + 1));
+        auto on_threads = [&](auto fn) {
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < nt; ++t) pool.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
+            fn((size_t)0, n / nt);
+            for (std::thread &th : pool) th.join();
+        };
+        on_threads([&](size_t lo, size_t hi) { std::memcpy(h->h_seed_stage.p + lo, h->dispatch.data() + lo, (hi - lo) * sizeof(RibbitSeed)); });
+        HIP_TRY(hipMemcpyAsync(h->d_seeds.p, h->h_seed_stage.p, n * sizeof(RibbitSeed), hipMemcpyHostToDevice, h->stream));
         rb::launch_seed_longest_runs(h->d_xa.p, h->xa_stride, h->params.min_motif, h->d_seeds.p, (int64_t)n, h->d_longest.p, h->stream);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h->longest_runs.data(), h->d_longest.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->h_longest_stage.p, h->d_longest.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        on_threads([&](size_t lo, size_t hi) { std::memcpy(h->longest_runs.data() + lo, h->h_longest_stage.p + lo, (hi - lo) * sizeof(int32_t)); });
     }
     h->longest_valid = true;
     return RIBBIT_OK;
@@ -58,10 +73,10 @@ int best_rows_of(RibbitHandle *h, const RibbitRefineParams &prm, const rb::SeedV
     if (!jobs.empty()) {
         if ((rc = bind_device(h))) return rc;
         if ((rc = h->d_sym.ensure((size_t)h->length + 16))) return rc;
-        if ((rc = h->d_seeds.ensure(jobs.size()))) return rc;
+        if ((rc = h->d_seeds_small.ensure(jobs.size()))) return rc;      // (d_seeds holds the dispatch list: the small-motif scan beside this one reads it)
         if ((rc = h->d_best.ensure(jobs.size()))) return rc;
         if (!h->sym_valid) { rb::launch_sym(h->dev_ascii_src, h->length, h->d_sym.p, h->stream); HIP_TRY(hipGetLastError()); h->sym_valid = true; }
-        HIP_TRY(hipMemcpyAsync(h->d_seeds.p, jobs.data(), jobs.size() * sizeof(RibbitSeed), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->d_seeds_small.p, jobs.data(), jobs.size() * sizeof(RibbitSeed), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemsetAsync(h->d_best.p, 0, jobs.size() * sizeof(unsigned long long), h->stream));
         // 64-row slices of every seed: {job, first row}
         std::vector<int32_t> slices;
@@ -73,7 +88,7 @@ int best_rows_of(RibbitHandle *h, const RibbitRefineParams &prm, const rb::SeedV
         if ((rc = h->d_slices.ensure(std::max<size_t>(slices.size(), 2)))) return rc;
         if (!slices.empty())
             HIP_TRY(hipMemcpyAsync(h->d_slices.p, slices.data(), slices.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-        rb::launch_long_motif_rows(h->d_sym.p, h->length, h->d_seeds.p, (int64_t)jobs.size(), h->d_slices.p,
+        rb::launch_long_motif_rows(h->d_sym.p, h->length, h->d_seeds_small.p, (int64_t)jobs.size(), h->d_slices.p,
                                    (int64_t)(slices.size() / 2), h->d_best.p, h->stream);
         HIP_TRY(hipGetLastError());
         std::vector<unsigned long long> got(jobs.size());
@@ -108,15 +123,11 @@ int build_small_motifs(RibbitHandle *h, const RibbitRefineParams &prm, hipStream
     const double t0 = now_ms();
     if ((rc = h->small_head.ensure(std::max<size_t>(4 * n, 4)))) return rc;
     h->n_small_records = 0;
-    rb::SeedVec jobs;          // reused as int4 {seed start, seed end, m, dispatch index}
-    jobs.reserve(n);
-    for (size_t i = 0; i < n; ++i) {
-        const RibbitSeed &s = h->dispatch[i];
-        if (s.mlen > 10 || s.mlen < 1 || h->longest_runs[i] < prm.continuous_ones_threshold) continue;
-        jobs.push_back(RibbitSeed{s.start, s.end, s.mlen, (int32_t)i});
-    }
-    if (jobs.empty()) {
-        for (size_t i = 0; i < n; ++i) h->small_head.p[4 * i + 3] = -1;
+    // The kernel selects the seeds itself (m <= 10, a long enough run of matches) from the dispatch list and the longest runs that
+    // build_longest_runs left on the device: until late in round 4 the host made a job list of them -- a walk over seventeen million
+    // seeds on one thread, a quarter of a gigabyte of fresh memory and its copy up: 60 of this scan's 130-160 ms for a chromosome.
+    if (n == 0) {
+        // nothing to do
     } else {
         if ((rc = bind_device(h))) return rc;
         rb::SmallMotifLimits lim{};
@@ -130,16 +141,15 @@ int build_small_motifs(RibbitHandle *h, const RibbitRefineParams &prm, hipStream
         // room for four records a seed (0.43 on average on the simulated 20-Mbp record: early reports, the one reported
         // survivor, and all classes only for the seeds with two or more) and a million more; a seed that finds the arena
         // full is left to the host
-        const size_t cap = std::min<size_t>(4 * jobs.size() + (1u << 20), 0x7fffffffu);
-        if ((rc = h->d_sym.ensure((size_t)h->length + 16)) || (rc = h->d_seeds_small.ensure(jobs.size())) || (rc = h->d_small_head.ensure(4 * n)) ||
+        const size_t cap = std::min<size_t>(4 * n + (1u << 20), 0x7fffffffu);
+        if ((rc = h->d_sym.ensure((size_t)h->length + 16)) || (rc = h->d_small_head.ensure(4 * n)) ||
             (rc = h->d_small_records.ensure(4 * cap)) || (rc = h->d_small_count.ensure(4)))
             return rc;
         if (!h->sym_valid) { rb::launch_sym(h->dev_ascii_src, h->length, h->d_sym.p, stream); HIP_TRY(hipGetLastError()); h->sym_valid = true; }
-        HIP_TRY(hipMemcpyAsync(h->d_seeds_small.p, jobs.data(), jobs.size() * sizeof(RibbitSeed), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemsetAsync(h->d_small_count.p, 0, 4 * sizeof(uint32_t), stream));
         HIP_TRY(hipMemsetAsync(h->d_small_head.p, 0xff, 4 * n * sizeof(int32_t), stream));      // flags -1: no device result
-        rb::launch_small_motifs(h->d_sym.p, h->length, h->d_seeds_small.p, (int64_t)jobs.size(), lim, h->d_small_records.p, (uint32_t)cap, h->d_small_count.p,
-                                h->d_small_head.p, stream);
+        rb::launch_small_motifs(h->d_sym.p, h->length, h->d_seeds.p, (int64_t)n, lim, h->d_small_records.p, (uint32_t)cap, h->d_small_count.p,
+                                h->d_small_head.p, stream, h->d_longest.p, prm.continuous_ones_threshold);
         HIP_TRY(hipGetLastError());
         uint32_t used = 0;
         HIP_TRY(hipMemcpyAsync(h->small_head.p, h->d_small_head.p, 4 * n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -154,7 +164,7 @@ int build_small_motifs(RibbitHandle *h, const RibbitRefineParams &prm, hipStream
         h->n_small_records = used;
     }
     static const bool profile = std::getenv("RIBBIT_PROFILE") != nullptr;
-    if (profile) std::fprintf(stderr, "[small motifs] %zu seeds on the GPU, %zu records, %.1f ms incl. transfers\n", jobs.size(), h->n_small_records, now_ms() - t0);
+    if (profile) std::fprintf(stderr, "[small motifs] %zu dispatched seeds looked at on the GPU, %zu records, %.1f ms incl. transfers\n", n, h->n_small_records, now_ms() - t0);
     h->small_valid = true;
     return RIBBIT_OK;
 }

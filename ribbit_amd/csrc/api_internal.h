@@ -213,7 +213,9 @@ struct RibbitHandle {
     bool longest_valid = false;
     std::vector<int32_t> longest_runs;
     DevBuf<RibbitSeed> d_seeds;
-    DevBuf<RibbitSeed> d_seeds_small;     // the small-motif scan's own, so that it can run beside the consensus-row scan
+    DevBuf<RibbitSeed> d_seeds_small;     // the consensus-row scan's jobs (the small-motif scan beside it reads d_seeds: the dispatch list as build_longest_runs left it)
+    PinnedBuf<RibbitSeed> h_seed_stage;   // the dispatch list on its way up
+    PinnedBuf<int32_t> h_longest_stage;   // ... and the longest runs on their way down
     DevBuf<int32_t> d_longest;
     DevBuf<uint8_t> d_sym;
     bool sym_valid = false;                                 // d_sym holds the loaded record

@@ -147,8 +147,11 @@ struct SmallMotifLimits {
     int32_t min_length[11];        // MINIMUM_LENGTH[m]
     int32_t min_units[11];         // PERFECT_UNITS[m]
 };
+// longest != null: `jobs` is the dispatch list on the device ({start, end, m, type}) and longest[i] its seeds' longest runs; the
+// kernel then selects the seeds itself (m <= 10, longest[i] >= longest_threshold) and a seed's index is its place in the list
 void launch_small_motifs(const uint8_t *sym, int64_t length, const void *jobs, int64_t njobs, const SmallMotifLimits &lim, void *records,
-                         uint32_t record_cap, uint32_t *record_count, void *head, hipStream_t stream);
+                         uint32_t record_cap, uint32_t *record_count, void *head, hipStream_t stream, const int32_t *longest = nullptr,
+                         int32_t longest_threshold = 0);
 // mostFrequentLongerMotif's row scores (parse_seed.cpp:165-243) for njobs seeds {seed_start, seed_sequence_length, m, -}:
 // best[job] = (best score << 32) | (0xffffffff - first row with that score), 0 when every row scores 0.
 // best[] must be zeroed by the caller.  blocks[nblocks] = {job, first row of a 64-row slice of that seed}: every

@@ -46,12 +46,19 @@ __device__ __forceinline__ uint32_t row_min(uint32_t v) {      // minimum over t
 // or none.
 __global__ __launch_bounds__(64) void small_motifs_kernel(const uint8_t *__restrict__ sym, int64_t length, const int4 *__restrict__ jobs,
                                                           int64_t njobs, SmallMotifLimits lim, uint4 *__restrict__ records,
-                                                          uint32_t record_cap, uint32_t *__restrict__ record_count, int4 *__restrict__ head) {
+                                                          uint32_t record_cap, uint32_t *__restrict__ record_count, int4 *__restrict__ head,
+                                                          const int32_t *__restrict__ longest, int32_t longest_threshold) {
     __shared__ uint4 early[64];
     const int64_t s = blockIdx.x;
     if (s >= njobs) return;
     const int lane = (int)threadIdx.x;
-    const int4 jb = jobs[s];
+    int4 jb = jobs[s];
+    // longest != null: `jobs` is the dispatch list itself {start, end, m, type} and this the selection the host used to make
+    // (parse_smallmotif_seed.cpp:234-236: m <= 10 and a long enough run of matches); the seed's index is its place in the list
+    if (longest) {
+        if (jb.z > 10 || jb.z < 1 || longest[s] < longest_threshold) return;
+        jb.w = (int)s;
+    }
     const int start = jb.x, end = jb.y, m = jb.z;
     const int L = (int)length;
     // the seed's sequence length: seed + one motif, cut at the first N (parse_smallmotif_seed.cpp:214-221)
@@ -132,10 +139,10 @@ __global__ __launch_bounds__(64) void small_motifs_kernel(const uint8_t *__restr
 }
 
 void launch_small_motifs(const uint8_t *sym, int64_t length, const void *jobs, int64_t njobs, const SmallMotifLimits &lim, void *records,
-                         uint32_t record_cap, uint32_t *record_count, void *head, hipStream_t stream) {
+                         uint32_t record_cap, uint32_t *record_count, void *head, hipStream_t stream, const int32_t *longest, int32_t longest_threshold) {
     if (njobs <= 0) return;
     hipLaunchKernelGGL(small_motifs_kernel, dim3((unsigned)njobs), dim3(64), 0, stream, sym, length, (const int4 *)jobs, njobs, lim,
-                       (uint4 *)records, record_cap, record_count, (int4 *)head);
+                       (uint4 *)records, record_cap, record_count, (int4 *)head, longest, longest_threshold);
 }
 
 }  // namespace rb
