@@ -273,10 +273,10 @@ int run_ssw_passes(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const 
     const size_t n_colossal = class_count[4], n_giant = class_count[3], n_huge = class_count[2], n_big = class_count[1], n_small = class_count[0];
     if (order.empty()) return RIBBIT_OK;
     tm_add(0, tq); tq = now_ms();
-    if ((rc = h->d_ssw_jobs.ensure(n * 9))) return rc;
-    if ((rc = h->d_ssw_out.ensure(n * 8))) return rc;
-    if ((rc = h->d_ssw_order.ensure(order.size()))) return rc;
-    if ((rc = h->d_ssw_pool.ensure(std::max<size_t>(pool_len, 1)))) return rc;
+    if ((rc = h->d_ssw_jobs.ensure(n * 9, true))) return rc;
+    if ((rc = h->d_ssw_out.ensure(n * 8, true))) return rc;
+    if ((rc = h->d_ssw_order.ensure(order.size(), true))) return rc;
+    if ((rc = h->d_ssw_pool.ensure(std::max<size_t>(pool_len, 1), true))) return rc;
     HIP_TRY(hipMemcpyAsync(h->d_ssw_jobs.p, jobs, n * sizeof(RibbitAlignJob), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->d_ssw_order.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     if (pool_len && !pool_resident) HIP_TRY(hipMemcpyAsync(h->d_ssw_pool.p, pool, pool_len, hipMemcpyHostToDevice, h->stream));
@@ -343,9 +343,9 @@ int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const s
     if (open.empty()) return RIBBIT_OK;
     tm_add(12, tq); tq = now_ms();
     const uint64_t path_cap = std::min<uint64_t>(worst_ops, 0xfffffff0u);
-    if ((rc = h->d_path_ops.ensure((size_t)path_cap))) return rc;
+    if ((rc = h->d_path_ops.ensure((size_t)path_cap, true))) return rc;
     if ((rc = h->d_path_count.ensure(4))) return rc;
-    if ((rc = h->d_path_result.ensure(4 * n))) return rc;
+    if ((rc = h->d_path_result.ensure(4 * n, true))) return rc;
     tm_add(13, tq); tq = now_ms();
     HIP_TRY(hipMemsetAsync(h->d_path_count.p, 0, 4 * sizeof(uint32_t), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_path_result.p, 0xff, 4 * n * sizeof(int32_t), h->stream));      // state -1: no path searched (the buffer is reused)
@@ -388,8 +388,8 @@ int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const s
             tm_add(5, tq); tq = now_ms();
             const size_t ni = at - first;
             const size_t n_narrow = first < n_narrow_all ? std::min(ni, n_narrow_all - first) : 0;
-            if ((rc = h->d_path_items.ensure(items.size())) || (rc = h->d_path_cell_off.ensure(ni)) || (rc = h->d_path_ops_off.ensure(ni)) ||
-                (rc = h->d_path_cells.ensure((size_t)std::max<uint64_t>(cells, 16))) || (rc = h->d_path_scratch.ensure((size_t)ops)))
+            if ((rc = h->d_path_items.ensure(items.size(), true)) || (rc = h->d_path_cell_off.ensure(ni, true)) || (rc = h->d_path_ops_off.ensure(ni, true)) ||
+                (rc = h->d_path_cells.ensure((size_t)std::max<uint64_t>(cells, 16), true)) || (rc = h->d_path_scratch.ensure((size_t)ops, true)))
                 return rc;
             HIP_TRY(hipMemcpyAsync(h->d_path_items.p, items.data(), items.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipMemcpyAsync(h->d_path_cell_off.p, cell_off.data(), ni * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
@@ -423,7 +423,7 @@ int run_ssw_paths(RibbitHandle *h, const RibbitAlignJob *jobs, size_t n, const s
     HIP_TRY(hipMemcpyAsync(&used, h->d_path_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (used > path_cap) return fail(RIBBIT_E_INTERNAL, "path operations overflowed their arena");
-    if ((rc = h->h_path_ops.ensure(std::max<size_t>(used, 1)))) return rc;
+    if ((rc = h->h_path_ops.ensure(std::max<size_t>(used, 1), true))) return rc;
     if (used) {
         HIP_TRY(hipMemcpyAsync(h->h_path_ops.p, h->d_path_ops.p, (size_t)used * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));

@@ -58,12 +58,13 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;   // elements
-    int ensure(size_t n) {
+    // grows: a buffer that is sized again and again within one call (the alignment batches', slice by slice) asks for half as much
+    // again as it has, at least, and a quarter of headroom: it is then released and allocated a few times per record instead of at
+    // every slice that is a little larger than the one before.  Everything else is sized exactly: callers derive region sizes
+    // from `cap` (a quarter more event capacity is a third off the perfect scan's throughput).
+    int ensure(size_t n, bool grows = false) {
         if (n <= cap) return RIBBIT_OK;
-        // (half as much again as the last time at least: a buffer that grows slice by slice -- the alignment batches' -- is then
-        // released and allocated a few times per record instead of at every slice that is a little larger than the one before, and
-        // hipFree waits for every stream of the device: 20 ms each time beside another feeder's kernels, round 4)
-        n = std::max(n + std::min(n / 4, ((size_t)256 << 20) / sizeof(T)), cap + std::min(cap / 2, ((size_t)1 << 30) / sizeof(T)));      // (and some headroom: the next slice is rarely smaller)
+        if (grows) n = std::max(n + std::min(n / 4, ((size_t)256 << 20) / sizeof(T)), cap + std::min(cap / 2, ((size_t)1 << 30) / sizeof(T)));
         if (p) { device_free_later(p); p = nullptr; cap = 0; }      // (hipFree waits for the whole device: not while another feeder's kernels run)
         // RIBBIT_PROFILE_MEMORY=<MB>: one line per device allocation of at least that size (which buffers are large, and when)
         static const size_t trace_from = std::getenv("RIBBIT_PROFILE_MEMORY") ? (size_t)std::max(1, std::atoi(std::getenv("RIBBIT_PROFILE_MEMORY"))) << 20 : 0;
@@ -89,9 +90,9 @@ template <typename T>
 struct PinnedBuf {
     T *p = nullptr;
     size_t cap = 0;
-    int ensure(size_t n) {
+    int ensure(size_t n, bool grows = false) {
         if (n <= cap) return RIBBIT_OK;
-        n = std::max(n + std::min(n / 4, ((size_t)256 << 20) / sizeof(T)), cap + std::min(cap / 2, ((size_t)1 << 30) / sizeof(T)));      // (as DevBuf: unpinning waits for the device too)
+        if (grows) n = std::max(n + std::min(n / 4, ((size_t)256 << 20) / sizeof(T)), cap + std::min(cap / 2, ((size_t)1 << 30) / sizeof(T)));      // (as DevBuf)
         if (p) { pinned_free_later(p); p = nullptr; cap = 0; }
         void *q = nullptr;
         const int rc = pinned_alloc(n * sizeof(T), &q);
