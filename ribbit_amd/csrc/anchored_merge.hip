@@ -501,12 +501,17 @@ __global__ __launch_bounds__(64) void anchored_merge_kernel(AnchoredMergeArgs a)
                         if (which < 0) continue;
                         if ((uint64_t)j >= (which ? nS : nP)) { ++guard_hits; continue; }
                         { const unsigned long long bit = 1ull << (j < 63u ? j : 63u); if (which) head_reads1 |= bit; else head_reads0 |= bit; }
-                        o_mlen = (which ? S : P)[j].mlen;
+                        const RibbitSeed now = (which ? S : P)[j];
+                        o_mlen = now.mlen;
                         if (o_mlen == f) {                                                   // logged, not made (parallel pass)
+                            // e[7]: the write would change the entry as it is NOW, and the entry lies in this range (ListRefs::HeadWrite::changed_then)
+                            const bool mine = now.end >= range_lo && now.start <= range_hi;
+                            const bool changes = now.start != o_start || now.end != o_end || now.type != RN;
                             const uint32_t at = atomicAdd(a.head_count, 1u);
                             if (at < a.head_cap) {
                                 uint32_t *e = a.head_log + 8 * (size_t)at;
-                                e[0] = kk; e[1] = (uint32_t)which; e[2] = j; e[3] = (uint32_t)o_start; e[4] = (uint32_t)o_end; e[5] = (uint32_t)o_mlen; e[6] = (uint32_t)RN; e[7] = 0u;
+                                e[0] = kk; e[1] = (uint32_t)which; e[2] = j; e[3] = (uint32_t)o_start; e[4] = (uint32_t)o_end; e[5] = (uint32_t)o_mlen; e[6] = (uint32_t)RN;
+                                e[7] = mine && changes ? 1u : 0u;
                             } else status |= AM_LOG_FULL;
                         }
                     }

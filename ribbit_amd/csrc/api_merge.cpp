@@ -108,7 +108,7 @@ bool run_device_pass(RibbitHandle *h, RibbitCall *d_calls, const int32_t *d_pend
     for (uint32_t i = 0; i < n_head; ++i) {
         const uint32_t *e = mg.h_head_log.p + 8 * (size_t)i;
         if (e[0] >= nr || e[1] > 1 || e[2] >= (e[1] ? nS : nP)) return false;
-        heads.push_back({e[0], e[1], e[2], RibbitSeed{(int32_t)e[3], (int32_t)e[4], (int32_t)e[5], (int32_t)e[6]}});
+        heads.push_back({e[0], e[1], e[2], RibbitSeed{(int32_t)e[3], (int32_t)e[4], (int32_t)e[5], (int32_t)e[6]}, e[7] != 0});
     }
     if (profile) {
         size_t slow_k = 0, merged = 0, too_slow = 0, too_many = 0, calls_on_device = 0;

@@ -701,7 +701,7 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
                     for (const AnchoredDevicePass::LogEntry &e : reads)
                         if (e.range >= lo && e.range < hi && !res[e.range].status && !host_done[e.range]) state[e.range].foreign_reads.push_back({seed_at(e.list, e.index), e.value != 0});
                     for (const AnchoredDevicePass::HeadEntry &e : heads)
-                        if (e.range >= lo && e.range < hi && !res[e.range].status && !host_done[e.range]) state[e.range].head_writes.push_back({seed_at(e.list, e.index), e.value});
+                        if (e.range >= lo && e.range < hi && !res[e.range].status && !host_done[e.range]) state[e.range].head_writes.push_back({seed_at(e.list, e.index), e.value, e.changed_then});
                 });
                 for (size_t k = 0; k < nr; ++k) if (res[k].status && !host_done[k]) host_todo.push_back(k);
                 st.device_ranges = (unsigned)(nr - host_todo.size() - host_took.load());
@@ -729,7 +729,7 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
         for (; k < nr; ++k) {
             bool redo = k > 0 && !state[k].reads_still_valid();
             int64_t changing = 0;
-            for (const ListRefs::HeadWrite &w : state[k].head_writes) changing += differs(*w.target, w.value);
+            for (const ListRefs::HeadWrite &w : state[k].head_writes) changing += w.changed_then || differs(*w.target, w.value);
             head_writes += changing;
             uint64_t ch[2] = {0, 0};
             int reach = -1;

@@ -94,7 +94,7 @@ struct AnchoredDevicePass {
         uint64_t head_reads[2] = {0, 0};
     };
     struct LogEntry { uint32_t range, list, index; int32_t value; };      // list 0 perfect, 1 substitution; value: old type / was live
-    struct HeadEntry { uint32_t range, list, index; RibbitSeed value; };
+    struct HeadEntry { uint32_t range, list, index; RibbitSeed value; bool changed_then; };      // changed_then: ListRefs::HeadWrite
     size_t min_calls = 1u << 20;          // smaller stages stay on the host threads
     size_t calls_per_range = 64;          // what the stage's calls are cut into (wherever a cut is valid)
     size_t max_range_passes = 6000;       // a range expected to take a lane more passes of its loop than this is the host threads' from the start

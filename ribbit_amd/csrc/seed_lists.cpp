@@ -533,7 +533,13 @@ Cursor2 anchored_add(ListRefs &sl, int seed_start, int seed_end, int mlen, const
                     o_mlen = (*dst)[j].mlen;
                     if (o_mlen == f) {
                         const RibbitSeed value{o_start, o_end, o_mlen, RIBBIT_RANK_N};
-                        if (sl.head_write_log) sl.head_write_log->push_back({&(*dst)[j], value});     // parallel worker: decided later
+                        if (sl.head_write_log) {                                                    // parallel worker: decided later
+                            const RibbitSeed &now = (*dst)[j];
+                            const bool mine = now.end >= sl.range_lo && now.start <= sl.range_hi;
+                            const bool changes = now.start != value.start || now.end != value.end || now.mlen != value.mlen ||
+                                                 __atomic_load_n(&now.type, __ATOMIC_RELAXED) != value.type;
+                            sl.head_write_log->push_back({&(*dst)[j], value, mine && changes});
+                        }
                         else {
                             RibbitSeed &tgt = (*dst)[j];
                             if (sl.head_changes && (tgt.start != value.start || tgt.end != value.end || tgt.mlen != value.mlen)) {

@@ -47,7 +47,11 @@ struct ListRefs {
     // i.e. entries at the HEAD of the perfect / substitution list, wherever in the record the seed lies.
     // Parallel workers log the write instead of performing it; the merge then checks that it changes nothing (the
     // usual case: the entry is retired already and is given its own coordinates) or redoes the stage in order.
-    struct HeadWrite { RibbitSeed *target; RibbitSeed value; };
+    // changed_then: the write would have changed its target as the target was WHEN it was logged, and the target lies in the worker's
+    // own range -- the calls of that range behind it then ran against the wrong entry, whatever the entry looks like by the time the
+    // ranges are walked (a later, ordinary retirement in the same range can make the logged write look like a no-op: fuzz seed 430991,
+    // found late in round 4 with ranges of one call; the reference makes the write at once, parse_anchored_shiftxor.cpp:511-522)
+    struct HeadWrite { RibbitSeed *target; RibbitSeed value; bool changed_then; };
     std::vector<HeadWrite> *head_write_log = nullptr;
     // What lets the parallel merge stay parallel when such a write does change an entry (round 3: it happens on most
     // chromosome-sized records).  head_reads[x] (x = 0 perfect, 1 substitution list): bit min(j, 63) set = the coverage code

@@ -50,6 +50,12 @@ def test_device_merge_matches_oracle(device_ranges, name, seq, m_lo, m_hi):
     _check(seq, m_lo, m_hi, name)
 
 
+def test_a_list_head_write_that_only_mattered_inside_its_own_range(device_ranges):
+    """tests/test_parallel_merge.py has the story (fuzz seed 430991): here the lane that merges the first range logs the write."""
+    seq, m_lo, m_hi = fuzz_case(430991)
+    _check(seq, m_lo, m_hi, "seed 430991")
+
+
 def test_device_merge_on_fuzz_records_and_that_it_ran(device_ranges):
     on_device = left_to_host = 0
     for seed in range(60):

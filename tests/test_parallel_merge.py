@@ -131,6 +131,22 @@ def test_ranges_that_read_a_stale_type_are_merged_again(tiny_ranges):
         _check(seq, m_lo, m_hi, f"seed {seed}")
 
 
+def test_a_list_head_write_that_only_mattered_inside_its_own_range(tiny_ranges):
+    """Fuzz seed 430991 (2 kb, -m 7 -M 28; found late in round 4 by a sweep with ranges of one call): a call of the FIRST range
+    writes a list-head entry (Q8, parse_anchored_shiftxor.cpp:511-522) that is live at that moment and that an ordinary merge of the
+    same range retires a few calls later.  The reference makes the write at once, so the calls in between see the entry retired; a
+    worker only logs it, and by the time the ranges are walked the logged write looks like a no-op.  The log now says whether the
+    write changed its target when it was made (ListRefs::HeadWrite::changed_then) and such a range is merged again with its writes
+    made.  Both the host threads' ranges and the ranges of the device pass (with a device that cannot run)."""
+    seq, m_lo, m_hi = fuzz_case(430991)
+    _check(seq, m_lo, m_hi, "seed 430991")
+    os.environ["RIBBIT_MERGE_DEVICE_RANGES"] = str(tiny_ranges)
+    try:
+        _check(seq, m_lo, m_hi, "seed 430991, device ranges")
+    finally:
+        del os.environ["RIBBIT_MERGE_DEVICE_RANGES"]
+
+
 def test_a_list_head_write_that_changes_its_entry_keeps_the_merge_parallel_and_exact(tiny_ranges):
     """Q8 (parse_anchored_shiftxor.cpp:511-522): the coverage code writes an entry at the HEAD of the perfect / substitution
     list from anywhere in the record.  On this record (generator seed 38, 300 kb, -M 30: found by a sweep, such writes are rare
