@@ -256,8 +256,13 @@ def chr1_full_path(ribbit_amd, bases: int, device: int, traffic: dict):
             dispatch = sc.dispatch_seeds(copy=False)
             t2 = time.perf_counter()
             n_lists = (int(len(perfect)), int(len(subst)), int(len(anchored)), int(len(dispatch)))
+            on_device, left_to_host, host_meanwhile, ranges, again = ribbit_amd.last_device_merge()
             passes.append({"load_and_perfect_stage_s": t1 - t0, "substitution_and_anchored_stages_s": t2 - t1, "scans_and_merges_s": t2 - t0,
-                           "merge_ms": {"substitution": sc.timing_ms(5), "anchored": sc.timing_ms(4)}})
+                           "merge_ms": {"substitution": sc.timing_ms(5), "anchored": sc.timing_ms(4)},
+                           # the anchored stage's merge: ranges its first pass merged on the GPU (one lane each), on the host threads while
+                           # that kernel ran, and after it (ranges the lanes gave up); all zero = the host threads alone
+                           "anchored_merge_ranges": {"all": ranges, "on_the_gpu": on_device, "on_host_threads_meanwhile": host_meanwhile,
+                                                     "left_by_the_gpu": left_to_host, "merged_again_by_the_walk": again}})
         kern = {"pack_kernel": sc.timing_ms(0), "scan_window_kernel<1>": sc.timing_ms(6), "scan_anchored_kernel": sc.timing_ms(7)}
         try:        # the anchored stage as two kernels: planes (anchors + composition), then the window scan of the planes
             kern["scan_anchored_kernel<planes>"], kern["scan_xa_window_kernel"] = sc.timing_ms(8), sc.timing_ms(9)

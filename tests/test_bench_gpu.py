@@ -51,6 +51,9 @@ def test_single_gpu_line_has_the_contracted_fields():
     c1 = d["chr1_full_path"]
     assert c1["verified"] is None          # (4 Mbp: the committed digest is for the full 248,956,422 bases)
     assert c1["bases"] == 4_000_000 and c1["bed_rows"] > 1000 and c1["seeds"]["anchored"] > 0 and len(c1["passes"]) == 2
+    # (4 Mbp is below the 2^20 kept calls from which the anchored merge's first pass runs on the GPU: all host threads here)
+    mr = c1["passes"][1]["anchored_merge_ranges"]
+    assert mr["all"] >= 1 and mr["on_the_gpu"] + mr["on_host_threads_meanwhile"] + mr["left_by_the_gpu"] in (0, mr["all"])
     for k in ("scan_window_kernel<1>", "scan_anchored_kernel", "scan_perfect_kernel"):
         rf2 = c1["roofline"][k]
         assert rf2["bound"] == "hbm" and rf2["kernel_ms"] > 0 and abs(rf2["frac"] - rf2["achieved"] / 8000.0) < 1e-12
