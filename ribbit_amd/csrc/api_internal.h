@@ -5,6 +5,7 @@
 //   api_perfect.cpp     the perfect stage: scan, device-side pairing, runs, calls, seeds; its chunk form
 //   api_window.cpp      the substitution and anchored stages: scans, streak pairing, window state machines, merges, dispatch order
 //   api_chunks.cpp      one chunk of a longer record (window stages) and the merging rank's half
+//   api_merge.cpp       the anchored stage's merge on the device: what parallel_merge.h's AnchoredDevicePass does on a handle
 //   api_align.cpp       the scans of the dispatched seeds, alignment jobs, batched striped passes and path searches
 //   api_refine_bed.cpp  refinement to BED text: the GPU alignment pipeline, the recursion's levels, the host-only form
 // Not part of the ABI; nothing outside ribbit_amd/csrc includes it.
