@@ -266,6 +266,9 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
         std::mutex put_off_lock;
         const rb::Deferral tree = make_deferral(&put_off, &put_off_lock);
         const rb::Deferral *const treep = tree.min_length > 0 ? &tree : nullptr;
+        const rb::Deferral *treep_now = treep;        // (the workers' and the set-aside seeds' calls: see the loop over the slices)
+        const char *level_env = std::getenv("RIBBIT_LEVEL_MIN");
+        const size_t level_batch = level_env ? (size_t)std::max(1, std::atoi(level_env)) : LEVEL_OWN_BATCH;
         if ((rc = bind_device(h))) return rc;       // before any helper thread exists: nothing to join on this way out
         std::thread long_thread, later_thread;
         struct JoinGuard {
@@ -474,9 +477,18 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
             const double tk = now_ms();
             rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
                               sequence_id, h->bed, h->host_threads, &sl.jobs, &sl.ends, &sl.paths, sl.lo, sl.hi, &order_dependent, &small,
-                              sl.job_first.data(), set_aside.data(), &pieces, nullptr, sl.lo, treep);
+                              sl.job_first.data(), set_aside.data(), &pieces, nullptr, sl.lo, treep_now);
             t_work += now_ms() - tk;
             if (order_dependent) break;
+            // Putting nodes off pays when a level fills a GPU batch of its own (refine_levels: LEVEL_OWN_BATCH nodes); nodes of smaller
+            // levels are finished by plain recursion BEHIND everything else, where the workers would have done them beside the feeders
+            // for nothing.  At -M 100 a chromosome puts 35 nodes off (80 ms at the end of 1.4 s), at -M 500 a hundred thousand: if the
+            // slices so far do not promise a batch's worth over the whole record, the rest is done where it is met.
+            if (treep_now) {
+                size_t so_far;
+                { std::lock_guard<std::mutex> lk(put_off_lock); so_far = put_off.size(); }
+                if (so_far * n_slices < level_batch * (c + 1)) treep_now = nullptr;
+            }
         }
         stop = true;
         cv.notify_all();
@@ -528,7 +540,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
                     return h->dispatch[x].end - h->dispatch[x].start > h->dispatch[y].end - h->dispatch[y].start; });
                 rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
                                   sequence_id, h->bed, h->host_threads, &lj, &le, &lp, 0, n_seeds, &order_dependent, &small, lfirst.data(), nullptr,
-                                  &pieces, &by_cost, 0, treep);
+                                  &pieces, &by_cost, 0, treep_now);
             }
             if (!stragglers.empty())
                 rb::refine_to_bed(h->host, h->host_bases ? h->host_bases : h->host_ascii.data(), *prm, h->dispatch, h->longest_runs.data(), h->best_rows.data(),
