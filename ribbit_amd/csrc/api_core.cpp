@@ -269,6 +269,7 @@ int ribbit_hip_close(RibbitHandle *h) {
     for (int k = 0; k < 2; ++k) { h->h_calls_[k].release(); h->h_flush_[k].release(); h->h_pend_[k].release(); h->h_ws_[k].release(); }
     h->h_xa.release();
     h->mg.release(); h->h_seed_stage.release(); h->h_longest_stage.release();
+    std::free(h->bed_raw); h->bed_raw = nullptr;
     if (h->ev_xa) (void)hipEventDestroy(h->ev_xa);
     if (h->ev_ssw) (void)hipEventDestroy(h->ev_ssw);
     if (h->ev_up) (void)hipEventDestroy(h->ev_up);

@@ -254,6 +254,9 @@ struct RibbitHandle {
     bool have_stage_timing[2] = {false, false};
     const uint8_t *dev_ascii_src = nullptr;
     std::string bed;
+    char *bed_raw = nullptr;              // the text of the last refinement when its pieces were joined (join_pieces: storage the copying threads touch first)
+    size_t bed_raw_len = 0, bed_raw_cap = 0;
+    bool bed_in_raw = false;              // the last ribbit_hip_refine_bed returned bed_raw, not bed
     int stage_done = STAGE_NONE;          // how far the seed lists have been advanced
     rb::SeedLists lists;
     bool refine_met_empty_query = false;  // the last ribbit_hip_refine_bed on this handle met an alignment with an empty query (ribbit_hip_refine_met_empty_query)

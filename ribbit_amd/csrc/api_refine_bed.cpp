@@ -123,13 +123,25 @@ static void join_pieces(RibbitHandle *h, std::vector<rb::BedPiece> &pieces, unsi
         return x.first_seed != y.first_seed ? x.first_seed < y.first_seed : x.path < y.path; });
     std::vector<size_t> at(pieces.size() + 1, 0);
     for (size_t k = 0; k < pieces.size(); ++k) at[k + 1] = at[k] + pieces[k].text.size();
-    h->bed.resize(at[pieces.size()]);
+    // Plain storage, not h->bed: a string constructs (zeroes) what it grows by, on one thread -- 35-45 ms for a chromosome's 150 MB on a
+    // handle's first record; here the threads that copy the pieces are also the first to touch the pages they copy into.
+    const size_t total = at[pieces.size()];
+    if (total + 1 > h->bed_raw_cap) {
+        std::free(h->bed_raw);
+        h->bed_raw_cap = total + total / 8 + 1;
+        h->bed_raw = static_cast<char *>(std::malloc(h->bed_raw_cap));
+        if (!h->bed_raw) { h->bed_raw_cap = 0; throw std::bad_alloc(); }
+    }
+    h->bed_raw[total] = '\0';
+    h->bed_raw_len = total;
+    h->bed_in_raw = true;
+    h->bed.clear();
     const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, at[pieces.size()] / (4u << 20) + 1));
     std::atomic<size_t> next_piece{0};
     auto place = [&]() {
         for (size_t k; (k = next_piece.fetch_add(64)) < pieces.size();)
             for (size_t q = k; q < std::min(pieces.size(), k + 64); ++q)
-                if (!pieces[q].text.empty()) std::memcpy(&h->bed[at[q]], pieces[q].text.data(), pieces[q].text.size());
+                if (!pieces[q].text.empty()) std::memcpy(h->bed_raw + at[q], pieces[q].text.data(), pieces[q].text.size());
     };
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < nt; ++t) pool.emplace_back(place);
@@ -144,6 +156,7 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
     if (!h->loaded) return fail(RIBBIT_E_STATE, "no record loaded");
     h->best_rows_valid = false;
     h->small_valid = false;
+    h->bed_in_raw = false;
     // cumulative over every handle of the process (ribbit-hip runs up to 64 workers through here at once): microseconds in atomics
     const double t_begin = now_ms();
     static std::atomic<int64_t> t_rows_us{0}, t_text_us{0}, t_jobs_us{0};
@@ -615,8 +628,8 @@ static int refine_bed_impl(RibbitHandle *h, const RibbitRefineParams *prm, const
     if (profile) std::fprintf(stderr, "[refine_bed] cumulative: GPU scans of the seeds %.1f ms, alignment set-up + GPU striped passes %.1f ms, host refinement + BED %.1f ms; nodes put off for GPU batches: %lld in %lld levels (%lld alignments)\n",
                               t_rows_us.load() / 1000.0, t_jobs_us.load() / 1000.0, t_text_us.load() / 1000.0,
                               (long long)g_level_counts[1].load(), (long long)g_level_counts[0].load(), (long long)g_level_counts[2].load());
-    *text = h->bed.c_str();
-    *len = h->bed.size();
+    *text = h->bed_in_raw ? h->bed_raw : h->bed.c_str();
+    *len = h->bed_in_raw ? h->bed_raw_len : h->bed.size();
     return RIBBIT_OK;
 }
 
