@@ -75,9 +75,13 @@ struct SubstReplay {
 // ------------------------------------------------------------------------------------ where to cut
 // positions covered by some interval [start, end] (closed: seeds that share a position interact)
 struct Coverage {
-    std::vector<uint64_t> w;
+    // (zero pages from the system, touched first by the threads that mark them: a vector zeroes its 31 MB per chromosome on one thread)
+    struct Free { void operator()(uint64_t *p) const { std::free(p); } };
+    std::unique_ptr<uint64_t[], Free> w;
     int64_t top;      // largest position
-    explicit Coverage(int64_t length) : w((size_t)(length / 64 + 2), 0), top(length) {}
+    explicit Coverage(int64_t length) : w(static_cast<uint64_t *>(std::calloc((size_t)(length / 64 + 2), sizeof(uint64_t)))), top(length) {
+        if (!w) throw std::bad_alloc();
+    }
     // (atomic: the intervals are marked by several threads at once, and neighbours in call order share words)
     void set(int64_t word, uint64_t bits) { __atomic_fetch_or(&w[(size_t)word], bits, __ATOMIC_RELAXED); }
     void mark(int64_t a, int64_t b) {
