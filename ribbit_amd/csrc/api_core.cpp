@@ -67,8 +67,17 @@ std::vector<void *> g_free_later, g_unpin_later;
 // A buffer that is being replaced by a larger one is released later (at the end of refinement, at a handle's close, or when an
 // allocation fails): hipFree and the unpinning calls wait for every stream of the device -- 20 ms at a time beside another feeder's
 // kernels, 240 ms of a chromosome's first refinement until round 4.
-void device_free_later(void *p) { std::lock_guard<std::mutex> lk(g_free_mu); g_free_later.push_back(p); }
-void pinned_free_later(void *p) { std::lock_guard<std::mutex> lk(g_free_mu); g_unpin_later.push_back(p); }
+void device_free_pending();
+namespace {
+// (a process that only ever scans never reaches the end of a refinement: what it has put aside is released when it has become much)
+void put_aside(std::vector<void *> &list, void *p) {
+    size_t waiting;
+    { std::lock_guard<std::mutex> lk(g_free_mu); list.push_back(p); waiting = g_free_later.size() + g_unpin_later.size(); }
+    if (waiting > 256) device_free_pending();
+}
+}
+void device_free_later(void *p) { put_aside(g_free_later, p); }
+void pinned_free_later(void *p) { put_aside(g_unpin_later, p); }
 void device_free_pending() {
     std::vector<void *> mine, pinned;
     { std::lock_guard<std::mutex> lk(g_free_mu); mine.swap(g_free_later); pinned.swap(g_unpin_later); }
