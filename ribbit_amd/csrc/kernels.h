@@ -187,6 +187,7 @@ void launch_ssw_passes(const uint8_t *ascii, int64_t length, const uint8_t *moti
 // path_ops, operations}: state 0 path found, 1 walk failed, 2 band too narrow (run again with twice the band).
 // max_band: the largest band among the items (sizes the LDS).
 constexpr int SSW_PATH_MAX_BAND = 2048;
+constexpr int SSW_PATH_CODE_TABLE = 1024;      // bytes of LDS for the motif's base codes (a longer motif is read from global memory)
 void launch_ssw_paths(const uint8_t *ascii, int64_t length, const uint8_t *motif_pool, const int32_t *jobs, const int32_t *ends,
                       const int32_t *items, const uint64_t *cell_off, const uint64_t *ops_off, int n_items, int max_band,
                       uint8_t *cells, uint32_t *ops, uint32_t *path_ops, uint32_t path_cap, uint32_t *path_count, int32_t *result,

@@ -140,14 +140,72 @@ __global__ __launch_bounds__(64) void ssw_path_kernel(const uint8_t *__restrict_
     const int lane_mod = lane % atom, chunk_mod = 64 % atom;
     int row_mod = ref_begin % atom;            // (ref_begin + first) % atom of the current row
     const uint8_t *q_at = ascii + qstart + query_begin;      // query position i of the rectangle
+    // the motif's bases as codes in LDS (a cell's reference base was a byte from global memory and a ten-way switch, per cell and
+    // row), the query's sixty-four rows at a time in a register (lane r holds row i0 + r; a row reads its own with v_readlane)
+    uint8_t *mcode = reinterpret_cast<uint8_t *>(lds + 3 * (slots + 1));
+    const bool table = atom <= SSW_PATH_CODE_TABLE;
+    if (table) for (int a = lane; a < atom; a += 64) mcode[a] = (uint8_t)path_code(motif[a]);
+    __builtin_amdgcn_wave_barrier();
+    int qcodes = 4;
     int best = 0;
+    if (row_cells <= 64) {
+        // ---- a row fits the wavefront (band <= 31: all but a few alignments of this kernel): the row above lives in REGISTERS.  Cell
+        // (i, j) is lane j - first(i); the row above is shifted by s = first(i) - first(i - 1) lanes (1 once the band has left the
+        // first column), so "above" is a wave_shl by s and "diagonal" a wave_shr by 1 - s; lanes beyond a row's cells hold 0, which is
+        // what the out-of-band neighbours and the cleared edge slot of the LDS form below read as.  No LDS, no barrier in the loop.
+        int h_prev = 0, e_prev = 0;
+        for (int i = 0; i < read_len; ++i) {
+            if ((i & 63) == 0) qcodes = i + lane < read_len ? path_code(q_at[i + lane]) : 4;
+            const int qc = __builtin_amdgcn_readlane(qcodes, i & 63);
+            const int first = max(0, i - band), last = min(ref_len - 1, i + band);
+            const int n_in_row = last - first + 1;
+            const bool shifted = i > band;
+            if (shifted) { if (++row_mod == atom) row_mod = 0; }
+            const bool live = lane < n_in_row;
+            const int h_next = __builtin_amdgcn_update_dpp(0, h_prev, 0x130, 0xf, 0xf, false);      // wave_shl:1 (lane 63 receives 0)
+            const int e_next = __builtin_amdgcn_update_dpp(0, e_prev, 0x130, 0xf, 0xf, false);
+            const int h_below = from_lane_below(h_prev, 0, lane);
+            const int up_h = shifted ? h_next : h_prev, up_e = shifted ? e_next : e_prev, dg_h = shifted ? h_prev : h_below;
+            int e = 0, g = 0, diag = 0;
+            uint8_t code = 0;
+            if (live) {
+                const int e_open = i == 0 ? -GAP_O : up_h - GAP_O;
+                const int e_ext = i == 0 ? -GAP_E : up_e - GAP_E;
+                e = max(e_open, e_ext);
+                if (e_open > e_ext) code |= E_OPENS;
+                int jm = row_mod + lane_mod;
+                if (jm >= atom) jm -= atom;
+                const int rc = table ? (int)mcode[jm] : path_code(motif[jm]);
+                diag = dg_h + ((rc == qc && rc < 4) ? 2 : -2);
+                g = max(max(e, 0), diag);
+            }
+            const int f_first = max(0 - GAP_O, 0 - GAP_E);           // the cell left of the row is out of band (h = f = 0)
+            const int inject = live ? g - GAP_O + (lane + 1) * GAP_E : INT32_MIN / 2;
+            const int before = wave_exclusive_max(inject, INT32_MIN / 2, lane);
+            const int f = max(f_first, before) - lane * GAP_E;
+            const int h = max(g, f);
+            const int h_left_cell = from_lane_below(h, 0, lane), f_left_cell = from_lane_below(f, 0, lane);
+            uint8_t *row = cell + (size_t)row_cells * i;
+            if (live) {
+                if (h_left_cell - GAP_O > f_left_cell - GAP_E) code |= F_OPENS;
+                const int e0 = max(e, 0), f0 = max(f, 0);
+                const int gap = max(e0, f0);
+                code |= gap <= diag ? FROM_DIAG : (e0 > f0 ? FROM_E : FROM_F);
+                row[lane] = code;
+                best = max(best, h);
+            } else if (lane < row_cells) row[lane] = NO_CELL;         // columns past the reference
+            h_prev = live ? h : 0;
+            e_prev = live ? e : 0;
+        }
+    } else
     for (int i = 0; i < read_len; ++i) {
+        if ((i & 63) == 0) qcodes = i + lane < read_len ? path_code(q_at[i + lane]) : 4;
         const int first = max(0, i - band), last = min(ref_len - 1, i + band);
         const int first_above = max(0, i - 1 - band);
         const int edge = min(last + 1, slots - 1);
         if (lane == 0) { h_above[0] = 0; e_above[0] = 0; h_above[edge] = 0; e_above[edge] = 0; h_row[0] = 0; }
         __builtin_amdgcn_wave_barrier();
-        const int qc = path_code(q_at[i]);
+        const int qc = __builtin_amdgcn_readlane(qcodes, i & 63);
         uint8_t *row = cell + (size_t)row_cells * i;
         int h_left = 0, f_left = 0;            // h and f of the cell left of the chunk (out of band: 0, 0)
         const int n_in_row = last - first + 1;
@@ -167,7 +225,7 @@ __global__ __launch_bounds__(64) void ssw_path_kernel(const uint8_t *__restrict_
                 if (e_open > e_ext) code |= E_OPENS;
                 int jm = base_mod + lane_mod;
                 if (jm >= atom) jm -= atom;
-                const int rc = path_code(motif[jm]);
+                const int rc = table ? (int)mcode[jm] : path_code(motif[jm]);
                 diag = h_above[above - 1] + ((rc == qc && rc < 4) ? 2 : -2);
                 g = max(max(e, 0), diag);
             }
@@ -225,8 +283,6 @@ __global__ __launch_bounds__(64) void ssw_path4_kernel(const uint8_t *__restrict
                                                        const uint64_t *__restrict__ ops_off, int n_items, uint8_t *__restrict__ cells,
                                                        uint32_t *__restrict__ ops, uint32_t *__restrict__ path_ops, uint32_t path_cap,
                                                        uint32_t *__restrict__ path_count, int32_t *__restrict__ result) {
-    constexpr int SLOTS = 2 * SSW_PATH_NARROW_BAND + 1 + 2;          // the widest row + its two edge slots
-    __shared__ int32_t lds4[4][3 * (SLOTS + 1)];
     const int lane = (int)threadIdx.x, grp = lane >> 4, gl = lane & 15;
     const int t = 4 * (int)blockIdx.x + grp;
     const bool have = t < n_items;
@@ -242,10 +298,7 @@ __global__ __launch_bounds__(64) void ssw_path4_kernel(const uint8_t *__restrict
         score = en[0]; ref_begin = en[5]; query_begin = en[6];
         ref_len = en[1] - en[5] + 1; read_len = en[2] - en[6] + 1;
     }
-    const int row_cells = 2 * band + 1, slots = row_cells + 2;
-    int32_t *h_above = lds4[grp], *e_above = h_above + (SLOTS + 1), *h_row = e_above + (SLOTS + 1);
-    for (int i = gl; i < 3 * (SLOTS + 1); i += 16) lds4[grp][i] = 0;
-    __builtin_amdgcn_wave_barrier();
+    const int row_cells = 2 * band + 1;
     uint8_t *cell = have ? cells + cell_off[t] : cells;
     const uint8_t *q_at = ascii + qstart + query_begin;
     const int lane_mod = gl % max(atom, 1);
@@ -254,30 +307,32 @@ __global__ __launch_bounds__(64) void ssw_path4_kernel(const uint8_t *__restrict
     const int most_rows = max(max(__builtin_amdgcn_readlane(my_rows, 0), __builtin_amdgcn_readlane(my_rows, 16)),
                               max(__builtin_amdgcn_readlane(my_rows, 32), __builtin_amdgcn_readlane(my_rows, 48)));
     int best = 0;
+    // the row above in registers, as in the kernel above: an alignment's 16 lanes shift it with row_shl / row_shr (lanes without a
+    // source receive 0: bound_ctrl), no LDS and no barrier in the loop
+    int h_prev = 0, e_prev = 0;
     for (int i = 0; i < most_rows; ++i) {
         const bool act = i < my_rows;                  // uniform over the 16 lanes of an alignment
         const int first = max(0, i - band), last = min(ref_len - 1, i + band);
-        const int first_above = max(0, i - 1 - band);
-        const int edge = min(last + 1, slots - 1);
-        if (act && gl == 0) { h_above[0] = 0; e_above[0] = 0; h_above[edge] = 0; e_above[edge] = 0; h_row[0] = 0; }
-        __builtin_amdgcn_wave_barrier();
-        if (act && i > band) { if (++row_mod == atom) row_mod = 0; }
+        const bool shifted = i > band;
+        if (act && shifted) { if (++row_mod == atom) row_mod = 0; }
         const int n_in_row = last - first + 1;         // <= row_cells <= 15
         const bool live = act && gl < n_in_row;
-        const int j = first + gl, u = gl + 1;
-        const int above = j - first_above + 1;
+        const int h_next = __builtin_amdgcn_update_dpp(0, h_prev, 0x101, 0xf, 0xf, true);      // row_shl:1
+        const int e_next = __builtin_amdgcn_update_dpp(0, e_prev, 0x101, 0xf, 0xf, true);
+        const int h_below = __builtin_amdgcn_update_dpp(0, h_prev, 0x111, 0xf, 0xf, true);     // row_shr:1
+        const int up_h = shifted ? h_next : h_prev, up_e = shifted ? e_next : e_prev, dg_h = shifted ? h_prev : h_below;
         int e = 0, g = 0, diag = 0;
         uint8_t code = 0;
         if (live) {
             const int qc = path_code(q_at[i]);
-            const int e_open = i == 0 ? -GAP_O : h_above[above] - GAP_O;
-            const int e_ext = i == 0 ? -GAP_E : e_above[above] - GAP_E;
+            const int e_open = i == 0 ? -GAP_O : up_h - GAP_O;
+            const int e_ext = i == 0 ? -GAP_E : up_e - GAP_E;
             e = max(e_open, e_ext);
             if (e_open > e_ext) code |= E_OPENS;
             int jm = row_mod + lane_mod;
             if (jm >= atom) jm -= atom;
             const int rc = path_code(motif[jm]);
-            diag = h_above[above - 1] + ((rc == qc && rc < 4) ? 2 : -2);
+            diag = dg_h + ((rc == qc && rc < 4) ? 2 : -2);
             g = max(max(e, 0), diag);
         }
         // F along the row, inside the alignment's 16 lanes: the cell left of the row is out of band (h = f = 0)
@@ -290,22 +345,18 @@ __global__ __launch_bounds__(64) void ssw_path4_kernel(const uint8_t *__restrict
         const int before = pdpp<0x111>(x, INT32_MIN / 2);          // row_shr:1: the first lane of a row keeps the identity
         const int f = max(f_first, before) - gl * GAP_E;
         const int h = max(g, f);
-        const int h_prev = pdpp<0x111>(h, 0), f_prev = pdpp<0x111>(f, 0);      // left of the first cell: 0, 0
+        const int h_left_cell = pdpp<0x111>(h, 0), f_left_cell = pdpp<0x111>(f, 0);      // left of the first cell: 0, 0
         if (live) {
-            if (h_prev - GAP_O > f_prev - GAP_E) code |= F_OPENS;
+            if (h_left_cell - GAP_O > f_left_cell - GAP_E) code |= F_OPENS;
             const int e0 = max(e, 0), f0 = max(f, 0);
             const int gap = max(e0, f0);
             code |= gap <= diag ? FROM_DIAG : (e0 > f0 ? FROM_E : FROM_F);
             uint8_t *row = cell + (size_t)row_cells * i;
             row[gl] = code;
-            e_above[u] = e;
-            h_row[u] = h;
             best = max(best, h);
         }
         if (act && gl >= n_in_row && gl < row_cells) cell[(size_t)row_cells * i + gl] = NO_CELL;      // columns past the reference
-        __builtin_amdgcn_wave_barrier();
-        if (live) h_above[u] = h_row[u];
-        __builtin_amdgcn_wave_barrier();
+        if (act) { h_prev = live ? h : 0; e_prev = live ? e : 0; }
     }
     // the alignment's maximum of best: over its 16 lanes
     best = max(best, pdpp<0x128>(best, best));       // row_ror:8
@@ -331,7 +382,7 @@ void launch_ssw_paths(const uint8_t *ascii, int64_t length, const uint8_t *motif
         hipLaunchKernelGGL(ssw_path4_kernel, dim3((unsigned)((n_narrow + 3) / 4)), dim3(64), 0, stream, ascii, length, motif_pool, jobs, ends, items, cell_off,
                            ops_off, n_narrow, cells, ops, path_ops, path_cap, path_count, result);
     if (n_items > n_narrow) {
-        const size_t lds = 3 * (size_t)(2 * max_band + 1 + 2 + 1) * sizeof(int32_t);
+        const size_t lds = 3 * (size_t)(2 * max_band + 1 + 2 + 1) * sizeof(int32_t) + (size_t)SSW_PATH_CODE_TABLE;      // row state + the motif's codes
         hipLaunchKernelGGL(ssw_path_kernel, dim3((unsigned)(n_items - n_narrow)), dim3(64), lds, stream, ascii, length, motif_pool, jobs, ends,
                            items + 4 * (size_t)n_narrow, cell_off + n_narrow, ops_off + n_narrow, n_items - n_narrow, cells, ops, path_ops, path_cap, path_count, result);
     }
