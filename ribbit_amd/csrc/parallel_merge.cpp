@@ -513,9 +513,13 @@ void merge_anchored_stage(SeedLists &lists, const KeptCalls &kc, unsigned thread
             return m;
         };
         std::vector<int32_t> mp, ms;
-        std::thread other([&]() { ms = running_max(lists.subst); });
-        mp = running_max(lists.perfect);
-        other.join();
+        bool other_failed = false;
+        {
+            std::thread other([&]() { try { ms = running_max(lists.subst); } catch (...) { other_failed = true; } });
+            struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join{other};      // (also on the way out of an exception)
+            mp = running_max(lists.perfect);
+        }
+        if (other_failed) throw std::bad_alloc();
         auto first_beyond = [](const std::vector<int32_t> &m, int seen) {
             if (m.empty()) return 0;
             const size_t i = (size_t)(std::upper_bound(m.begin(), m.end(), seen) - m.begin());
