@@ -2,7 +2,7 @@
 replayed through ribbit_host_replay_calls with ranges of 1 and 3 calls -- the host threads' ranges (`plain`) or the ranges of the
 GPU's pass of the anchored merge with a device that cannot run (`dev`: RIBBIT_MERGE_DEVICE_RANGES) -- against the oracle's lists,
 dispatch order and guard count.  Round 4 found fuzz seed 430991 this way (a list-head write that only mattered inside its own
-range); 140,000 records since without a mismatch.
+range); 196,000 records since without a mismatch.
 Usage: python tests/sweeps/merge_ranges_cpu_sweep.py <lo> <hi> plain|dev [scale]     (run several ranges of seeds side by side)"""
 import os
 import sys
